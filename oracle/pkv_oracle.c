@@ -1,0 +1,453 @@
+// oracle/pkv_oracle.c — CPU restatement of the reference's paged-KV hot path (see pkv_oracle.h).
+//
+// TEST INFRASTRUCTURE ONLY: the checker for tests/, smoke() and bench.py's cpu_baseline leg.
+// Parity status: PINNED against oracle/_ref (the reference compiled in place) and tests/golden/.
+//
+// This is our own scalar restatement; where the reference's result depends on its SIMD evaluation
+// order (x86 AVX2 build: 4x8-lane f32 accumulators, hsum order) we reproduce that order so that the
+// restatement agrees with oracle/_ref to the last bit wherever libm's expf/cosf/sinf allow.
+#define _GNU_SOURCE
+#include "pkv_oracle.h"
+
+#include <immintrin.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define QK 32  // QK8_0 == QK4_0 == 32 (ggml/src/ggml-common.h:155,197)
+
+static inline uint16_t f2h(float f) { return _cvtss_sh(f, 0); }  // RN-even, as GGML_FP32_TO_FP16 w/ F16C
+static inline float    h2f(uint16_t h) { return _cvtsh_ss(h); }
+
+size_t pkv_o_row_size(int type, int64_t ne) {
+    switch (type) {
+        case PKV_O_F32:  return (size_t) ne * 4;
+        case PKV_O_F16:  return (size_t) ne * 2;
+        case PKV_O_Q8_0: return (size_t) (ne / QK) * 34;  // block_q8_0 {half d; int8 qs[32]} ggml-common.h:203-208
+        case PKV_O_Q4_0: return (size_t) (ne / QK) * 18;  // block_q4_0 {half d; uint8 qs[16]} ggml-common.h:161-166
+        default: return 0;
+    }
+}
+
+void pkv_o_f32_to_f16(const float * x, uint16_t * y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = f2h(x[i]); }
+void pkv_o_f16_to_f32(const uint16_t * x, float * y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = h2f(x[i]); }
+
+// ggml/src/ggml-quants.c:194-215
+void pkv_o_quantize_q8_0_ref(const float * x, void * vy, int64_t k) {
+    uint8_t * y = (uint8_t *) vy;
+    for (int64_t i = 0; i < k / QK; ++i, y += 34) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; ++j) amax = fmaxf(amax, fabsf(x[i * QK + j]));
+        const float d  = amax / 127;
+        const float id = d ? 1.0f / d : 0.0f;
+        const uint16_t dh = f2h(d);
+        memcpy(y, &dh, 2);
+        for (int j = 0; j < QK; ++j) ((int8_t *) (y + 2))[j] = (int8_t) roundf(x[i * QK + j] * id);
+    }
+}
+
+// ggml/src/ggml-cpu/ggml-cpu-quants.c:808-862 (AVX2 branch): d = max/127, id = 127/max, _MM_ROUND_NEAREST
+void pkv_o_quantize_q8_0_cpu(const float * x, void * vy, int64_t k) {
+    uint8_t * y = (uint8_t *) vy;
+    for (int64_t i = 0; i < k / QK; ++i, y += 34) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; ++j) amax = fmaxf(amax, fabsf(x[i * QK + j]));
+        const float d  = amax / 127.f;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        const uint16_t dh = f2h(d);
+        memcpy(y, &dh, 2);
+        for (int j = 0; j < QK; ++j) ((int8_t *) (y + 2))[j] = (int8_t) nearbyintf(x[i * QK + j] * id);  // ties-to-even
+    }
+}
+
+// ggml/src/ggml-quants.c:31-66
+void pkv_o_quantize_q4_0(const float * x, void * vy, int64_t k) {
+    uint8_t * y = (uint8_t *) vy;
+    for (int64_t i = 0; i < k / QK; ++i, y += 18) {
+        float amax = 0.0f, max = 0.0f;
+        for (int j = 0; j < QK; ++j) {
+            const float v = x[i * QK + j];
+            if (amax < fabsf(v)) { amax = fabsf(v); max = v; }
+        }
+        const float d  = max / -8;
+        const float id = d ? 1.0f / d : 0.0f;
+        const uint16_t dh = f2h(d);
+        memcpy(y, &dh, 2);
+        for (int j = 0; j < QK / 2; ++j) {
+            const float x0 = x[i * QK + j] * id;
+            const float x1 = x[i * QK + QK / 2 + j] * id;
+            const int a0 = (int8_t) (x0 + 8.5f), a1 = (int8_t) (x1 + 8.5f);
+            const uint8_t q0 = (uint8_t) (a0 < 15 ? a0 : 15), q1 = (uint8_t) (a1 < 15 ? a1 : 15);
+            y[2 + j] = (uint8_t) (q0 | (q1 << 4));
+        }
+    }
+}
+
+// ggml/src/ggml-quants.c:349-362 (q8_0), :255-273 (q4_0)
+void pkv_o_to_float(int type, const void * vx, float * y, int64_t k) {
+    const uint8_t * x = (const uint8_t *) vx;
+    if (type == PKV_O_F32) { memcpy(y, vx, (size_t) k * 4); return; }
+    if (type == PKV_O_F16) { pkv_o_f16_to_f32((const uint16_t *) vx, y, k); return; }
+    for (int64_t i = 0; i < k / QK; ++i) {
+        uint16_t dh;
+        if (type == PKV_O_Q8_0) {
+            memcpy(&dh, x + i * 34, 2);
+            const float d = h2f(dh);
+            const int8_t * qs = (const int8_t *) (x + i * 34 + 2);
+            for (int j = 0; j < QK; ++j) y[i * QK + j] = qs[j] * d;
+        } else {
+            memcpy(&dh, x + i * 18, 2);
+            const float d = h2f(dh);
+            const uint8_t * qs = x + i * 18 + 2;
+            for (int j = 0; j < QK / 2; ++j) {
+                y[i * QK + j]          = ((qs[j] & 0x0F) - 8) * d;
+                y[i * QK + j + QK / 2] = ((qs[j] >> 4) - 8) * d;
+            }
+        }
+    }
+}
+
+void pkv_o_from_float(int type, const float * x, void * y, int64_t k) {
+    switch (type) {
+        case PKV_O_F32:  memcpy(y, x, (size_t) k * 4); break;
+        case PKV_O_F16:  pkv_o_f32_to_f16(x, (uint16_t *) y, k); break;
+        case PKV_O_Q8_0: pkv_o_quantize_q8_0_cpu(x, y, k); break;
+        case PKV_O_Q4_0: pkv_o_quantize_q4_0(x, y, k); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE — ggml-cpu.c:10571-10609 (yarn + cache init), :10669-10852 (apply); corr dims ggml.c:3735-3747
+static float yarn_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {
+    return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(base));
+}
+
+void pkv_o_rope(const float * x, const int32_t * pos, const float * ff, float * out,
+                int ne0, int n_head, int n_tok, int n_dims, int mode, int n_ctx_orig,
+                float freq_base, float freq_scale, float ext_factor, float attn_factor,
+                float beta_fast, float beta_slow, int inverse) {
+    const float theta_scale = powf(freq_base, -2.0f / n_dims);
+    float corr[2];
+    {
+        const float start = floorf(yarn_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base));
+        const float end   = ceilf(yarn_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));
+        corr[0] = start > 0 ? start : 0;
+        corr[1] = end < n_dims - 1 ? end : n_dims - 1;
+    }
+    const int   is_neox  = mode & 2;
+    const float sin_sign = inverse ? -1.0f : 1.0f;
+    float * cache = (float *) malloc(sizeof(float) * (size_t) ne0);
+
+    for (int t = 0; t < n_tok; ++t) {
+        float theta = (float) pos[t];
+        for (int i0 = 0; i0 < ne0; i0 += 2) {
+            const float f            = ff ? ff[i0 / 2] : 1.0f;
+            const float theta_extrap = theta / f;
+            const float theta_interp = freq_scale * theta_extrap;
+            float th = theta_interp, mscale = attn_factor;
+            if (ext_factor != 0.0f) {
+                const float hi_lo = corr[1] - corr[0];
+                const float yv    = (i0 / 2 - corr[0]) / (hi_lo > 0.001f ? hi_lo : 0.001f);
+                const float ramp  = (1 - fminf(1, fmaxf(0, yv))) * ext_factor;
+                th = theta_interp * (1 - ramp) + theta_extrap * ramp;
+                mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+            }
+            cache[i0]     = cosf(th) * mscale;
+            cache[i0 + 1] = sinf(th) * mscale * sin_sign;
+            theta *= theta_scale;
+        }
+        for (int h = 0; h < n_head; ++h) {
+            const float * s = x + ((size_t) t * n_head + h) * ne0;
+            float *       d = out + ((size_t) t * n_head + h) * ne0;
+            if (is_neox) {
+                for (int i0 = 0; i0 < n_dims; i0 += 2) {
+                    const int ic = i0 / 2;
+                    const float c = cache[i0], sn = cache[i0 + 1], x0 = s[ic], x1 = s[ic + n_dims / 2];
+                    d[ic]              = x0 * c - x1 * sn;
+                    d[ic + n_dims / 2] = x0 * sn + x1 * c;
+                }
+            } else {
+                for (int i0 = 0; i0 < n_dims; i0 += 2) {
+                    const float c = cache[i0], sn = cache[i0 + 1], x0 = s[i0], x1 = s[i0 + 1];
+                    d[i0]     = x0 * c - x1 * sn;
+                    d[i0 + 1] = x0 * sn + x1 * c;
+                }
+            }
+            for (int i0 = n_dims; i0 < ne0; ++i0) d[i0] = s[i0];
+        }
+    }
+    free(cache);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// vec dots in the reference's AVX2 evaluation order
+
+// ggml_vec_dot_f16 (ggml-cpu.c:1565-1603), GGML_F16_STEP 32 / EPR 8 / ARR 4, FMA; reduce :671-689
+static float vec_dot_f16(int n, const uint16_t * x, const uint16_t * y) {
+    float sum[4][8];
+    memset(sum, 0, sizeof(sum));
+    const int np = n & ~31;
+    for (int i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; ++j)
+            for (int l = 0; l < 8; ++l)
+                sum[j][l] = fmaf(h2f(x[i + j * 8 + l]), h2f(y[i + j * 8 + l]), sum[j][l]);
+    float t[4];
+    for (int l = 0; l < 8; ++l) { sum[0][l] += sum[2][l]; sum[1][l] += sum[3][l]; }
+    for (int l = 0; l < 8; ++l) sum[0][l] += sum[1][l];
+    for (int l = 0; l < 4; ++l) t[l] = sum[0][l] + sum[0][l + 4];
+    double sumf = (double) ((t[0] + t[1]) + (t[2] + t[3]));
+    for (int i = np; i < n; ++i) sumf += (double) (h2f(x[i]) * h2f(y[i]));
+    return (float) sumf;
+}
+
+static inline float hsum8(const float * a) {  // hsum_float_8, ggml-cpu-quants.c:49-55
+    float r[4];
+    for (int l = 0; l < 4; ++l) r[l] = a[l + 4] + a[l];
+    r[0] += r[2];
+    r[1] += r[3];
+    return r[0] + r[1];
+}
+
+// ggml_vec_dot_q8_0_q8_0 AVX2 (ggml-cpu-quants.c:3935-3952): per block 8 int32 lanes of 4 products each
+static float vec_dot_q8_0_q8_0(int n, const uint8_t * x, const uint8_t * y) {
+    float acc[8] = {0};
+    for (int ib = 0; ib < n / QK; ++ib) {
+        uint16_t dx, dy;
+        memcpy(&dx, x + ib * 34, 2);
+        memcpy(&dy, y + ib * 34, 2);
+        const float d = h2f(dx) * h2f(dy);
+        const int8_t * qx = (const int8_t *) (x + ib * 34 + 2);
+        const int8_t * qy = (const int8_t *) (y + ib * 34 + 2);
+        for (int l = 0; l < 8; ++l) {
+            int s = 0;
+            for (int j = 0; j < 4; ++j) s += (int) qx[l * 4 + j] * (int) qy[l * 4 + j];
+            acc[l] = fmaf(d, (float) s, acc[l]);
+        }
+    }
+    return hsum8(acc);
+}
+
+// ggml_vec_dot_q4_0_q8_0 AVX2 (ggml-cpu-quants.c:2273-2296): low nibbles -> elems 0..15, high -> 16..31, minus 8
+static float vec_dot_q4_0_q8_0(int n, const uint8_t * x, const uint8_t * y) {
+    float acc[8] = {0};
+    for (int ib = 0; ib < n / QK; ++ib) {
+        uint16_t dx, dy;
+        memcpy(&dx, x + ib * 18, 2);
+        memcpy(&dy, y + ib * 34, 2);
+        const float d = h2f(dx) * h2f(dy);
+        const uint8_t * qx = x + ib * 18 + 2;
+        const int8_t *  qy = (const int8_t *) (y + ib * 34 + 2);
+        int8_t e[QK];
+        for (int j = 0; j < 16; ++j) { e[j] = (int8_t) ((qx[j] & 0x0F) - 8); e[j + 16] = (int8_t) ((qx[j] >> 4) - 8); }
+        for (int l = 0; l < 8; ++l) {
+            int s = 0;
+            for (int j = 0; j < 4; ++j) s += (int) e[l * 4 + j] * (int) qy[l * 4 + j];
+            acc[l] = fmaf(d, (float) s, acc[l]);
+        }
+    }
+    return hsum8(acc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ggml_compute_forward_flash_attn_ext_f16, ggml-cpu.c:12219-12432
+int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const uint16_t * mask,
+                         float * out, float * logits,
+                         int D, int n_q, int n_head, int n_kv, int n_head_kv, int mask_stride,
+                         int type_k, int type_v, float scale, float max_bias, float logit_softcap,
+                         int n_threads) {
+    if (type_k != PKV_O_F16 && type_k != PKV_O_Q8_0 && type_k != PKV_O_Q4_0) return -1;
+    if (type_v != PKV_O_F16 && type_v != PKV_O_Q8_0 && type_v != PKV_O_Q4_0) return -1;
+    if (logit_softcap != 0) scale /= logit_softcap;                                   // :12290-12292
+    const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2(n_head));               // :12295
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2);
+    const float m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    const size_t rk = pkv_o_row_size(type_k, D), rv = pkv_o_row_size(type_v, D);
+    const int gq = n_head / n_head_kv;                                               // rk2 :12264
+    // k's vec_dot_type: f16 for f16, q8_0 for q8_0/q4_0 (type_traits_cpu, ggml-cpu.c:240-300)
+    const int q_type = type_k == PKV_O_F16 ? PKV_O_F16 : PKV_O_Q8_0;
+    const int nr = n_head * n_q;
+    if (n_threads < 1) n_threads = 1;
+
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int ir = 0; ir < nr; ++ir) {
+        const int h = ir / n_q, iq = ir % n_q;                                       // :12311-12313
+        const float slope = (max_bias > 0.0f)
+            ? ((uint32_t) h < n_head_log2 ? powf(m0, h + 1) : powf(m1, 2 * (h - n_head_log2) + 1)) : 1.0f;
+        float    S = 0.0f, M = -INFINITY;
+        float    VKQ32[512], V32[512];
+        uint16_t VKQ16[512];
+        uint8_t  Qq[512 * 2];
+        memset(VKQ32, 0, sizeof(float) * D);
+        memset(VKQ16, 0, sizeof(uint16_t) * D);
+        const uint16_t * mp = mask ? mask + (size_t) iq * mask_stride : NULL;
+        const int hk = h / gq;
+        const float * pq = q + ((size_t) h * n_q + iq) * D;
+        if (q_type == PKV_O_F16) pkv_o_f32_to_f16(pq, (uint16_t *) Qq, D);
+        else                     pkv_o_quantize_q8_0_cpu(pq, Qq, D);                 // :12343
+        float * lg = logits ? logits + ((size_t) h * n_q + iq) * n_kv : NULL;
+
+        for (int ic = 0; ic < n_kv; ++ic) {
+            const float mv = mp ? slope * h2f(mp[ic]) : 0.0f;
+            if (mv == -INFINITY) { if (lg) lg[ic] = -INFINITY; continue; }           // :12349-12352
+            const uint8_t * kd = (const uint8_t *) k + ((size_t) hk * n_kv + ic) * rk;
+            float s;
+            if (type_k == PKV_O_F16)       s = vec_dot_f16(D, (const uint16_t *) kd, (const uint16_t *) Qq);
+            else if (type_k == PKV_O_Q8_0) s = vec_dot_q8_0_q8_0(D, kd, Qq);
+            else                           s = vec_dot_q4_0_q8_0(D, kd, Qq);
+            s = s * scale;
+            if (logit_softcap != 0.0f) s = logit_softcap * tanhf(s);
+            s += mv;
+            if (lg) lg[ic] = s;
+            const float Mold = M;
+            float ms = 1.0f, vs = 1.0f;
+            const uint8_t * vd = (const uint8_t *) v + ((size_t) hk * n_kv + ic) * rv;
+            if (type_v == PKV_O_F16) {                                               // :12374-12388 (f16 accumulator)
+                if (s > M) {
+                    M = s; ms = expf(Mold - M);
+                    for (int d = 0; d < D; ++d) VKQ16[d] = f2h(h2f(VKQ16[d]) * ms);  // ggml_vec_scale_f16
+                } else {
+                    vs = expf(s - M);
+                }
+                const uint16_t * vh = (const uint16_t *) vd;
+                for (int d = 0; d < D; ++d) VKQ16[d] = f2h(fmaf(h2f(vh[d]), vs, h2f(VKQ16[d])));  // ggml_vec_mad_f16 (FMA)
+            } else {                                                                 // :12389-12406
+                if (s > M) {
+                    M = s; ms = expf(Mold - M);
+                    for (int d = 0; d < D; ++d) VKQ32[d] *= ms;
+                } else {
+                    vs = expf(s - M);
+                }
+                pkv_o_to_float(type_v, vd, V32, D);
+                for (int d = 0; d < D; ++d) VKQ32[d] = fmaf(V32[d], vs, VKQ32[d]);   // ggml_vec_mad_f32 (FMA)
+            }
+            S = S * ms + vs;                                                         // :12408
+        }
+        if (type_v == PKV_O_F16) for (int d = 0; d < D; ++d) VKQ32[d] = h2f(VKQ16[d]);
+        const float S_inv = 1.0f / S;                                                // :12418
+        float * o = out + ((size_t) iq * n_head + h) * D;                            // permuted dst :12430
+        for (int d = 0; d < D; ++d) o[d] = VKQ32[d] * S_inv;
+    }
+    return 0;
+}
+
+int pkv_o_flash_attn_f64(const float * q, const void * k, const void * v, const uint16_t * mask,
+                         double * out, int D, int n_q, int n_head, int n_kv, int n_head_kv, int mask_stride,
+                         int type_k, int type_v, float scale, float logit_softcap) {
+    const size_t rk = pkv_o_row_size(type_k, D), rv = pkv_o_row_size(type_v, D);
+    if (!rk || !rv) return -1;
+    const int gq = n_head / n_head_kv;
+    double sc = scale;
+    if (logit_softcap != 0) sc /= logit_softcap;
+#pragma omp parallel for schedule(static)
+    for (int ir = 0; ir < n_head * n_q; ++ir) {
+        const int h = ir / n_q, iq = ir % n_q, hk = h / gq;
+        const float * pq = q + ((size_t) h * n_q + iq) * D;
+        double * s = (double *) malloc(sizeof(double) * (size_t) n_kv);
+        float row[512];
+        double M = -INFINITY;
+        for (int ic = 0; ic < n_kv; ++ic) {
+            const float mv = mask ? h2f(mask[(size_t) iq * mask_stride + ic]) : 0.0f;
+            if (mv == -INFINITY) { s[ic] = -INFINITY; continue; }
+            pkv_o_to_float(type_k, (const uint8_t *) k + ((size_t) hk * n_kv + ic) * rk, row, D);
+            double acc = 0;
+            for (int d = 0; d < D; ++d) acc += (double) row[d] * (double) pq[d];
+            acc *= sc;
+            if (logit_softcap != 0) acc = logit_softcap * tanh(acc);
+            s[ic] = acc + mv;
+            if (s[ic] > M) M = s[ic];
+        }
+        double S = 0, o[512];
+        memset(o, 0, sizeof(double) * D);
+        for (int ic = 0; ic < n_kv; ++ic) {
+            if (s[ic] == -INFINITY) continue;
+            const double p = exp(s[ic] - M);
+            S += p;
+            pkv_o_to_float(type_v, (const uint8_t *) v + ((size_t) hk * n_kv + ic) * rv, row, D);
+            for (int d = 0; d < D; ++d) o[d] += p * (double) row[d];
+        }
+        double * od = out + ((size_t) iq * n_head + h) * D;
+        for (int d = 0; d < D; ++d) od[d] = o[d] / S;
+        free(s);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// paged pool layout (include/mi355_paged_kv.h "Pool layout")
+size_t pkv_o_tile_bytes(int type, int block_size, int D) {
+    switch (type) {
+        case PKV_O_F16:  return (size_t) block_size * D * 2;
+        case PKV_O_Q8_0: return (size_t) block_size * D + (size_t) block_size * (D / QK) * 2;
+        case PKV_O_Q4_0: return (size_t) block_size * D / 2 + (size_t) block_size * (D / QK) * 2;
+        default: return 0;
+    }
+}
+
+// one reference-format row (one kv head of one token) <-> its place inside a tile
+static void tile_put_row(uint8_t * tile, int type, int off, const uint8_t * row, int D, int block_size) {
+    if (type == PKV_O_F16) { memcpy(tile + (size_t) off * D * 2, row, (size_t) D * 2); return; }
+    const int nb = D / QK, qb = type == PKV_O_Q8_0 ? QK : QK / 2, bb = qb + 2;
+    uint8_t * qs = tile + (size_t) off * nb * qb;
+    uint8_t * ds = tile + (size_t) block_size * nb * qb + (size_t) off * nb * 2;
+    for (int b = 0; b < nb; ++b) {
+        memcpy(ds + b * 2, row + (size_t) b * bb, 2);
+        memcpy(qs + (size_t) b * qb, row + (size_t) b * bb + 2, qb);
+    }
+}
+static void tile_get_row(const uint8_t * tile, int type, int off, uint8_t * row, int D, int block_size) {
+    if (type == PKV_O_F16) { memcpy(row, tile + (size_t) off * D * 2, (size_t) D * 2); return; }
+    const int nb = D / QK, qb = type == PKV_O_Q8_0 ? QK : QK / 2, bb = qb + 2;
+    const uint8_t * qs = tile + (size_t) off * nb * qb;
+    const uint8_t * ds = tile + (size_t) block_size * nb * qb + (size_t) off * nb * 2;
+    for (int b = 0; b < nb; ++b) {
+        memcpy(row + (size_t) b * bb, ds + b * 2, 2);
+        memcpy(row + (size_t) b * bb + 2, qs + (size_t) b * qb, qb);
+    }
+}
+
+void pkv_o_pool_store(void * pool, int type, const void * rows, const int32_t * slot_block,
+                      const int32_t * slot_off, int n_tok, int n_head_kv, int D, int block_size) {
+    const size_t tb = pkv_o_tile_bytes(type, block_size, D), rb = pkv_o_row_size(type, D);
+    for (int t = 0; t < n_tok; ++t) {
+        if (slot_block[t] < 0) continue;
+        for (int h = 0; h < n_head_kv; ++h)
+            tile_put_row((uint8_t *) pool + ((size_t) slot_block[t] * n_head_kv + h) * tb, type, slot_off[t],
+                         (const uint8_t *) rows + ((size_t) t * n_head_kv + h) * rb, D, block_size);
+    }
+}
+
+void pkv_o_pool_gather(const void * pool, int type, const int32_t * block_table, int n_kv,
+                       int n_head_kv, int D, int block_size, void * dst) {
+    const size_t tb = pkv_o_tile_bytes(type, block_size, D), rb = pkv_o_row_size(type, D);
+    for (int h = 0; h < n_head_kv; ++h)
+        for (int i = 0; i < n_kv; ++i)
+            tile_get_row((const uint8_t *) pool + ((size_t) block_table[i / block_size] * n_head_kv + h) * tb, type,
+                         i % block_size, (uint8_t *) dst + ((size_t) h * n_kv + i) * rb, D, block_size);
+}
+
+int pkv_o_attn_paged(const float * q, const void * k_pool, const void * v_pool,
+                     const int32_t * block_table, int max_blocks, const int32_t * seq_lens,
+                     float * out, int n_seq, int n_q, int D, int n_head, int n_head_kv, int block_size,
+                     int type_k, int type_v, float scale, float logit_softcap, int n_threads) {
+    int rc = 0;
+    for (int s = 0; s < n_seq && rc == 0; ++s) {
+        const int n_kv = seq_lens[s];
+        float * o = out + (size_t) s * n_q * n_head * D;
+        if (n_kv <= 0) { memset(o, 0, sizeof(float) * (size_t) n_q * n_head * D); continue; }
+        void * kc = malloc(pkv_o_row_size(type_k, D) * (size_t) n_kv * n_head_kv);
+        void * vc = malloc(pkv_o_row_size(type_v, D) * (size_t) n_kv * n_head_kv);
+        uint16_t * mask = (uint16_t *) malloc(sizeof(uint16_t) * (size_t) n_q * n_kv);
+        pkv_o_pool_gather(k_pool, type_k, block_table + (size_t) s * max_blocks, n_kv, n_head_kv, D, block_size, kc);
+        pkv_o_pool_gather(v_pool, type_v, block_table + (size_t) s * max_blocks, n_kv, n_head_kv, D, block_size, vc);
+        // causal mask as llm_graph_input_attn_kv_unified::set_input builds it (src/llama-graph.cpp:429-468):
+        // 0 where cell.pos <= query pos, -inf otherwise
+        for (int j = 0; j < n_q; ++j) {
+            const int qpos = n_kv - n_q + j;
+            for (int i = 0; i < n_kv; ++i) mask[(size_t) j * n_kv + i] = i <= qpos ? 0x0000 : 0xFC00;
+        }
+        rc = pkv_o_flash_attn_ext(q + (size_t) s * n_q * n_head * D, kc, vc, mask, o, NULL, D, n_q, n_head, n_kv,
+                                  n_head_kv, n_kv, type_k, type_v, scale, 0.0f, logit_softcap, n_threads);
+        free(kc); free(vc); free(mask);
+    }
+    return rc;
+}

@@ -1,0 +1,88 @@
+// oracle/pkv_oracle.h — CPU restatement of the reference's paged-KV hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library; the product (llama.cpp_test_amd/csrc) never links, imports or calls it.
+//
+// Parity status: PINNED.  Every function below is checked (tests/test_oracle_vs_ref.py, dev container)
+// against the reference's own compiled CPU path (oracle/_ref, built in place from /root/reference by
+// oracle/Makefile) and, everywhere (incl. the GPU box), against the golden vectors that path produced
+// (tests/golden/*.npz, generator tests/golden/make_golden.py).
+//
+// All "reference file:line" citations are relative to /root/reference.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// numeric values follow enum ggml_type (ggml/include/ggml.h:350-360)
+enum { PKV_O_F32 = 0, PKV_O_F16 = 1, PKV_O_Q4_0 = 2, PKV_O_Q8_0 = 8 };
+
+// ggml_row_size (ggml/src/ggml.c) for the four KV-relevant types
+size_t pkv_o_row_size(int type, int64_t ne);
+
+// f32 <-> f16, round-to-nearest-even (GGML_FP32_TO_FP16 on x86 = F16C, ggml/src/ggml-impl.h)
+void pkv_o_f32_to_f16(const float * x, uint16_t * y, int64_t n);
+void pkv_o_f16_to_f32(const uint16_t * x, float * y, int64_t n);
+
+// quantize_row_q8_0_ref (ggml/src/ggml-quants.c:194-215): id = 1/d, roundf (ties away)
+void pkv_o_quantize_q8_0_ref(const float * x, void * y, int64_t k);
+// quantize_row_q8_0, x86 AVX2 branch (ggml/src/ggml-cpu/ggml-cpu-quants.c:808-862): id = 127/amax, ties-to-even.
+// This is what ggml_cpy(f32 -> q8_0) and the flash-attn Q conversion run on the reference's CPU backend.
+void pkv_o_quantize_q8_0_cpu(const float * x, void * y, int64_t k);
+// quantize_row_q4_0(_ref) (ggml/src/ggml-quants.c:31-66; CPU from_float forwards to it, ggml-cpu-quants.c:722)
+void pkv_o_quantize_q4_0(const float * x, void * y, int64_t k);
+// dequantize_row_{q8_0,q4_0} (ggml/src/ggml-quants.c:349-362, :255-273), f16 -> f32
+void pkv_o_to_float(int type, const void * x, float * y, int64_t k);
+// what ggml_cpy(f32 -> type) stores on the CPU backend (ggml_compute_forward_dup_f32, ggml-cpu.c:3742)
+void pkv_o_from_float(int type, const float * x, void * y, int64_t k);
+
+// ggml_compute_forward_rope_f32 (ggml/src/ggml-cpu/ggml-cpu.c:10669-10852), modes NORM (0) and NEOX (2),
+// incl. YaRN (rope_yarn :10578, corr dims ggml.c ggml_rope_yarn_corr_dims) and freq_factors.
+// x,out: f32 [n_tok][n_head][ne0]; pos: i32 [n_tok]; ff: f32 [n_dims/2] or NULL.  inverse != 0 flips sin.
+void pkv_o_rope(const float * x, const int32_t * pos, const float * ff, float * out,
+                int ne0, int n_head, int n_tok, int n_dims, int mode, int n_ctx_orig,
+                float freq_base, float freq_scale, float ext_factor, float attn_factor,
+                float beta_fast, float beta_slow, int inverse);
+
+// ggml_compute_forward_flash_attn_ext_f16 (ggml/src/ggml-cpu/ggml-cpu.c:12219-12432).
+// q: f32 [n_head][n_q][D]; k,v: reference-format rows [n_head_kv][n_kv][row_size(type,D)];
+// mask: f16 [>=n_q][n_kv] or NULL; out: f32 [n_q][n_head][D].  Returns 0, or -1 for unsupported types.
+// logits (optional, may be NULL): f32 [n_head][n_q][n_kv] = the post-scale/softcap/mask KQ value `s`
+// of :12359-12365 (-inf where the mask skips the cell) — the "attention logits" of the north-star tolerance.
+int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const uint16_t * mask,
+                         float * out, float * logits,
+                         int D, int n_q, int n_head, int n_kv, int n_head_kv, int mask_stride,
+                         int type_k, int type_v, float scale, float max_bias, float logit_softcap,
+                         int n_threads);
+
+// Same contraction in double precision on dequantized K/V and unrounded Q (accuracy yardstick, not parity).
+int pkv_o_flash_attn_f64(const float * q, const void * k, const void * v, const uint16_t * mask,
+                         double * out, int D, int n_q, int n_head, int n_kv, int n_head_kv, int mask_stride,
+                         int type_k, int type_v, float scale, float logit_softcap);
+
+// ---- paged pool layout (defined by include/mi355_paged_kv.h "Pool layout") -------------------------
+// tile(block b, kv-head h) = [block_size tokens][D] of type; quantized types keep the quants first and the
+// per-32 f16 scales after them inside the tile.
+size_t pkv_o_tile_bytes(int type, int block_size, int D);
+// scatter reference-format rows (rows: [n_tok][n_head_kv][row_size(type,D)], i.e. one KV-cache row per token,
+// src/llama-kv-cache.cpp:100) into the pool at (slot_block[t], slot_off[t]).
+void pkv_o_pool_store(void * pool, int type, const void * rows, const int32_t * slot_block,
+                      const int32_t * slot_off, int n_tok, int n_head_kv, int D, int block_size);
+// de-page: logical token i of the sequence lives in block_table[i / block_size] at offset i % block_size.
+// dst: reference-format [n_head_kv][n_kv][row_size(type,D)] (the layout k/v have in pkv_o_flash_attn_ext).
+void pkv_o_pool_gather(const void * pool, int type, const int32_t * block_table, int n_kv,
+                       int n_head_kv, int D, int block_size, void * dst);
+// paged attention for n_seq independent sequences, one or more query tokens each, causal by position:
+// query j of sequence s (q_pos = seq_lens[s] - n_q + j) sees logical tokens i <= q_pos.
+// q/out: [n_seq][...] concatenation of the per-sequence layouts above.  gather + flash_attn_ext.
+int pkv_o_attn_paged(const float * q, const void * k_pool, const void * v_pool,
+                     const int32_t * block_table, int max_blocks, const int32_t * seq_lens,
+                     float * out, int n_seq, int n_q, int D, int n_head, int n_head_kv, int block_size,
+                     int type_k, int type_v, float scale, float logit_softcap, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
