@@ -1,0 +1,239 @@
+/* mi355_paged_kv.h — C ABI of the MI355X-native paged-KV-cache attention path for llama.cpp.
+ *
+ * Drop-in boundary for ONE hot path of the reference (KwanyoungCho/llama.cpp_test, "/ref" below =
+ * /root/reference): KV store (+RoPE), block-table gather, paged single-token decode attention,
+ * flash-style prefill attention, in-place K-shift, and the host block manager behind the
+ * llama_kv_cache_* method set.  Everything here is `extern "C"`, plain pointers and sizes; device
+ * pointers are raw HIP device addresses, `stream` is a hipStream_t passed as void*.
+ * The library (libmi355_paged_kv.so) links only libamdhip64; there is NO CPU fallback: every compute
+ * entry point returns PKV_ERR_NO_DEVICE when no gfx950 device/code object is available.
+ *
+ * Reference interfaces each group replaces are cited as /ref/<file>:<line>.
+ *
+ * ---------------------------------------------------------------------------------------------
+ * Pool layout (private to this library; reference bytes only cross the boundary via
+ * pkv_pool_scatter_rows / pkv_pool_gather_rows):
+ *
+ *   One pool per layer and per K/V, replacing the flat ring `k_l[il]` / `v_l[il]`
+ *   (/ref/src/llama-kv-cache.cpp:100-101).  pool = [n_blocks][n_head_kv] tiles; tile(b,h) holds
+ *   block_size (128) consecutive logical tokens of ONE kv head, so the per-head tile the decode kernel
+ *   streams is contiguous (the reference's per-head view is 256 B every 2048 B,
+ *   /ref/src/llama-graph.cpp:1414-1419):
+ *     f16  : half  e[block_size][D]                                  (32 KiB at 128x128)
+ *     q8_0 : quants then half scales, 17 KiB -- block_q8_0 (/ref/ggml/src/ggml-common.h:203-208: 34 B,
+ *            2-B aligned) split so that every 16-B lane load is aligned:
+ *              K pool: int8 qs[tok][D],             half d[tok][D/32]
+ *              V pool: int8 qs[tok/2][D/8][2][8],   half d[tok/2][D/32][2]   (token pairs interleaved per
+ *                      8-d group: one 16-B load = 8 d of 2 tokens, so PV keeps 8 accumulators per lane)
+ *     q4_0 : quants then half scales, 9 KiB (/ref/ggml/src/ggml-common.h:161-166):
+ *              K pool: uint8 qs[tok][D/2] (per 32-block byte j = elem j | elem j+16 << 4, as block_q4_0),
+ *                      half d[tok][D/32]
+ *              V pool: uint8 qs[tok/4][D/8][4][4] (byte m = d 2m | d 2m+1 << 4), half d[tok/4][D/32][4]
+ *   tile offset = (b * n_head_kv + h) * pkv_tile_bytes(type, block_size, D); K and V tiles of a type have
+ *   the same size; functions that touch tile contents take `is_v` to select the layout.
+ *   Bytes per token are identical to the reference's row sizes (2048 / 1088 / 576 B per 1024 elems).
+ * ---------------------------------------------------------------------------------------------
+ */
+#ifndef MI355_PAGED_KV_H
+#define MI355_PAGED_KV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PKV_ABI_VERSION 1
+
+/* values follow enum ggml_type (/ref/ggml/include/ggml.h:351-360) */
+enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8 };
+
+enum pkv_status {
+    PKV_OK              =  0,
+    PKV_ERR_INVALID     = -1, /* bad argument (shape/type/alignment) — nothing was launched        */
+    PKV_ERR_NO_DEVICE   = -2, /* no HIP device / kernel image for this GPU — there is no CPU path   */
+    PKV_ERR_HIP         = -3, /* a HIP call failed; pkv_last_error() has the text                   */
+    PKV_ERR_NO_SPACE    = -4, /* block pool exhausted (find_slot failure, /ref/src/llama-kv-cache.cpp:654) */
+    PKV_ERR_UNSUPPORTED = -5  /* valid in the reference but outside this path (e.g. ALiBi max_bias) */
+};
+
+int          pkv_abi_version(void);
+const char * pkv_last_error(void);              /* thread-local text of the last non-OK status     */
+int          pkv_device_count(void);            /* number of visible gfx950 devices (0 on CPU box) */
+const char * pkv_device_arch(int device);       /* e.g. "gfx950"; NULL if no such device            */
+
+size_t pkv_row_size  (int type, int64_t ne);                    /* = ggml_row_size, /ref/ggml/include/ggml.h:651 */
+size_t pkv_tile_bytes(int type, int block_size, int head_dim);   /* see "Pool layout"               */
+size_t pkv_pool_bytes(int type, int n_blocks, int n_head_kv, int block_size, int head_dim);
+
+/* RoPE parameters = op_params of GGML_OP_ROPE (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10681-10693) */
+typedef struct pkv_rope_params {
+    int32_t n_dims;        /* op_params[1]                                   */
+    int32_t mode;          /* op_params[2]; 0 = NORM (llama), 2 = NEOX        */
+    int32_t n_ctx_orig;    /* op_params[4]                                   */
+    float   freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow; /* [5..10]        */
+    const float * freq_factors; /* device f32 [n_dims/2] or NULL (src[2], llama-3 rope_freqs)       */
+} pkv_rope_params;
+
+/* ---- kernels (stateless) ------------------------------------------------------------------- */
+
+/* RoPE on activations: replaces ggml_rope_ext on Q/K in llm_build_llama (/ref/src/llama-model.cpp:4091-4102),
+ * CPU kernel ggml_compute_forward_rope_f32 (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10669).
+ * x,out: device f32 [n_tok][n_head][head_dim] (out may alias x); pos: device i32 [n_tok]. */
+int pkv_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, int n_head, int head_dim,
+                 const pkv_rope_params * rope, int inverse, void * stream);
+
+/* KV store: replaces ggml_cpy(k_cur -> k_cache_view) / (v_cur -> v_cache_view) in build_attn
+ * (/ref/src/llama-graph.cpp:1367-1398), CPU kernel ggml_compute_forward_dup_f32 + from_float
+ * (/ref/ggml/src/ggml-cpu/ggml-cpu.c:3742, ggml-cpu-quants.c:738).
+ * k_cur,v_cur: device f32 [n_tok][n_head_kv][head_dim].  Token t goes to block slot_block[t], offset
+ * slot_off[t] (slot_block[t] < 0 = skip).  If `rope` != NULL, K is rotated with pos[t] first (fused
+ * ggml_rope_ext + ggml_cpy).  Either of k_cur/v_cur may be NULL to store only the other. */
+int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool,
+                 int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off,
+                 const int32_t * pos, const pkv_rope_params * rope,
+                 int n_tok, int n_head_kv, int head_dim, int block_size, void * stream);
+
+/* Paged attention, one launch for all sequences of a micro-batch: replaces the K/V "gather" views +
+ * ggml_flash_attn_ext of build_attn / build_attn_mha (/ref/src/llama-graph.cpp:1404-1432, :1160-1250),
+ * CPU kernel ggml_compute_forward_flash_attn_ext_f16 (/ref/ggml/src/ggml-cpu/ggml-cpu.c:12219), and the dense
+ * KQ_mask built on the host per step (/ref/src/llama-graph.cpp:403-468), which becomes (seq_lens, block_table). */
+typedef struct pkv_attn_args {
+    const float *   q;            /* device f32; token t, head h at q + t*q_stride_tok + h*q_stride_head      */
+    int64_t         q_stride_tok, q_stride_head; /* in floats; contiguous [n_tok][n_head][D] = (n_head*D, D)    */
+    float *         out;          /* device f32 [n_tok][n_head][head_dim]  (ggml dst [D, n_head, n_tok])       */
+    const void *    k_pool;       /* this layer's pools, "Pool layout"                                         */
+    const void *    v_pool;
+    const int32_t * block_table;  /* device i32 [n_seq][max_blocks]: logical block -> physical block          */
+    const int32_t * seq_lens;     /* device i32 [n_seq]: logical KV length INCLUDING this step's tokens        */
+    const int32_t * q_start;      /* device i32 [n_seq+1] token offsets per sequence; NULL = one token per seq  */
+    const int32_t * slot_pos;     /* device i32 [n_seq][max_blocks*block_size] cell positions for irregular     */
+                                  /* sequences (holes after seq_rm / seq_add), -1 = empty; NULL = slot i has pos i */
+    const int32_t * q_pos;        /* device i32 [n_tok] query positions (only read when slot_pos != NULL)       */
+    void *          workspace;    /* device scratch, >= pkv_attn_workspace_bytes(...)                           */
+    size_t          workspace_bytes;
+    int32_t n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, head_dim, block_size, max_blocks;
+    int32_t type_k, type_v;
+    float   scale;                /* op_params[0], 1/sqrt(head_dim) for llama (/ref/src/llama-model.cpp:4054)   */
+    float   logit_softcap;        /* op_params[2]; 0 = off.  max_bias (ALiBi) != 0 is PKV_ERR_UNSUPPORTED       */
+    int32_t max_seq_len;          /* upper bound of seq_lens[] known on the host (sizes the split-KV grid)      */
+    int32_t flags;                /* PKV_ATTN_* bits                                                            */
+} pkv_attn_args;
+
+/* leave the per-block (m, l, O) partials in `workspace` and skip the merge launch (measurement / callers that
+ * merge elsewhere); `out` is not written */
+#define PKV_ATTN_NO_COMBINE 1
+
+size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq_len, int block_size);
+/* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks */
+int pkv_attn_decode(const pkv_attn_args * args, void * stream);
+/* batched prefill (many query tokens per sequence, causal): MFMA QK^T / PV */
+int pkv_attn_prefill(const pkv_attn_args * args, void * stream);
+
+/* In-place K-shift: replaces build_kv_self_shift / build_rope_shift (/ref/src/llama-context.cpp:447-571).
+ * For each listed cell rotate the cached K row of every kv head by `delta` positions (f16 in place; quantized:
+ * dequantize -> rope -> requantize, as :469-487).  cell i = (cell_block[i], cell_off[i]), shift cell_delta[i]. */
+int pkv_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,
+                const int32_t * cell_delta, int n_cells, int n_head_kv, int head_dim, int block_size,
+                const pkv_rope_params * rope, void * stream);
+
+/* Block copy (copy-on-write / defrag moves): replaces the ggml_cpy row-range moves of build_kv_self_defrag
+ * (/ref/src/llama-context.cpp:653-711).  Copies whole blocks src[i] -> dst[i] inside one pool. */
+int pkv_copy_blocks(void * pool, int type, const int32_t * src, const int32_t * dst, int n,
+                    int n_head_kv, int head_dim, int block_size, void * stream);
+
+/* Reference-format row I/O: what ggml_backend_tensor_set/get on k_l[il]/v_l[il] do for session files
+ * (/ref/src/llama-kv-cache.cpp:904-1001 write, :1105-1221 read) and for test-backend-ops
+ * (/ref/tests/test-backend-ops.cpp:471).  rows: device bytes [n_tok][n_head_kv][pkv_row_size(type, head_dim)],
+ * i.e. one KV-cache row per token exactly as the reference lays it out. */
+int pkv_pool_scatter_rows(void * pool, int type, int is_v, const void * rows, const int32_t * slot_block,
+                          const int32_t * slot_off, int n_tok, int n_head_kv, int head_dim, int block_size,
+                          void * stream);
+int pkv_pool_gather_rows(const void * pool, int type, int is_v, void * rows, const int32_t * slot_block,
+                         const int32_t * slot_off, int n_tok, int n_head_kv, int head_dim, int block_size,
+                         void * stream);
+
+/* ---- host block manager: the llama_kv_cache method set -------------------------------------- */
+/* Opaque paged cache = llama_kv_cache_unified re-designed around a block table
+ * (/ref/src/llama-kv-cache.h:63-178).  Owns the per-layer device pools unless created with n_layer == 0
+ * (host-only bookkeeping, usable without a GPU). */
+typedef struct pkv_cache pkv_cache;
+
+typedef struct pkv_cache_params {
+    int32_t n_layer;         /* 0 = bookkeeping only, no device memory                             */
+    int32_t n_head_kv, head_dim;
+    int32_t type_k, type_v;  /* cparams type_k/type_v (/ref/include/llama.h:313-346)                */
+    int32_t block_size;      /* tokens per block; 128                                               */
+    int32_t n_blocks;        /* pool capacity; kv_size = n_blocks * block_size cells                */
+    int32_t n_seq_max;       /* llama_context_params.n_seq_max                                      */
+    int32_t device;          /* HIP device ordinal                                                  */
+    int32_t evict_when_full; /* 0: allocation failure is reported (default); 1: the fork prototype's
+                                BlockManager policy — evict the lowest allocated block               */
+} pkv_cache_params;
+
+pkv_cache * pkv_cache_create(const pkv_cache_params * p);
+void        pkv_cache_free  (pkv_cache * c);
+
+/* llama_kv_cache_* C wrappers (/ref/src/llama-kv-cache.cpp:1227-1332): same names, argument meaning
+ * and NULL-tolerance. p0 < 0 means 0, p1 < 0 means +inf (/ref/src/llama-kv-cache.cpp:176-182). */
+int32_t pkv_cache_n_tokens   (const pkv_cache * c);
+int32_t pkv_cache_used_cells (const pkv_cache * c);
+void    pkv_cache_clear      (pkv_cache * c);
+int     pkv_cache_seq_rm     (pkv_cache * c, int32_t seq_id, int32_t p0, int32_t p1);     /* bool */
+void    pkv_cache_seq_cp     (pkv_cache * c, int32_t seq_src, int32_t seq_dst, int32_t p0, int32_t p1);
+void    pkv_cache_seq_keep   (pkv_cache * c, int32_t seq_id);
+void    pkv_cache_seq_add    (pkv_cache * c, int32_t seq_id, int32_t p0, int32_t p1, int32_t delta);
+void    pkv_cache_seq_div    (pkv_cache * c, int32_t seq_id, int32_t p0, int32_t p1, int32_t d);
+int32_t pkv_cache_seq_pos_max(pkv_cache * c, int32_t seq_id);
+void    pkv_cache_defrag     (pkv_cache * c);
+int     pkv_cache_can_shift  (const pkv_cache * c);                                       /* bool */
+
+/* find_slot (/ref/src/llama-kv-cache.cpp:453-672, non-recurrent branch): place the n_tok tokens of a
+ * ubatch (token t belongs to sequence seq_id[t] at position pos[t]) and return their cells.
+ * out_block/out_off (host, n_tok each) receive the physical block and in-block offset of every token.
+ * Returns PKV_OK or PKV_ERR_NO_SPACE (nothing is modified on failure, as the reference's find_slot). */
+int pkv_cache_find_slot(pkv_cache * c, int n_tok, const int32_t * seq_id, const int32_t * pos,
+                        int32_t * out_block, int32_t * out_off);
+
+/* block-table introspection (host) */
+int32_t pkv_cache_seq_len      (const pkv_cache * c, int32_t seq_id);              /* logical cells   */
+int32_t pkv_cache_seq_n_blocks (const pkv_cache * c, int32_t seq_id);
+int32_t pkv_cache_seq_blocks   (const pkv_cache * c, int32_t seq_id, int32_t * out, int32_t cap);
+int32_t pkv_cache_seq_is_regular(const pkv_cache * c, int32_t seq_id);            /* pos[i]==i ∀i     */
+int32_t pkv_cache_seq_slot_pos (const pkv_cache * c, int32_t seq_id, int32_t * out, int32_t cap);
+int32_t pkv_cache_n_free_blocks(const pkv_cache * c);
+int32_t pkv_cache_block_refcount(const pkv_cache * c, int32_t block);
+int32_t pkv_cache_has_shift    (const pkv_cache * c);
+/* device work queued by host edits and not yet applied by pkv_cache_update: rows of
+ * {is_cell_copy, src_block, src_off, dst_block, dst_off} (whole-block copy-on-write copies have offsets 0) */
+int32_t pkv_cache_n_pending    (const pkv_cache * c);
+int32_t pkv_cache_pending      (const pkv_cache * c, int32_t * out5, int32_t cap);
+
+/* device side of the cache (n_layer > 0) */
+void * pkv_cache_k_pool(pkv_cache * c, int layer);
+void * pkv_cache_v_pool(pkv_cache * c, int layer);
+/* kv_self_update (/ref/src/llama-context.cpp:719-803): apply pending copy-on-write block copies and the
+ * pending K-shift (has_shift) to every layer on `stream`, then clear the deltas. */
+int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream);
+
+/* ---- the fork prototype's toy classes (sources absent from /ref; semantics recovered from
+ * /ref/tests/test_block_manager.cpp, test_kv_cache.cpp, test_block_kv_cache.cpp and the ELF symbols,
+ * SURVEY.md §8(a-toy)) ---------------------------------------------------------------------------- */
+typedef struct pkv_toy_block_manager pkv_toy_block_manager;
+pkv_toy_block_manager * pkv_toy_bm_create(int n_blocks);
+void pkv_toy_bm_free    (pkv_toy_block_manager * bm);
+int  pkv_toy_bm_allocate(pkv_toy_block_manager * bm);            /* BlockManager::allocateBlock  */
+void pkv_toy_bm_release (pkv_toy_block_manager * bm, int block); /* BlockManager::freeBlock      */
+int  pkv_toy_bm_status  (const pkv_toy_block_manager * bm, uint8_t * out, int cap); /* getBlockStatus */
+
+typedef struct pkv_toy_kv_manager pkv_toy_kv_manager;            /* KVCacheManager + PhysicalBlock */
+pkv_toy_kv_manager * pkv_toy_kvm_create(int slot_capacity);
+void pkv_toy_kvm_free  (pkv_toy_kv_manager * m);
+int  pkv_toy_kvm_insert(pkv_toy_kv_manager * m, int * physical_block, int * slot); /* VirtualBlockEntry */
+int  pkv_toy_kvm_release(pkv_toy_kv_manager * m, int physical_block, int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_PAGED_KV_H */

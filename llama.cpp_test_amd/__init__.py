@@ -1,0 +1,346 @@
+"""llama.cpp_test_amd — MI355X-native paged-KV-cache attention path for llama.cpp (host-side Python mirror).
+
+This package is a THIN ctypes binding over the C ABI in include/mi355_paged_kv.h
+(libmi355_paged_kv.so = hand-written HIP kernels for gfx950 + the C++ host block manager).  It mirrors the
+reference's interface for this path — the `llama_kv_cache_*` method set (/root/reference/src/llama-kv-cache.h:17-26,
+/root/reference/src/llama-memory.h:7-21) and the three graph ops of `build_attn` (KV store, RoPE, flash-attn;
+/root/reference/src/llama-graph.cpp:1340-1432) — so that the parity tests read like the reference's own tests.
+
+There is NO fallback: if the shared library is missing the import of any symbol raises, and every compute entry
+point raises `PkvError` when no gfx950 device is present.  PyTorch is only plumbing here (device buffers, streams):
+every tensor argument is reduced to a raw device pointer before crossing the C ABI.
+
+The directory name contains a dot, so the package is loaded by path (see `_load_pkg.py` at the repo root) under the
+module name `llama_cpp_test_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_paged_kv.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355_paged_kv.h")
+
+# enum pkv_type (= enum ggml_type values)
+F32, F16, Q4_0, Q8_0 = 0, 1, 2, 8
+TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0}
+# enum pkv_status
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SPACE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+ATTN_NO_COMBINE = 1
+
+
+class PkvError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"pkv status {status}: {msg}")
+        self.status = status
+
+
+class RopeParams(C.Structure):
+    """pkv_rope_params = op_params of GGML_OP_ROPE (/root/reference/ggml/src/ggml-cpu/ggml-cpu.c:10681-10693)"""
+    _fields_ = [("n_dims", C.c_int32), ("mode", C.c_int32), ("n_ctx_orig", C.c_int32),
+                ("freq_base", C.c_float), ("freq_scale", C.c_float), ("ext_factor", C.c_float),
+                ("attn_factor", C.c_float), ("beta_fast", C.c_float), ("beta_slow", C.c_float),
+                ("freq_factors", C.c_void_p)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("q_stride_tok", C.c_int64), ("q_stride_head", C.c_int64), ("out", C.c_void_p),
+                ("k_pool", C.c_void_p), ("v_pool", C.c_void_p), ("block_table", C.c_void_p), ("seq_lens", C.c_void_p),
+                ("q_start", C.c_void_p), ("slot_pos", C.c_void_p), ("q_pos", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t),
+                ("n_seq", C.c_int32), ("n_tok", C.c_int32), ("max_q_per_seq", C.c_int32), ("n_head", C.c_int32),
+                ("n_head_kv", C.c_int32), ("head_dim", C.c_int32), ("block_size", C.c_int32), ("max_blocks", C.c_int32),
+                ("type_k", C.c_int32), ("type_v", C.c_int32), ("scale", C.c_float), ("logit_softcap", C.c_float),
+                ("max_seq_len", C.c_int32), ("flags", C.c_int32)]
+
+
+class CacheParams(C.Structure):
+    _fields_ = [("n_layer", C.c_int32), ("n_head_kv", C.c_int32), ("head_dim", C.c_int32), ("type_k", C.c_int32),
+                ("type_v", C.c_int32), ("block_size", C.c_int32), ("n_blocks", C.c_int32), ("n_seq_max", C.c_int32),
+                ("device", C.c_int32), ("evict_when_full", C.c_int32)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The C-ABI library.  Fails loudly when it has not been built (no Python/CPU substitute exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); this path has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.pkv_last_error.restype = C.c_char_p
+        L.pkv_device_arch.restype = C.c_char_p
+        for f in ("pkv_row_size", "pkv_tile_bytes", "pkv_pool_bytes", "pkv_attn_workspace_bytes"):
+            getattr(L, f).restype = C.c_size_t
+        L.pkv_row_size.argtypes = [C.c_int, C.c_int64]
+        L.pkv_cache_create.restype = C.c_void_p
+        L.pkv_cache_create.argtypes = [C.POINTER(CacheParams)]
+        for f in ("pkv_cache_k_pool", "pkv_cache_v_pool", "pkv_toy_bm_create", "pkv_toy_kvm_create"):
+            getattr(L, f).restype = C.c_void_p
+        for f in ("pkv_cache_free", "pkv_cache_clear", "pkv_cache_seq_cp", "pkv_cache_seq_keep", "pkv_cache_seq_add",
+                  "pkv_cache_seq_div", "pkv_cache_defrag", "pkv_toy_bm_free", "pkv_toy_bm_release", "pkv_toy_kvm_free"):
+            getattr(L, f).restype = None
+        if L.pkv_abi_version() != 1:
+            raise RuntimeError("libmi355_paged_kv.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise PkvError(rc, lib().pkv_last_error().decode())
+
+
+def device_count() -> int:
+    return lib().pkv_device_count()
+
+
+def _ptr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError(f"expected a device tensor or an address, got {type(x)}")
+
+
+def _stream(stream=None) -> int:
+    if stream is not None:
+        return stream if isinstance(stream, int) else stream.cuda_stream
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def row_size(t: int, ne: int) -> int:
+    return lib().pkv_row_size(t, ne)
+
+
+def tile_bytes(t: int, block_size: int, head_dim: int) -> int:
+    return lib().pkv_tile_bytes(t, block_size, head_dim)
+
+
+def pool_bytes(t: int, n_blocks: int, n_head_kv: int, block_size: int, head_dim: int) -> int:
+    return lib().pkv_pool_bytes(t, n_blocks, n_head_kv, block_size, head_dim)
+
+
+def rope_params(*, n_dims: int, mode: int = 0, n_ctx_orig: int = 8192, freq_base: float = 500000.0,
+                freq_scale: float = 1.0, ext_factor: float = 0.0, attn_factor: float = 1.0, beta_fast: float = 32.0,
+                beta_slow: float = 1.0, freq_factors=None) -> RopeParams:
+    """Defaults are Llama-3 (rope.freq_base 5e5, NORM pairs; /root/reference/src/llama-model.cpp:11798)."""
+    return RopeParams(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow,
+                      _ptr(freq_factors))
+
+
+# ---- ops (device tensors in, device tensors out) -----------------------------------------------------------------
+def rope_f32(x, pos, rope: RopeParams, *, inverse: bool = False, out=None, stream=None):
+    """ggml_rope_ext on x f32 [n_tok][n_head][head_dim] (/root/reference/ggml/include/ggml.h:1438)."""
+    n_tok, n_head, D = x.shape
+    out = x.new_empty(x.shape) if out is None else out
+    check(lib().pkv_rope_f32(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(pos)), C.c_void_p(_ptr(out)), n_tok, n_head, D,
+                             C.byref(rope), int(inverse), C.c_void_p(_stream(stream))))
+    return out
+
+
+def kv_store(k_cur, v_cur, k_pool, v_pool, *, type_k: int, type_v: int, slot_block, slot_off, block_size: int,
+             pos=None, rope: Optional[RopeParams] = None, stream=None) -> None:
+    """ggml_cpy(k_cur/v_cur -> cache) of build_attn (/root/reference/src/llama-graph.cpp:1367-1398), optionally fused
+    with RoPE(K).  k_cur/v_cur f32 [n_tok][n_head_kv][head_dim]."""
+    ref = k_cur if k_cur is not None else v_cur
+    n_tok, n_head_kv, D = ref.shape
+    check(lib().pkv_kv_store(C.c_void_p(_ptr(k_cur)), C.c_void_p(_ptr(v_cur)), C.c_void_p(_ptr(k_pool)),
+                             C.c_void_p(_ptr(v_pool)), type_k, type_v, C.c_void_p(_ptr(slot_block)),
+                             C.c_void_p(_ptr(slot_off)), C.c_void_p(_ptr(pos)), C.byref(rope) if rope is not None else None,
+                             n_tok, n_head_kv, D, block_size, C.c_void_p(_stream(stream))))
+
+
+def attn_workspace_bytes(n_tok: int, n_head: int, head_dim: int, max_seq_len: int, block_size: int) -> int:
+    return lib().pkv_attn_workspace_bytes(n_tok, n_head, head_dim, max_seq_len, block_size)
+
+
+def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
+          q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
+          stream=None, flags=0):
+    import torch
+    n_tok, n_head, D = q.shape
+    n_seq, max_blocks = block_table.shape
+    out = torch.empty((n_tok, n_head, D), dtype=torch.float32, device=q.device) if out is None else out
+    need = attn_workspace_bytes(n_tok, n_head, D, max_seq_len, block_size)
+    if workspace is None:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    a = AttnArgs(_ptr(q), q.stride(0), q.stride(1), _ptr(out), _ptr(k_pool), _ptr(v_pool), _ptr(block_table),
+                 _ptr(seq_lens), _ptr(q_start), _ptr(slot_pos), _ptr(q_pos), _ptr(workspace), workspace.numel(),
+                 n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
+                 scale, logit_softcap, max_seq_len, flags)
+    check(fn(C.byref(a), C.c_void_p(_stream(stream))))
+    return out
+
+
+def attn_decode(q, k_pool, v_pool, block_table, seq_lens, **kw):
+    """Paged single-token decode: ggml_flash_attn_ext for one query per sequence
+    (/root/reference/src/llama-graph.cpp:1187-1197).  q f32 [n_seq][n_head][D] -> out f32 [n_seq][n_head][D]."""
+    return _attn(lib().pkv_attn_decode, q, k_pool, v_pool, block_table, seq_lens, **kw)
+
+
+def attn_prefill(q, k_pool, v_pool, block_table, seq_lens, q_start, **kw):
+    """Paged causal prefill (many query tokens per sequence); q f32 [n_tok][n_head][D]."""
+    return _attn(lib().pkv_attn_prefill, q, k_pool, v_pool, block_table, seq_lens, q_start=q_start, **kw)
+
+
+def k_shift(k_pool, *, type_k, cell_block, cell_off, cell_delta, n_head_kv, head_dim, block_size, rope: RopeParams,
+            stream=None) -> None:
+    """build_kv_self_shift (/root/reference/src/llama-context.cpp:524-571) for an explicit cell list."""
+    check(lib().pkv_k_shift(C.c_void_p(_ptr(k_pool)), type_k, C.c_void_p(_ptr(cell_block)), C.c_void_p(_ptr(cell_off)),
+                            C.c_void_p(_ptr(cell_delta)), cell_block.numel(), n_head_kv, head_dim, block_size,
+                            C.byref(rope), C.c_void_p(_stream(stream))))
+
+
+def copy_blocks(pool, *, type, src, dst, n_head_kv, head_dim, block_size, stream=None) -> None:
+    check(lib().pkv_copy_blocks(C.c_void_p(_ptr(pool)), type, C.c_void_p(_ptr(src)), C.c_void_p(_ptr(dst)), src.numel(),
+                                n_head_kv, head_dim, block_size, C.c_void_p(_stream(stream))))
+
+
+def pool_scatter_rows(pool, rows, *, type, is_v, slot_block, slot_off, n_head_kv, head_dim, block_size, stream=None):
+    """ggml_backend_tensor_set of reference-format KV rows (/root/reference/src/llama-kv-cache.cpp:1105-1221)."""
+    check(lib().pkv_pool_scatter_rows(C.c_void_p(_ptr(pool)), type, int(is_v), C.c_void_p(_ptr(rows)),
+                                      C.c_void_p(_ptr(slot_block)), C.c_void_p(_ptr(slot_off)), slot_block.numel(),
+                                      n_head_kv, head_dim, block_size, C.c_void_p(_stream(stream))))
+
+
+def pool_gather_rows(pool, rows, *, type, is_v, slot_block, slot_off, n_head_kv, head_dim, block_size, stream=None):
+    """ggml_backend_tensor_get of reference-format KV rows (/root/reference/src/llama-kv-cache.cpp:904-1001)."""
+    check(lib().pkv_pool_gather_rows(C.c_void_p(_ptr(pool)), type, int(is_v), C.c_void_p(_ptr(rows)),
+                                     C.c_void_p(_ptr(slot_block)), C.c_void_p(_ptr(slot_off)), slot_block.numel(),
+                                     n_head_kv, head_dim, block_size, C.c_void_p(_stream(stream))))
+    return rows
+
+
+# ---- llama_kv_cache mirror ---------------------------------------------------------------------------------------------
+class PagedKVCache:
+    """`llama_kv_cache` method set (/root/reference/src/llama-kv-cache.h:17-26) over the C++ block manager.
+
+    n_layer == 0 gives a bookkeeping-only cache that needs no GPU (used by the CPU test-suite)."""
+
+    def __init__(self, *, n_blocks: int, block_size: int = 128, n_seq_max: int = 1, n_layer: int = 0, n_head_kv: int = 8,
+                 head_dim: int = 128, type_k: int = F16, type_v: int = F16, device: int = 0, evict_when_full: bool = False):
+        self.params = CacheParams(n_layer, n_head_kv, head_dim, type_k, type_v, block_size, n_blocks, n_seq_max, device,
+                                  int(evict_when_full))
+        self._h = lib().pkv_cache_create(C.byref(self.params))
+        if not self._h:
+            raise PkvError(ERR_INVALID, lib().pkv_last_error().decode())
+        self.block_size, self.n_blocks, self.n_seq_max, self.n_layer = block_size, n_blocks, n_seq_max, n_layer
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pkv_cache_free(C.c_void_p(self._h))
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def h(self):
+        return C.c_void_p(self._h)
+
+    # llama_memory_i
+    def clear(self): lib().pkv_cache_clear(self.h)
+    def defrag(self): lib().pkv_cache_defrag(self.h)
+    def seq_rm(self, seq_id, p0, p1) -> bool: return bool(lib().pkv_cache_seq_rm(self.h, seq_id, p0, p1))
+    def seq_cp(self, src, dst, p0, p1): lib().pkv_cache_seq_cp(self.h, src, dst, p0, p1)
+    def seq_keep(self, seq_id): lib().pkv_cache_seq_keep(self.h, seq_id)
+    def seq_add(self, seq_id, p0, p1, delta): lib().pkv_cache_seq_add(self.h, seq_id, p0, p1, delta)
+    def seq_div(self, seq_id, p0, p1, d): lib().pkv_cache_seq_div(self.h, seq_id, p0, p1, d)
+    def seq_pos_max(self, seq_id) -> int: return lib().pkv_cache_seq_pos_max(self.h, seq_id)
+    def get_can_edit(self) -> bool: return self.get_can_shift()
+    # llama_kv_cache
+    def get_n_tokens(self) -> int: return lib().pkv_cache_n_tokens(self.h)
+    def get_used_cells(self) -> int: return lib().pkv_cache_used_cells(self.h)
+    def get_can_shift(self) -> bool: return bool(lib().pkv_cache_can_shift(self.h))
+
+    def find_slot(self, seq_id: Sequence[int], pos: Sequence[int]):
+        """llama_kv_cache_unified::find_slot for a ubatch; returns (block[n_tok], off[n_tok]) or raises PkvError(NO_SPACE)."""
+        sid = np.ascontiguousarray(seq_id, np.int32)
+        p = np.ascontiguousarray(pos, np.int32)
+        blk, off = np.empty(len(sid), np.int32), np.empty(len(sid), np.int32)
+        check(lib().pkv_cache_find_slot(self.h, len(sid), sid.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p),
+                                        blk.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)))
+        return blk, off
+
+    # block-table introspection
+    def seq_len(self, s) -> int: return lib().pkv_cache_seq_len(self.h, s)
+    def seq_is_regular(self, s) -> bool: return bool(lib().pkv_cache_seq_is_regular(self.h, s))
+    def n_free_blocks(self) -> int: return lib().pkv_cache_n_free_blocks(self.h)
+    def block_refcount(self, b) -> int: return lib().pkv_cache_block_refcount(self.h, b)
+    def has_shift(self) -> bool: return bool(lib().pkv_cache_has_shift(self.h))
+
+    def seq_blocks(self, s) -> np.ndarray:
+        n = lib().pkv_cache_seq_n_blocks(self.h, s)
+        out = np.empty(n, np.int32)
+        lib().pkv_cache_seq_blocks(self.h, s, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def seq_slot_pos(self, s) -> np.ndarray:
+        n = self.seq_len(s)
+        out = np.empty(n, np.int32)
+        lib().pkv_cache_seq_slot_pos(self.h, s, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def pending(self) -> np.ndarray:
+        """queued device work: rows {is_cell_copy, src_block, src_off, dst_block, dst_off}"""
+        n = lib().pkv_cache_n_pending(self.h)
+        out = np.empty((n, 5), np.int32)
+        lib().pkv_cache_pending(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def block_table(self, seq_ids: Sequence[int], max_blocks: Optional[int] = None):
+        """(block_table[n_seq][max_blocks] padded with 0, seq_lens[n_seq]) for the given sequences (host arrays)."""
+        tabs = [self.seq_blocks(s) for s in seq_ids]
+        mb = max_blocks or max(1, max(len(t) for t in tabs))
+        bt = np.zeros((len(tabs), mb), np.int32)
+        for i, t in enumerate(tabs):
+            bt[i, :len(t)] = t
+        return bt, np.array([self.seq_len(s) for s in seq_ids], np.int32)
+
+    # device side
+    def k_pool(self, layer: int) -> int: return lib().pkv_cache_k_pool(self.h, layer)
+    def v_pool(self, layer: int) -> int: return lib().pkv_cache_v_pool(self.h, layer)
+
+    def update(self, rope: Optional[RopeParams] = None, stream=None):
+        """kv_self_update (/root/reference/src/llama-context.cpp:719-803): queued copies + pending K-shift."""
+        st = C.c_void_p(_stream(stream)) if self.n_layer > 0 else None
+        check(lib().pkv_cache_update(self.h, C.byref(rope) if rope is not None else None, st))
+
+
+class ToyBlockManager:
+    """The fork prototype's BlockManager (/root/reference/tests/test_block_manager.cpp)."""
+
+    def __init__(self, n): self._h = lib().pkv_toy_bm_create(n); self.n = n
+    def __del__(self): lib().pkv_toy_bm_free(C.c_void_p(self._h))
+    def allocateBlock(self) -> int: return lib().pkv_toy_bm_allocate(C.c_void_p(self._h))
+    def freeBlock(self, i): lib().pkv_toy_bm_release(C.c_void_p(self._h), i)
+
+    def getBlockStatus(self):
+        out = np.zeros(self.n, np.uint8)
+        lib().pkv_toy_bm_status(C.c_void_p(self._h), out.ctypes.data_as(C.c_void_p), self.n)
+        return [bool(x) for x in out]
+
+
+class ToyKVCacheManager:
+    """The fork prototype's KVCacheManager / PhysicalBlock (/root/reference/tests/test_kv_cache.cpp)."""
+
+    def __init__(self, slot_capacity): self._h = lib().pkv_toy_kvm_create(slot_capacity)
+    def __del__(self): lib().pkv_toy_kvm_free(C.c_void_p(self._h))
+
+    def insert(self):
+        b, s = C.c_int(), C.c_int()
+        assert lib().pkv_toy_kvm_insert(C.c_void_p(self._h), C.byref(b), C.byref(s)) == 0
+        return b.value, s.value
+
+    def free(self, entry) -> bool:
+        return lib().pkv_toy_kvm_release(C.c_void_p(self._h), entry[0], entry[1]) == 0

@@ -1,0 +1,337 @@
+// pkv_cache.cpp — host block manager (no HIP in this file; see pkv_capi.cpp for the device side).
+#include "pkv_cache.h"
+
+#include <algorithm>
+#include <climits>
+#include <set>
+
+namespace pkv {
+
+// ---- fork prototype semantics ---------------------------------------------------------
+int ToyBlockManager::allocateBlock() {
+    for (size_t i = 0; i < used_.size(); ++i)
+        if (!used_[i]) { used_[i] = true; return (int) i; }
+    return evictBlock();
+}
+int ToyBlockManager::evictBlock() {
+    for (size_t i = 0; i < used_.size(); ++i)
+        if (used_[i]) { used_[i] = false; used_[i] = true; return (int) i; }  // cleared, then re-marked
+    return -1;
+}
+void ToyBlockManager::freeBlock(int i) {
+    if (i < 0 || (size_t) i >= used_.size()) return;
+    used_[i] = false;
+}
+
+bool ToyKvManager::insert(int * block, int * slot) {
+    auto first_free = [&](int * b, int * s) {
+        for (size_t i = 0; i < blocks_.size(); ++i)
+            for (int j = 0; j < cap_; ++j)
+                if (!blocks_[i][j]) { *b = (int) i; *s = j; return true; }
+        return false;
+    };
+    int b, s;
+    if (!first_free(&b, &s)) {  // ensureFreeSlot
+        blocks_.emplace_back(cap_, false);
+        b = (int) blocks_.size() - 1;
+        s = 0;
+    }
+    blocks_[b][s] = true;
+    *block = b;
+    *slot  = s;
+    return true;
+}
+bool ToyKvManager::release(int block, int slot) {
+    if (block < 0 || (size_t) block >= blocks_.size() || slot < 0 || slot >= cap_) return false;
+    blocks_[block][slot] = false;
+    return true;
+}
+
+// ---- paged cache ---------------------------------------------------------------------------------------------------
+KvCachePaged::KvCachePaged(const pkv_cache_params & p)
+    : p_(p), seqs_(p.n_seq_max > 0 ? p.n_seq_max : 1), ref_(p.n_blocks > 0 ? p.n_blocks : 0, 0), n_free_((int32_t) ref_.size()) {}
+
+int32_t KvCachePaged::alloc_block() {
+    if (n_free_ > 0) {
+        for (size_t i = 0; i < ref_.size(); ++i)
+            if (ref_[i] == 0) { ref_[i] = 1; --n_free_; return (int32_t) i; }
+    }
+    if (p_.evict_when_full) {
+        // fork BlockManager::evictBlock: the lowest allocated block is taken away from whoever holds it.
+        // Its cells become holes in every owner and trim() drops it from their tables.
+        for (size_t i = 0; i < ref_.size(); ++i) {
+            if (ref_[i] == 0) continue;
+            const int32_t b = (int32_t) i;
+            for (auto & s : seqs_) {
+                bool hit = false;
+                for (size_t lb = 0; lb < s.blocks.size(); ++lb) {
+                    if (s.blocks[lb] != b) continue;
+                    hit = true;
+                    const size_t c0 = lb * p_.block_size, c1 = std::min(s.pos.size(), c0 + (size_t) p_.block_size);
+                    for (size_t c = c0; c < c1; ++c) { s.pos[c] = -1; s.delta[c] = 0; }
+                }
+                if (hit) trim(s);
+            }
+            if (ref_[i] != 0) { n_free_ += 1; }  // defensive: nobody may still hold it
+            ref_[i] = 1;
+            --n_free_;
+            return b;
+        }
+    }
+    return -1;
+}
+
+void KvCachePaged::unref_block(int32_t b) {
+    if (b < 0 || (size_t) b >= ref_.size() || ref_[b] == 0) return;
+    if (--ref_[b] == 0) ++n_free_;
+}
+
+void KvCachePaged::drop_seq(Seq & s) {
+    for (int32_t b : s.blocks) unref_block(b);
+    s.blocks.clear();
+    s.pos.clear();
+    s.delta.clear();
+}
+
+void KvCachePaged::trim(Seq & s) {
+    const size_t BS = (size_t) p_.block_size;
+    // (1) wholly-empty logical blocks are removed from the table (later cells slide down by BS; their
+    //     positions are explicit, so nothing else changes) — this is what replaces defrag moves
+    for (size_t lb = s.blocks.size(); lb-- > 0;) {
+        const size_t c0 = lb * BS, c1 = std::min(s.pos.size(), c0 + BS);
+        bool empty = true;
+        for (size_t c = c0; c < c1 && empty; ++c) empty = s.pos[c] < 0;
+        if (!empty) continue;
+        unref_block(s.blocks[lb]);
+        s.blocks.erase(s.blocks.begin() + lb);
+        s.pos.erase(s.pos.begin() + c0, s.pos.begin() + c1);
+        s.delta.erase(s.delta.begin() + c0, s.delta.begin() + c1);
+    }
+    // (2) trailing holes
+    while (!s.pos.empty() && s.pos.back() < 0) { s.pos.pop_back(); s.delta.pop_back(); }
+}
+
+bool KvCachePaged::cow_block(Seq & s, size_t lb) {
+    const int32_t old = s.blocks[lb];
+    if (ref_[old] <= 1) return true;
+    const int32_t nb = alloc_block();
+    if (nb < 0) return false;
+    pending.push_back({false, old, 0, nb, 0});
+    unref_block(old);
+    s.blocks[lb] = nb;
+    return true;
+}
+
+void KvCachePaged::clear() {
+    for (auto & s : seqs_) drop_seq(s);
+    std::fill(ref_.begin(), ref_.end(), 0);
+    n_free_    = (int32_t) ref_.size();
+    has_shift_ = false;
+    pending.clear();
+}
+
+static inline void norm_range(int32_t & p0, int32_t & p1) {  // /ref/src/llama-kv-cache.cpp:176-182
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = INT32_MAX;
+}
+
+bool KvCachePaged::seq_rm(int32_t seq_id, int32_t p0, int32_t p1) {
+    norm_range(p0, p1);
+    auto rm = [&](Seq & s) {
+        for (size_t c = 0; c < s.pos.size(); ++c)
+            if (s.pos[c] >= p0 && s.pos[c] < p1) { s.pos[c] = -1; s.delta[c] = 0; }
+        trim(s);
+    };
+    if (seq_id < 0) { for (auto & s : seqs_) rm(s); }
+    else if (valid(seq_id)) rm(seqs_[seq_id]);
+    return true;
+}
+
+void KvCachePaged::seq_cp(int32_t src, int32_t dst, int32_t p0, int32_t p1) {
+    if (src == dst || !valid(src) || !valid(dst)) return;
+    norm_range(p0, p1);
+    Seq & a = seqs_[src];
+    Seq & b = seqs_[dst];
+    const size_t BS = (size_t) p_.block_size;
+    // cells of src inside the range
+    std::vector<size_t> idx;
+    for (size_t c = 0; c < a.pos.size(); ++c)
+        if (a.pos[c] >= p0 && a.pos[c] < p1) idx.push_back(c);
+    if (idx.empty()) return;
+    const bool prefix = idx.back() + 1 == idx.size();  // cells 0..n-1
+    if (b.pos.empty() && prefix) {
+        // share the blocks (the reference inserts dst into the src cells' seq_id sets, :285-292)
+        const size_t n = idx.size(), nblk = (n + BS - 1) / BS;
+        b.blocks.assign(a.blocks.begin(), a.blocks.begin() + nblk);
+        for (int32_t blk : b.blocks) ++ref_[blk];
+        b.pos.assign(a.pos.begin(), a.pos.begin() + n);
+        b.delta.assign(a.delta.begin(), a.delta.begin() + n);
+        // cells of src beyond n that live in the last shared block are not part of dst: nothing to do, dst's
+        // logical length ends at n and the first append to that block by either owner copies it (find_slot).
+        return;
+    }
+    // general case: append copies of the cells to dst (device cell copies queued for pkv_cache_update)
+    const size_t need_cells = b.pos.size() + idx.size();
+    size_t need_blocks = (need_cells + BS - 1) / BS - b.blocks.size();
+    if (!b.pos.empty() && b.pos.size() % BS != 0 && ref_[b.blocks.back()] > 1) ++need_blocks;
+    if ((int32_t) need_blocks > n_free_ && !p_.evict_when_full) return;  // no room: dst is left unchanged
+    if (!b.pos.empty() && b.pos.size() % BS != 0 && !cow_block(b, b.blocks.size() - 1)) return;
+    for (size_t c : idx) {
+        const size_t i = b.pos.size();
+        if (i / BS == b.blocks.size()) {
+            const int32_t nb = alloc_block();
+            if (nb < 0) return;
+            b.blocks.push_back(nb);
+        }
+        pending.push_back({true, a.blocks[c / BS], (int32_t) (c % BS), b.blocks[i / BS], (int32_t) (i % BS)});
+        b.pos.push_back(a.pos[c]);
+        b.delta.push_back(a.delta[c]);
+    }
+}
+
+void KvCachePaged::seq_keep(int32_t seq_id) {
+    for (int32_t s = 0; s < (int32_t) seqs_.size(); ++s)
+        if (s != seq_id) drop_seq(seqs_[s]);
+}
+
+void KvCachePaged::seq_add(int32_t seq_id, int32_t p0, int32_t p1, int32_t delta) {
+    if (delta == 0 || !valid(seq_id)) return;
+    norm_range(p0, p1);
+    if (p0 == p1) return;
+    Seq & s = seqs_[seq_id];
+    const size_t BS = (size_t) p_.block_size;
+    for (size_t c = 0; c < s.pos.size(); ++c) {
+        if (s.pos[c] < p0 || s.pos[c] >= p1) continue;
+        // the K rows of this cell will be rotated in place: make the block private first.  If the pool is full the
+        // shift is applied to the shared block, which is the reference's behaviour for shared cells (:360-364).
+        cow_block(s, c / BS);
+        has_shift_ = true;
+        s.pos[c] += delta;
+        s.delta[c] += delta;
+        if (s.pos[c] < 0) { s.pos[c] = -1; s.delta[c] = 0; }  // :366-373
+    }
+    trim(s);
+}
+
+void KvCachePaged::seq_div(int32_t seq_id, int32_t p0, int32_t p1, int d) {
+    if (d == 1 || d == 0 || !valid(seq_id)) return;
+    norm_range(p0, p1);
+    if (p0 == p1) return;
+    Seq & s = seqs_[seq_id];
+    const size_t BS = (size_t) p_.block_size;
+    for (size_t c = 0; c < s.pos.size(); ++c) {
+        if (s.pos[c] < p0 || s.pos[c] >= p1) continue;
+        cow_block(s, c / BS);
+        has_shift_ = true;
+        const int32_t old = s.pos[c];
+        s.pos[c] /= d;                    // :414-418
+        s.delta[c] += s.pos[c] - old;
+    }
+}
+
+int32_t KvCachePaged::seq_pos_max(int32_t seq_id) const {
+    int32_t r = 0;  // the reference starts from 0 as well (:432)
+    if (!valid(seq_id)) return r;
+    for (int32_t p : seqs_[seq_id].pos) r = std::max(r, p);
+    return r;
+}
+
+int32_t KvCachePaged::get_n_tokens() const {  // sum over cells of |seq_id set| (:133-141)
+    int32_t n = 0;
+    for (const auto & s : seqs_)
+        for (int32_t p : s.pos) n += p >= 0;
+    return n;
+}
+
+int32_t KvCachePaged::get_used_cells() const {  // distinct occupied physical cells (`used`)
+    std::set<int64_t> cells;
+    for (const auto & s : seqs_)
+        for (size_t c = 0; c < s.pos.size(); ++c)
+            if (s.pos[c] >= 0) cells.insert((int64_t) s.blocks[c / p_.block_size] * p_.block_size + (int64_t) (c % p_.block_size));
+    return (int32_t) cells.size();
+}
+
+bool KvCachePaged::seq_is_regular(int32_t sid) const {
+    if (!valid(sid)) return true;
+    const auto & pos = seqs_[sid].pos;
+    for (size_t c = 0; c < pos.size(); ++c)
+        if (pos[c] != (int32_t) c) return false;
+    return true;
+}
+
+int KvCachePaged::find_slot(int n_tok, const int32_t * seq_id, const int32_t * pos, int32_t * out_block, int32_t * out_off) {
+    const size_t BS = (size_t) p_.block_size;
+    // pass 1: how many fresh blocks would this ubatch need?  (all-or-nothing like the reference, :654)
+    std::vector<int32_t> add(seqs_.size(), 0);
+    for (int t = 0; t < n_tok; ++t) {
+        if (!valid(seq_id[t])) return PKV_ERR_INVALID;
+        ++add[seq_id[t]];
+    }
+    int64_t need = 0;
+    for (size_t s = 0; s < seqs_.size(); ++s) {
+        if (!add[s]) continue;
+        const Seq & q = seqs_[s];
+        need += (int64_t) ((q.pos.size() + add[s] + BS - 1) / BS) - (int64_t) q.blocks.size();
+        if (!q.pos.empty() && q.pos.size() % BS != 0 && ref_[q.blocks.back()] > 1) ++need;  // copy-on-write of the tail block
+    }
+    if (need > n_free_ && !p_.evict_when_full) return PKV_ERR_NO_SPACE;
+    // pass 2: place the tokens in batch order
+    for (int t = 0; t < n_tok; ++t) {
+        Seq & q = seqs_[seq_id[t]];
+        const size_t i = q.pos.size(), lb = i / BS;
+        if (lb == q.blocks.size()) {
+            const int32_t nb = alloc_block();
+            if (nb < 0) return PKV_ERR_NO_SPACE;
+            q.blocks.push_back(nb);
+        } else if (ref_[q.blocks[lb]] > 1) {
+            if (!cow_block(q, lb)) return PKV_ERR_NO_SPACE;
+        }
+        q.pos.push_back(pos[t]);
+        q.delta.push_back(0);
+        out_block[t] = q.blocks[lb];
+        out_off[t]   = (int32_t) (i % BS);
+    }
+    return PKV_OK;
+}
+
+void KvCachePaged::defrag() {
+    // Holes that do not fill a whole block survive trim(); defrag rewrites such sequences densely into fresh
+    // blocks (cell copies are queued for the device).  Sequences without holes are already "defragmented":
+    // the block table makes physical contiguity irrelevant.
+    const size_t BS = (size_t) p_.block_size;
+    for (auto & s : seqs_) {
+        size_t n_valid = 0;
+        for (int32_t p : s.pos) n_valid += p >= 0;
+        if (n_valid == s.pos.size()) continue;
+        const size_t nblk = (n_valid + BS - 1) / BS;
+        if ((int32_t) nblk > n_free_) continue;  // not enough scratch blocks: leave as is
+        Seq d;
+        for (size_t c = 0; c < s.pos.size(); ++c) {
+            if (s.pos[c] < 0) continue;
+            const size_t i = d.pos.size();
+            if (i / BS == d.blocks.size()) d.blocks.push_back(alloc_block());
+            pending.push_back({true, s.blocks[c / BS], (int32_t) (c % BS), d.blocks[i / BS], (int32_t) (i % BS)});
+            d.pos.push_back(s.pos[c]);
+            d.delta.push_back(s.delta[c]);
+        }
+        for (int32_t b : s.blocks) unref_block(b);
+        s = std::move(d);
+    }
+}
+
+void KvCachePaged::take_shifts(std::vector<int32_t> & blk, std::vector<int32_t> & off, std::vector<int32_t> & dlt) {
+    std::set<int64_t> seen;
+    for (auto & s : seqs_) {
+        for (size_t c = 0; c < s.pos.size(); ++c) {
+            if (s.delta[c] == 0) continue;
+            const int32_t b = s.blocks[c / p_.block_size], o = (int32_t) (c % p_.block_size);
+            if (seen.insert((int64_t) b * p_.block_size + o).second) {
+                blk.push_back(b); off.push_back(o); dlt.push_back(s.delta[c]);
+            }
+            s.delta[c] = 0;
+        }
+    }
+    has_shift_ = false;
+}
+
+}  // namespace pkv

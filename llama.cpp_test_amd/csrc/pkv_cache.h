@@ -1,0 +1,99 @@
+// pkv_cache.h — host block manager of the paged KV cache (C++ mirror of the llama_kv_cache method set).
+//
+// Replaces llama_kv_cache_unified's cell ring (/ref/src/llama-kv-cache.h:63-178, /ref/src/llama-kv-cache.cpp)
+// with a vLLM-style logical->physical block table.  Allocation policy and the toy classes follow the fork
+// prototype recovered in SURVEY.md §8(a-toy) (/ref/tests/test_block_manager.cpp, test_kv_cache.cpp).
+#pragma once
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "../../include/mi355_paged_kv.h"
+
+namespace pkv {
+
+// ---- fork prototype: BlockManager (test_block_manager.cpp) ------------------------------------------------
+class ToyBlockManager {
+  public:
+    explicit ToyBlockManager(int n) : used_(n > 0 ? n : 0, false) {}
+    int  allocateBlock();            // lowest free index, else evictBlock(), else -1
+    int  evictBlock();               // lowest ALLOCATED index: cleared, then handed out again
+    void freeBlock(int i);           // bounds-checked, idempotent
+    const std::vector<bool> & getBlockStatus() const { return used_; }
+  private:
+    std::vector<bool> used_;
+};
+
+// ---- fork prototype: PhysicalBlock + KVCacheManager (test_kv_cache.cpp) --------------------------------------
+class ToyKvManager {
+  public:
+    explicit ToyKvManager(int slot_cap) : cap_(slot_cap > 0 ? slot_cap : 1), blocks_(1, std::vector<bool>(cap_, false)) {}
+    bool insert(int * block, int * slot);  // ensureFreeSlot(): append a block iff none has a free slot; first fit
+    bool release(int block, int slot);     // bounds-checked
+    int  n_blocks() const { return (int) blocks_.size(); }
+  private:
+    int                            cap_;
+    std::vector<std::vector<bool>> blocks_;
+};
+
+// ---- the paged cache ------------------------------------------------------------------------------------------
+// device work queued by host edits, executed IN ORDER by pkv_cache_update: whole-block copies (copy-on-write)
+// and single-cell copies (seq_cp of unaligned ranges, defrag)
+struct PendingOp { bool cell; int32_t src_block, src_off, dst_block, dst_off; };
+
+class KvCachePaged {
+  public:
+    explicit KvCachePaged(const pkv_cache_params & p);
+
+    // llama_memory_i / llama_kv_cache (/ref/src/llama-memory.h:7-21, /ref/src/llama-kv-cache.h:17-26)
+    void    clear();
+    void    defrag();
+    bool    seq_rm(int32_t seq_id, int32_t p0, int32_t p1);
+    void    seq_cp(int32_t src, int32_t dst, int32_t p0, int32_t p1);
+    void    seq_keep(int32_t seq_id);
+    void    seq_add(int32_t seq_id, int32_t p0, int32_t p1, int32_t delta);
+    void    seq_div(int32_t seq_id, int32_t p0, int32_t p1, int d);
+    int32_t seq_pos_max(int32_t seq_id) const;
+    int32_t get_n_tokens() const;
+    int32_t get_used_cells() const;
+    bool    get_can_shift() const { return true; }
+
+    // find_slot (/ref/src/llama-kv-cache.cpp:453-672): all-or-nothing placement of a ubatch
+    int find_slot(int n_tok, const int32_t * seq_id, const int32_t * pos, int32_t * out_block, int32_t * out_off);
+
+    // introspection
+    int32_t seq_len(int32_t s) const { return valid(s) ? (int32_t) seqs_[s].pos.size() : 0; }
+    const std::vector<int32_t> & seq_blocks(int32_t s) const { return seqs_[s].blocks; }
+    const std::vector<int32_t> & seq_slot_pos(int32_t s) const { return seqs_[s].pos; }
+    bool    seq_is_regular(int32_t s) const;
+    int32_t n_free_blocks() const { return n_free_; }
+    int32_t refcount(int32_t b) const { return b >= 0 && b < (int32_t) ref_.size() ? ref_[b] : -1; }
+    bool    has_shift() const { return has_shift_; }
+    bool    valid(int32_t s) const { return s >= 0 && s < (int32_t) seqs_.size(); }
+    const pkv_cache_params & params() const { return p_; }
+
+    // work queued for the device (consumed by pkv_cache_update)
+    std::vector<PendingOp> pending;
+    // cells with a pending K-shift: (block, off, delta); clears the per-cell deltas
+    void take_shifts(std::vector<int32_t> & blk, std::vector<int32_t> & off, std::vector<int32_t> & dlt);
+
+  private:
+    struct Seq {
+        std::vector<int32_t> blocks;  // logical block -> physical block
+        std::vector<int32_t> pos;     // per logical cell; -1 = empty (hole)
+        std::vector<int32_t> delta;   // accumulated, not yet applied position shift (llama_kv_cell::delta)
+    };
+    int32_t alloc_block();            // fork BlockManager policy: lowest free index first
+    void    unref_block(int32_t b);
+    void    trim(Seq & s);            // drop trailing holes, wholly-empty blocks, release their blocks
+    void    drop_seq(Seq & s);
+    bool    cow_block(Seq & s, size_t lb);  // make logical block lb private to s (copy-on-write)
+
+    pkv_cache_params     p_;
+    std::vector<Seq>     seqs_;
+    std::vector<int32_t> ref_;        // per physical block reference count, 0 = free
+    int32_t              n_free_;
+    bool                 has_shift_ = false;
+};
+
+}  // namespace pkv

@@ -1,0 +1,341 @@
+// pkv_capi.cpp — the extern "C" boundary declared in include/mi355_paged_kv.h.
+// Argument validation happens here, on the host, BEFORE any launch (a faulting kernel can reset the whole GPU node).
+#include "pkv_cache.h"
+#include "pkv_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace pkv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char * fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int hip_fail(hipError_t e, const char * what) {
+    set_error("HIP error %d (%s) in %s", (int) e, hipGetErrorString(e), what);
+    return PKV_ERR_HIP;
+}
+int ensure_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void) hipGetLastError();
+        set_error("no HIP device visible: this library has no CPU path (kernels are gfx950 code objects)");
+        return PKV_ERR_NO_DEVICE;
+    }
+    return PKV_OK;
+}
+
+// device half of a pkv_cache
+struct CacheDev {
+    std::vector<void *> k, v;
+    int32_t * scratch = nullptr;  // device i32 staging for copy / shift lists
+    size_t    scratch_n = 0;
+};
+
+}  // namespace pkv
+
+using namespace pkv;
+
+struct pkv_cache {
+    KvCachePaged host;
+    CacheDev     dev;
+    explicit pkv_cache(const pkv_cache_params & p) : host(p) {}
+};
+struct pkv_toy_block_manager { ToyBlockManager bm; explicit pkv_toy_block_manager(int n) : bm(n) {} };
+struct pkv_toy_kv_manager    { ToyKvManager m;     explicit pkv_toy_kv_manager(int c) : m(c) {} };
+
+extern "C" {
+
+int          pkv_abi_version(void) { return PKV_ABI_VERSION; }
+const char * pkv_last_error(void) { return g_err; }
+int          pkv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return n;
+}
+const char * pkv_device_arch(int device) {
+    static thread_local char arch[256];
+    hipDeviceProp_t prop;
+    if (device < 0 || device >= pkv_device_count() || hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
+    snprintf(arch, sizeof(arch), "%s", prop.gcnArchName);
+    if (char * c = strchr(arch, ':')) *c = 0;
+    return arch;
+}
+
+size_t pkv_row_size(int type, int64_t ne) { return row_size(type, ne); }
+size_t pkv_tile_bytes(int type, int block_size, int head_dim) { return tile_bytes(type, block_size, head_dim); }
+size_t pkv_pool_bytes(int type, int n_blocks, int n_head_kv, int block_size, int head_dim) {
+    return (size_t) n_blocks * n_head_kv * tile_bytes(type, block_size, head_dim);
+}
+
+// ---- kernels -----------------------------------------------------------------------------------------------
+int pkv_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, int n_head, int head_dim,
+                 const pkv_rope_params * rope, int inverse, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && pos && out && n_tok >= 0 && n_head > 0 && head_dim > 0 && head_dim % 2 == 0, "pkv_rope_f32: bad arguments");
+    RopeDev r;
+    if (int rc = make_rope(rope, head_dim, &r)) return rc;
+    return launch_rope_f32(x, pos, out, n_tok, n_head, head_dim, r, inverse, (hipStream_t) stream);
+}
+
+int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
+                 const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
+                 const pkv_rope_params * rope, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE((k_cur || v_cur) && slot_block && slot_off, "pkv_kv_store: null pointer");
+    PKV_REQUIRE(!k_cur || k_pool, "pkv_kv_store: k_cur without k_pool");
+    PKV_REQUIRE(!v_cur || v_pool, "pkv_kv_store: v_cur without v_pool");
+    PKV_REQUIRE(kv_type_ok(type_k) && kv_type_ok(type_v), "pkv_kv_store: KV types must be f16/q8_0/q4_0");
+    PKV_REQUIRE(n_tok >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 4 == 0, "pkv_kv_store: bad sizes");
+    PKV_REQUIRE(!rope || pos, "pkv_kv_store: fused rope needs pos");
+    RopeDev r;
+    if (rope) { if (int rc = make_rope(rope, head_dim, &r)) return rc; }
+    return launch_kv_store(k_cur, v_cur, k_pool, v_pool, type_k, type_v, slot_block, slot_off, pos, rope ? &r : nullptr,
+                           n_tok, n_head_kv, head_dim, block_size, (hipStream_t) stream);
+}
+
+size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq_len, int block_size) {
+    (void) block_size;
+    const size_t a = decode_workspace_bytes(n_tok, n_head, head_dim, max_seq_len);
+    const size_t b = prefill_workspace_bytes(n_tok, n_head, head_dim);
+    return a > b ? a : b;
+}
+
+int pkv_attn_decode(const pkv_attn_args * args, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args != nullptr, "pkv_attn_decode: null args");
+    return launch_attn_decode(*args, (hipStream_t) stream);
+}
+
+int pkv_attn_prefill(const pkv_attn_args * args, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args != nullptr, "pkv_attn_prefill: null args");
+    return launch_attn_prefill(*args, (hipStream_t) stream);
+}
+
+int pkv_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,
+                const int32_t * cell_delta, int n_cells, int n_head_kv, int head_dim, int block_size,
+                const pkv_rope_params * rope, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(k_pool && cell_block && cell_off && cell_delta && n_cells >= 0, "pkv_k_shift: bad arguments");
+    PKV_REQUIRE(kv_type_ok(type_k), "pkv_k_shift: K type must be f16/q8_0/q4_0");
+    RopeDev r;
+    if (int rc = make_rope(rope, head_dim, &r)) return rc;
+    return launch_k_shift(k_pool, type_k, cell_block, cell_off, cell_delta, n_cells, n_head_kv, head_dim, block_size, r,
+                          (hipStream_t) stream);
+}
+
+int pkv_copy_blocks(void * pool, int type, const int32_t * src, const int32_t * dst, int n, int n_head_kv,
+                    int head_dim, int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(pool && src && dst && n >= 0 && kv_type_ok(type), "pkv_copy_blocks: bad arguments");
+    return launch_copy_blocks(pool, (size_t) n_head_kv * tile_bytes(type, block_size, head_dim), src, dst, n, (hipStream_t) stream);
+}
+
+int pkv_pool_scatter_rows(void * pool, int type, int is_v, const void * rows, const int32_t * slot_block,
+                          const int32_t * slot_off, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(pool && rows && slot_block && slot_off && n_tok >= 0 && kv_type_ok(type), "pkv_pool_scatter_rows: bad arguments");
+    return launch_rows_io(pool, type, is_v, const_cast<void *>(rows), slot_block, slot_off, n_tok, n_head_kv, head_dim, block_size,
+                          true, (hipStream_t) stream);
+}
+int pkv_pool_gather_rows(const void * pool, int type, int is_v, void * rows, const int32_t * slot_block,
+                         const int32_t * slot_off, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(pool && rows && slot_block && slot_off && n_tok >= 0 && kv_type_ok(type), "pkv_pool_gather_rows: bad arguments");
+    return launch_rows_io(const_cast<void *>(pool), type, is_v, rows, slot_block, slot_off, n_tok, n_head_kv, head_dim, block_size,
+                          false, (hipStream_t) stream);
+}
+
+// ---- cache ---------------------------------------------------------------------------------------------------
+pkv_cache * pkv_cache_create(const pkv_cache_params * p) {
+    if (!p || p->n_blocks <= 0 || p->block_size <= 0 || p->n_seq_max <= 0) { set_error("pkv_cache_create: bad params"); return nullptr; }
+    if (p->n_layer > 0) {
+        if (ensure_device() != PKV_OK) return nullptr;
+        if (!kv_type_ok(p->type_k) || !kv_type_ok(p->type_v) || p->n_head_kv <= 0 || (p->head_dim != 64 && p->head_dim != 128)) {
+            set_error("pkv_cache_create: unsupported KV geometry/types");
+            return nullptr;
+        }
+    }
+    pkv_cache * c = new pkv_cache(*p);
+    if (p->n_layer > 0) {
+        if (hipSetDevice(p->device) != hipSuccess) { hip_fail(hipGetLastError(), "hipSetDevice"); delete c; return nullptr; }
+        const size_t kb = pkv_pool_bytes(p->type_k, p->n_blocks, p->n_head_kv, p->block_size, p->head_dim);
+        const size_t vb = pkv_pool_bytes(p->type_v, p->n_blocks, p->n_head_kv, p->block_size, p->head_dim);
+        for (int l = 0; l < p->n_layer; ++l) {
+            void * k = nullptr, * v = nullptr;
+            // zero-filled like ggml_backend_buffer_clear at init (/ref/src/llama-kv-cache.cpp:118)
+            if (hipMalloc(&k, kb) != hipSuccess || hipMalloc(&v, vb) != hipSuccess || hipMemset(k, 0, kb) != hipSuccess ||
+                hipMemset(v, 0, vb) != hipSuccess) {
+                hip_fail(hipGetLastError(), "pool allocation");
+                if (k) (void) hipFree(k);
+                if (v) (void) hipFree(v);
+                pkv_cache_free(c);
+                return nullptr;
+            }
+            c->dev.k.push_back(k);
+            c->dev.v.push_back(v);
+        }
+    }
+    return c;
+}
+
+void pkv_cache_free(pkv_cache * c) {
+    if (!c) return;
+    for (void * p : c->dev.k) (void) hipFree(p);
+    for (void * p : c->dev.v) (void) hipFree(p);
+    if (c->dev.scratch) (void) hipFree(c->dev.scratch);
+    delete c;
+}
+
+int32_t pkv_cache_n_tokens(const pkv_cache * c) { return c ? c->host.get_n_tokens() : 0; }
+int32_t pkv_cache_used_cells(const pkv_cache * c) { return c ? c->host.get_used_cells() : 0; }
+void    pkv_cache_clear(pkv_cache * c) { if (c) c->host.clear(); }
+int     pkv_cache_seq_rm(pkv_cache * c, int32_t s, int32_t p0, int32_t p1) { return c ? c->host.seq_rm(s, p0, p1) : 1; }
+void    pkv_cache_seq_cp(pkv_cache * c, int32_t a, int32_t b, int32_t p0, int32_t p1) { if (c) c->host.seq_cp(a, b, p0, p1); }
+void    pkv_cache_seq_keep(pkv_cache * c, int32_t s) { if (c) c->host.seq_keep(s); }
+void    pkv_cache_seq_add(pkv_cache * c, int32_t s, int32_t p0, int32_t p1, int32_t d) { if (c) c->host.seq_add(s, p0, p1, d); }
+void    pkv_cache_seq_div(pkv_cache * c, int32_t s, int32_t p0, int32_t p1, int32_t d) { if (c) c->host.seq_div(s, p0, p1, d); }
+int32_t pkv_cache_seq_pos_max(pkv_cache * c, int32_t s) { return c ? c->host.seq_pos_max(s) : 0; }
+void    pkv_cache_defrag(pkv_cache * c) { if (c) c->host.defrag(); }
+int     pkv_cache_can_shift(const pkv_cache * c) { return c ? c->host.get_can_shift() : 0; }
+
+int pkv_cache_find_slot(pkv_cache * c, int n_tok, const int32_t * seq_id, const int32_t * pos, int32_t * out_block,
+                        int32_t * out_off) {
+    PKV_REQUIRE(c && n_tok >= 0 && (n_tok == 0 || (seq_id && pos && out_block && out_off)), "pkv_cache_find_slot: bad arguments");
+    const int rc = c->host.find_slot(n_tok, seq_id, pos, out_block, out_off);
+    if (rc == PKV_ERR_NO_SPACE) set_error("pkv_cache_find_slot: failed to find a slot for %d tokens (%d free blocks)", n_tok, c->host.n_free_blocks());
+    if (rc == PKV_ERR_INVALID) set_error("pkv_cache_find_slot: seq_id out of range");
+    return rc;
+}
+
+int32_t pkv_cache_seq_len(const pkv_cache * c, int32_t s) { return c ? c->host.seq_len(s) : 0; }
+int32_t pkv_cache_seq_n_blocks(const pkv_cache * c, int32_t s) { return c && c->host.valid(s) ? (int32_t) c->host.seq_blocks(s).size() : 0; }
+int32_t pkv_cache_seq_blocks(const pkv_cache * c, int32_t s, int32_t * out, int32_t cap) {
+    if (!c || !c->host.valid(s)) return 0;
+    const auto & b = c->host.seq_blocks(s);
+    for (int32_t i = 0; i < (int32_t) b.size() && i < cap; ++i) out[i] = b[i];
+    return (int32_t) b.size();
+}
+int32_t pkv_cache_seq_is_regular(const pkv_cache * c, int32_t s) { return c ? c->host.seq_is_regular(s) : 1; }
+int32_t pkv_cache_seq_slot_pos(const pkv_cache * c, int32_t s, int32_t * out, int32_t cap) {
+    if (!c || !c->host.valid(s)) return 0;
+    const auto & p = c->host.seq_slot_pos(s);
+    for (int32_t i = 0; i < (int32_t) p.size() && i < cap; ++i) out[i] = p[i];
+    return (int32_t) p.size();
+}
+int32_t pkv_cache_n_free_blocks(const pkv_cache * c) { return c ? c->host.n_free_blocks() : 0; }
+int32_t pkv_cache_block_refcount(const pkv_cache * c, int32_t b) { return c ? c->host.refcount(b) : -1; }
+int32_t pkv_cache_has_shift(const pkv_cache * c) { return c ? c->host.has_shift() : 0; }
+int32_t pkv_cache_n_pending(const pkv_cache * c) { return c ? (int32_t) c->host.pending.size() : 0; }
+int32_t pkv_cache_pending(const pkv_cache * c, int32_t * out5, int32_t cap) {
+    if (!c) return 0;
+    const auto & q = c->host.pending;
+    for (int32_t i = 0; i < (int32_t) q.size() && i < cap; ++i) {
+        out5[i * 5 + 0] = q[i].cell; out5[i * 5 + 1] = q[i].src_block; out5[i * 5 + 2] = q[i].src_off;
+        out5[i * 5 + 3] = q[i].dst_block; out5[i * 5 + 4] = q[i].dst_off;
+    }
+    return (int32_t) q.size();
+}
+
+void * pkv_cache_k_pool(pkv_cache * c, int layer) { return c && layer >= 0 && layer < (int) c->dev.k.size() ? c->dev.k[layer] : nullptr; }
+void * pkv_cache_v_pool(pkv_cache * c, int layer) { return c && layer >= 0 && layer < (int) c->dev.v.size() ? c->dev.v[layer] : nullptr; }
+
+static int upload(pkv_cache * c, const std::vector<int32_t> & h, hipStream_t st) {
+    if (h.size() > c->dev.scratch_n) {
+        if (c->dev.scratch) { PKV_HIP(hipStreamSynchronize(st)); PKV_HIP(hipFree(c->dev.scratch)); c->dev.scratch = nullptr; }
+        c->dev.scratch_n = h.size() * 2 + 1024;
+        PKV_HIP(hipMalloc((void **) &c->dev.scratch, c->dev.scratch_n * sizeof(int32_t)));
+    }
+    PKV_HIP(hipMemcpyAsync(c->dev.scratch, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    PKV_HIP(hipStreamSynchronize(st));  // h is pageable and dies with the caller's frame
+    return PKV_OK;
+}
+
+int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream) {
+    PKV_REQUIRE(c != nullptr, "pkv_cache_update: null cache");
+    const pkv_cache_params & p = c->host.params();
+    hipStream_t st = (hipStream_t) stream;
+    auto & q = c->host.pending;
+    if (p.n_layer <= 0) {  // bookkeeping-only cache: nothing to run, just retire the queues
+        q.clear();
+        std::vector<int32_t> a, b, d;
+        c->host.take_shifts(a, b, d);
+        return PKV_OK;
+    }
+    if (int rc = ensure_device()) return rc;
+    // (1) queued copies, in issue order, batched per run of equal kind
+    size_t i = 0;
+    while (i < q.size()) {
+        size_t j = i;
+        while (j < q.size() && q[j].cell == q[i].cell) ++j;
+        const int n = (int) (j - i);
+        std::vector<int32_t> h((size_t) n * 4);
+        for (int k = 0; k < n; ++k) {
+            h[k] = q[i + k].src_block; h[n + k] = q[i + k].src_off; h[2 * n + k] = q[i + k].dst_block; h[3 * n + k] = q[i + k].dst_off;
+        }
+        if (int rc = upload(c, h, st)) return rc;
+        const int32_t * sb = c->dev.scratch, * so = sb + n, * db = so + n, * dof = db + n;
+        for (int l = 0; l < p.n_layer; ++l) {
+            int rc;
+            if (!q[i].cell) {
+                rc = launch_copy_blocks(c->dev.k[l], (size_t) p.n_head_kv * tile_bytes(p.type_k, p.block_size, p.head_dim), sb, db, n, st);
+                if (!rc) rc = launch_copy_blocks(c->dev.v[l], (size_t) p.n_head_kv * tile_bytes(p.type_v, p.block_size, p.head_dim), sb, db, n, st);
+            } else {
+                rc = launch_copy_cells(c->dev.k[l], p.type_k, 0, sb, so, db, dof, n, p.n_head_kv, p.head_dim, p.block_size, st);
+                if (!rc) rc = launch_copy_cells(c->dev.v[l], p.type_v, 1, sb, so, db, dof, n, p.n_head_kv, p.head_dim, p.block_size, st);
+            }
+            if (rc) return rc;
+        }
+        PKV_HIP(hipStreamSynchronize(st));  // scratch is reused by the next run
+        i = j;
+    }
+    q.clear();
+    // (2) pending K-shift (/ref/src/llama-context.cpp:719-760)
+    if (c->host.has_shift()) {
+        PKV_REQUIRE(rope != nullptr, "pkv_cache_update: a K-shift is pending but no rope parameters were given");
+        RopeDev r;
+        if (int rc = make_rope(rope, p.head_dim, &r)) return rc;
+        std::vector<int32_t> blk, off, dlt;
+        c->host.take_shifts(blk, off, dlt);
+        const int n = (int) blk.size();
+        if (n > 0) {
+            std::vector<int32_t> h;
+            h.insert(h.end(), blk.begin(), blk.end());
+            h.insert(h.end(), off.begin(), off.end());
+            h.insert(h.end(), dlt.begin(), dlt.end());
+            if (int rc = upload(c, h, st)) return rc;
+            for (int l = 0; l < p.n_layer; ++l)
+                if (int rc = launch_k_shift(c->dev.k[l], p.type_k, c->dev.scratch, c->dev.scratch + n, c->dev.scratch + 2 * n, n,
+                                            p.n_head_kv, p.head_dim, p.block_size, r, st))
+                    return rc;
+            PKV_HIP(hipStreamSynchronize(st));
+        }
+    }
+    return PKV_OK;
+}
+
+// ---- fork prototype toys ---------------------------------------------------------------------------------------------
+pkv_toy_block_manager * pkv_toy_bm_create(int n) { return new pkv_toy_block_manager(n); }
+void pkv_toy_bm_free(pkv_toy_block_manager * bm) { delete bm; }
+int  pkv_toy_bm_allocate(pkv_toy_block_manager * bm) { return bm ? bm->bm.allocateBlock() : -1; }
+void pkv_toy_bm_release(pkv_toy_block_manager * bm, int b) { if (bm) bm->bm.freeBlock(b); }
+int  pkv_toy_bm_status(const pkv_toy_block_manager * bm, uint8_t * out, int cap) {
+    if (!bm) return 0;
+    const auto & s = bm->bm.getBlockStatus();
+    for (int i = 0; i < (int) s.size() && i < cap; ++i) out[i] = s[i];
+    return (int) s.size();
+}
+pkv_toy_kv_manager * pkv_toy_kvm_create(int cap) { return new pkv_toy_kv_manager(cap); }
+void pkv_toy_kvm_free(pkv_toy_kv_manager * m) { delete m; }
+int  pkv_toy_kvm_insert(pkv_toy_kv_manager * m, int * b, int * s) { return m && m->m.insert(b, s) ? 0 : -1; }
+int  pkv_toy_kvm_release(pkv_toy_kv_manager * m, int b, int s) { return m && m->m.release(b, s) ? 0 : -1; }
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// pkv_common.h — shared host/device helpers for the MI355X paged-KV path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/mi355_paged_kv.h"
+
+#define PKV_QK 32  // elements per quant block: QK8_0 == QK4_0 (/ref/ggml/src/ggml-common.h:155,197)
+
+namespace pkv {
+
+// ---- status / error text -------------------------------------------------------------------------
+void set_error(const char * fmt, ...);
+int  hip_fail(hipError_t e, const char * what);
+#define PKV_HIP(call)                                                       \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return ::pkv::hip_fail(e_, #call);            \
+    } while (0)
+#define PKV_REQUIRE(cond, ...)                                              \
+    do {                                                                    \
+        if (!(cond)) { ::pkv::set_error(__VA_ARGS__); return PKV_ERR_INVALID; } \
+    } while (0)
+
+int ensure_device();  // PKV_OK or PKV_ERR_NO_DEVICE
+
+// ---- pool layout ("Pool layout" in include/mi355_paged_kv.h) -------------------------------------
+__host__ __device__ inline size_t tile_quant_bytes(int type, int block_size, int D) {
+    return type == PKV_TYPE_F16  ? (size_t) block_size * D * 2
+         : type == PKV_TYPE_Q8_0 ? (size_t) block_size * D
+         : type == PKV_TYPE_Q4_0 ? (size_t) block_size * D / 2 : 0;
+}
+__host__ __device__ inline size_t tile_bytes(int type, int block_size, int D) {
+    const size_t q = tile_quant_bytes(type, block_size, D);
+    return type == PKV_TYPE_F16 ? q : (q ? q + (size_t) block_size * (D / PKV_QK) * 2 : 0);
+}
+__host__ __device__ inline size_t row_size(int type, int64_t ne) {
+    return type == PKV_TYPE_F32  ? (size_t) ne * 4
+         : type == PKV_TYPE_F16  ? (size_t) ne * 2
+         : type == PKV_TYPE_Q8_0 ? (size_t) (ne / PKV_QK) * 34
+         : type == PKV_TYPE_Q4_0 ? (size_t) (ne / PKV_QK) * 18 : 0;
+}
+inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0; }
+
+// ---- kernel launchers (pkv_kernels_*.hip) ---------------------------------------------------------
+struct RopeDev {  // pkv_rope_params resolved on the host (corr dims = ggml_rope_yarn_corr_dims, /ref/ggml/src/ggml.c:3739)
+    int   n_dims, mode;
+    float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1;
+    const float * freq_factors;
+};
+int make_rope(const pkv_rope_params * p, int head_dim, RopeDev * out);
+
+int launch_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, int n_head, int D,
+                    const RopeDev & r, int inverse, hipStream_t st);
+int launch_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
+                    const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos, const RopeDev * rope,
+                    int n_tok, int n_head_kv, int D, int block_size, hipStream_t st);
+int launch_attn_decode(const pkv_attn_args & a, hipStream_t st);
+int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st);
+size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
+size_t prefill_workspace_bytes(int n_tok, int n_head, int D);
+int launch_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,
+                   const int32_t * cell_delta, int n_cells, int n_head_kv, int D, int block_size, const RopeDev & r,
+                   hipStream_t st);
+int launch_copy_blocks(void * pool, size_t block_bytes, const int32_t * src, const int32_t * dst, int n, hipStream_t st);
+int launch_copy_cells(void * pool, int type, int is_v, const int32_t * sb, const int32_t * so, const int32_t * db,
+                      const int32_t * dof, int n, int n_head_kv, int D, int block_size, hipStream_t st);
+int launch_rows_io(void * pool, int type, int is_v, void * rows, const int32_t * slot_block, const int32_t * slot_off, int n_tok,
+                   int n_head_kv, int D, int block_size, bool scatter, hipStream_t st);
+
+}  // namespace pkv

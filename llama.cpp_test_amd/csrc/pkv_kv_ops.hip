@@ -1,0 +1,482 @@
+// pkv_kv_ops.hip — RoPE, fused KV store (RoPE + f16/q8_0/q4_0 convert + scatter through the slot mapping),
+// in-place K-shift, reference-format row I/O and block copies for the paged pools.  gfx950 only.
+//
+// One 64-lane wave handles one (token, kv head) row; lane i owns elements (2i, 2i+1), i.e. one RoPE pair in
+// NORM mode (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10807-10821).  Quantization block reductions (32 elements = 16
+// lanes = one DPP row) use DPP only.
+#include "pkv_common.h"
+
+#include <math.h>
+
+namespace pkv {
+namespace {
+
+template <int CTRL> __device__ __forceinline__ float dppf(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float x) {  // all-reduce max over the 16 lanes of a DPP row
+    x = fmaxf(x, dppf<0xB1>(x));
+    x = fmaxf(x, dppf<0x4E>(x));
+    x = fmaxf(x, dppf<0x141>(x));
+    x = fmaxf(x, dppf<0x140>(x));
+    return x;
+}
+
+// ---- RoPE --------------------------------------------------------------------------------------------
+// (cos, sin) * mscale for rotation pair `ip` at position `pos`:
+// ggml_rope_cache_init + rope_yarn (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10578-10609).  theta is formed by the same
+// sequence of f32 multiplications as the reference (theta *= theta_scale per pair), not by powf.
+__device__ __forceinline__ float2 rope_cs(int pos, int ip, const RopeDev & r, float sin_sign) {
+    float theta = (float) pos;
+    for (int k = 0; k < ip; ++k) theta *= r.theta_scale;
+    const float ff           = r.freq_factors ? r.freq_factors[ip] : 1.0f;
+    const float theta_extrap = theta / ff;
+    const float theta_interp = r.freq_scale * theta_extrap;
+    float th = theta_interp, mscale = r.attn_factor;
+    if (r.ext_factor != 0.0f) {
+        const float y    = ((float) ip - r.corr0) / fmaxf(0.001f, r.corr1 - r.corr0);
+        const float ramp = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * r.ext_factor;
+        th = theta_interp * (1.0f - ramp) + theta_extrap * ramp;
+        mscale *= 1.0f + 0.1f * logf(1.0f / r.freq_scale);
+    }
+    return make_float2(cosf(th) * mscale, sinf(th) * mscale * sin_sign);
+}
+
+// rotate the wave's row in registers: lane i holds (x0, x1) = elements (2i, 2i+1) of a row of D elements
+template <int D>
+__device__ __forceinline__ float2 rope_row(float2 x, int lane, int pos, const RopeDev & r, float sin_sign) {
+    const int e0 = 2 * lane;
+    if ((r.mode & 2) == 0) {  // NORM: pairs (2i, 2i+1)
+        if (e0 < r.n_dims) {
+            const float2 cs = rope_cs(pos, lane, r, sin_sign);
+            return make_float2(x.x * cs.x - x.y * cs.y, x.x * cs.y + x.y * cs.x);
+        }
+        return x;
+    }
+    // NEOX with n_dims == D: pairs (ic, ic + D/2); the partner elements live in lane ^ (D/4)
+    constexpr int HL = D / 4;
+    const float px = __shfl_xor(x.x, HL), py = __shfl_xor(x.y, HL);
+    const bool  lo = lane < HL;
+    const int   ic = lo ? e0 : e0 - D / 2;
+    const float2 c0 = rope_cs(pos, ic, r, sin_sign), c1 = rope_cs(pos, ic + 1, r, sin_sign);
+    return lo ? make_float2(x.x * c0.x - px * c0.y, x.y * c1.x - py * c1.y)
+              : make_float2(px * c0.y + x.x * c0.x, py * c1.y + x.y * c1.x);
+}
+
+__global__ void __launch_bounds__(64) rope_f32_kernel(const float * x, const int32_t * pos, float * out, int n_head,
+                                                      int D, const RopeDev r, float sin_sign) {
+    const int t = blockIdx.y, h = blockIdx.x;
+    const float * src = x + ((size_t) t * n_head + h) * D;
+    float *       dst = out + ((size_t) t * n_head + h) * D;
+    const int p = pos[t];
+    const bool neox = r.mode & 2;
+    for (int ip = threadIdx.x; ip < D / 2; ip += 64) {
+        if (2 * ip < r.n_dims) {
+            const float2 cs = rope_cs(p, ip, r, sin_sign);
+            const int i0 = neox ? ip : 2 * ip, i1 = neox ? ip + r.n_dims / 2 : 2 * ip + 1;
+            const float x0 = src[i0], x1 = src[i1];
+            dst[i0] = x0 * cs.x - x1 * cs.y;
+            dst[i1] = x0 * cs.y + x1 * cs.x;
+        } else {  // pass-through channels (:10841-10847)
+            dst[2 * ip]     = src[2 * ip];
+            dst[2 * ip + 1] = src[2 * ip + 1];
+        }
+    }
+}
+
+// ---- row <-> tile / reference-format codecs ----------------------------------------------------------------
+// A row in flight: lane i holds the raw quants (q0, q1) of elements (2i, 2i+1) and the f16 bits of its block scale.
+struct Q2 { int q0, q1; uint16_t d; };
+
+__device__ __forceinline__ uint16_t h_bits(float f) { _Float16 h = (_Float16) f; return *reinterpret_cast<uint16_t *>(&h); }
+__device__ __forceinline__ float    h_val(uint16_t b) { return (float) *reinterpret_cast<_Float16 *>(&b); }
+
+// f32 pair -> Q2, following what ggml_cpy stores on the reference CPU backend:
+//   f16 : GGML_FP32_TO_FP16 (RN-even)
+//   q8_0: quantize_row_q8_0 AVX2 branch (/ref/ggml/src/ggml-cpu/ggml-cpu-quants.c:808-862)
+//   q4_0: quantize_row_q4_0_ref (/ref/ggml/src/ggml-quants.c:31-66), first-max-wins tie rule included
+template <int T> __device__ __forceinline__ Q2 quantize(float2 x, int lane) {
+    Q2 r;
+    if constexpr (T == PKV_TYPE_F16) {
+        r.q0 = h_bits(x.x); r.q1 = h_bits(x.y); r.d = 0;
+    } else if constexpr (T == PKV_TYPE_Q8_0) {
+        const float amax = row16_max(fmaxf(fabsf(x.x), fabsf(x.y)));
+        const float d    = amax / 127.0f;
+        const float id   = amax != 0.0f ? 127.0f / amax : 0.0f;
+        r.d  = h_bits(d);
+        r.q0 = (int) __builtin_rintf(x.x * id);
+        r.q1 = (int) __builtin_rintf(x.y * id);
+    } else {
+        // (amax, max) with the reference's sequential "first strictly greater" rule == smallest index among ties
+        float am = fabsf(x.x), mv = x.x;
+        int   ix = 2 * lane;
+        if (fabsf(x.y) > am) { am = fabsf(x.y); mv = x.y; ix = 2 * lane + 1; }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            const float oa = __shfl_xor(am, m), ov = __shfl_xor(mv, m);
+            const int   oi = __shfl_xor(ix, m);
+            if (oa > am || (oa == am && oi < ix)) { am = oa; mv = ov; ix = oi; }
+        }
+        const float d  = mv / -8.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        r.d  = h_bits(d);
+        const int a0 = (int) (signed char) (int) (x.x * id + 8.5f), a1 = (int) (signed char) (int) (x.y * id + 8.5f);
+        r.q0 = min(15, a0) & 0xFF;
+        r.q1 = min(15, a1) & 0xFF;
+    }
+    return r;
+}
+template <int T> __device__ __forceinline__ float2 dequantize(const Q2 & v) {
+    if constexpr (T == PKV_TYPE_F16) return make_float2(h_val((uint16_t) v.q0), h_val((uint16_t) v.q1));
+    else if constexpr (T == PKV_TYPE_Q8_0) { const float d = h_val(v.d); return make_float2(v.q0 * d, v.q1 * d); }
+    else { const float d = h_val(v.d); return make_float2((v.q0 - 8) * d, (v.q1 - 8) * d); }
+}
+
+// K-layout / V-layout tile access ("Pool layout", include/mi355_paged_kv.h; V interleave in pkv_attn_decode.hip)
+template <int T, bool IS_V>
+__device__ __forceinline__ void tile_write(char * tile, int row, int lane, const Q2 & v, int BS, int D) {
+    const int e0 = 2 * lane;
+    if (e0 >= D) return;
+    if constexpr (T == PKV_TYPE_F16) {
+        *reinterpret_cast<uint32_t *>(tile + ((size_t) row * D + e0) * 2) = (uint32_t) (v.q0 & 0xFFFF) | ((uint32_t) v.q1 << 16);
+    } else {
+        const int    nb = D / PKV_QK, blk = e0 / PKV_QK;
+        char *       sc = tile + tile_quant_bytes(T, BS, D);
+        if constexpr (T == PKV_TYPE_Q8_0) {
+            const uint16_t pk = (uint16_t) ((v.q0 & 0xFF) | ((v.q1 & 0xFF) << 8));
+            if (!IS_V) {
+                *reinterpret_cast<uint16_t *>(tile + (size_t) row * D + e0) = pk;
+                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + ((size_t) row * nb + blk) * 2) = v.d;
+            } else {  // int8[row/2][D/8][2][8]; half d[row/2][D/32][2]
+                *reinterpret_cast<uint16_t *>(tile + (((size_t) (row / 2) * (D / 8) + e0 / 8) * 2 + (row & 1)) * 8 + (e0 & 7)) = pk;
+                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + (((size_t) (row / 2) * nb + blk) * 2 + (row & 1)) * 2) = v.d;
+            }
+        } else {
+            if (!IS_V) {  // byte j of the block = elem j | elem (j+16) << 4  (block_q4_0)
+                const int p0 = __shfl_xor(v.q0, 8), p1 = __shfl_xor(v.q1, 8);
+                if ((lane & 15) < 8) {
+                    const uint16_t pk = (uint16_t) ((v.q0 | (p0 << 4)) | ((v.q1 | (p1 << 4)) << 8));
+                    *reinterpret_cast<uint16_t *>(tile + (size_t) row * (D / 2) + blk * 16 + 2 * (lane & 15)) = pk;
+                }
+                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + ((size_t) row * nb + blk) * 2) = v.d;
+            } else {  // nib[row/4][D/8][4][4 bytes]: byte m = d 2m | d 2m+1 << 4; half d[row/4][D/32][4]
+                *reinterpret_cast<uint8_t *>(tile + (((size_t) (row / 4) * (D / 8) + e0 / 8) * 4 + (row & 3)) * 4 + (e0 & 7) / 2) =
+                    (uint8_t) (v.q0 | (v.q1 << 4));
+                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + (((size_t) (row / 4) * nb + blk) * 4 + (row & 3)) * 2) = v.d;
+            }
+        }
+    }
+}
+template <int T, bool IS_V>
+__device__ __forceinline__ Q2 tile_read(const char * tile, int row, int lane, int BS, int D) {
+    Q2 r{0, 0, 0};
+    const int e0 = 2 * lane;
+    if (e0 >= D) return r;
+    if constexpr (T == PKV_TYPE_F16) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(tile + ((size_t) row * D + e0) * 2);
+        r.q0 = w & 0xFFFF; r.q1 = w >> 16;
+    } else {
+        const int    nb = D / PKV_QK, blk = e0 / PKV_QK;
+        const char * sc = tile + tile_quant_bytes(T, BS, D);
+        if constexpr (T == PKV_TYPE_Q8_0) {
+            uint16_t pk;
+            if (!IS_V) {
+                pk  = *reinterpret_cast<const uint16_t *>(tile + (size_t) row * D + e0);
+                r.d = *reinterpret_cast<const uint16_t *>(sc + ((size_t) row * nb + blk) * 2);
+            } else {
+                pk  = *reinterpret_cast<const uint16_t *>(tile + (((size_t) (row / 2) * (D / 8) + e0 / 8) * 2 + (row & 1)) * 8 + (e0 & 7));
+                r.d = *reinterpret_cast<const uint16_t *>(sc + (((size_t) (row / 2) * nb + blk) * 2 + (row & 1)) * 2);
+            }
+            r.q0 = (int) (signed char) (pk & 0xFF); r.q1 = (int) (signed char) (pk >> 8);
+        } else {
+            if (!IS_V) {
+                const int      j  = (lane & 15) & 7;  // lanes 0..7 read low nibbles, 8..15 the high nibbles of the same bytes
+                const uint16_t pk = *reinterpret_cast<const uint16_t *>(tile + (size_t) row * (D / 2) + blk * 16 + 2 * j);
+                const int      sh = (lane & 15) < 8 ? 0 : 4;
+                r.q0 = (pk >> sh) & 0xF; r.q1 = (pk >> (8 + sh)) & 0xF;
+                r.d  = *reinterpret_cast<const uint16_t *>(sc + ((size_t) row * nb + blk) * 2);
+            } else {
+                const uint8_t b = *reinterpret_cast<const uint8_t *>(tile + (((size_t) (row / 4) * (D / 8) + e0 / 8) * 4 + (row & 3)) * 4 + (e0 & 7) / 2);
+                r.q0 = b & 0xF; r.q1 = b >> 4;
+                r.d  = *reinterpret_cast<const uint16_t *>(sc + (((size_t) (row / 4) * nb + blk) * 4 + (row & 3)) * 2);
+            }
+        }
+    }
+    return r;
+}
+// reference-format row: f16[D] / block_q8_0[D/32] / block_q4_0[D/32] (/ref/ggml/src/ggml-common.h:161-166,203-208)
+template <int T> __device__ __forceinline__ void ref_write(char * row, int lane, const Q2 & v, int D) {
+    const int e0 = 2 * lane;
+    if constexpr (T == PKV_TYPE_Q4_0) {
+        const int p0 = __shfl_xor(v.q0, 8), p1 = __shfl_xor(v.q1, 8);
+        if (e0 >= D) return;
+        char * b = row + (size_t) (e0 / PKV_QK) * 18;
+        if ((lane & 15) < 8) *reinterpret_cast<uint16_t *>(b + 2 + 2 * (lane & 15)) = (uint16_t) ((v.q0 | (p0 << 4)) | ((v.q1 | (p1 << 4)) << 8));
+        if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(b) = v.d;
+    } else {
+        if (e0 >= D) return;
+        if constexpr (T == PKV_TYPE_F16) {
+            *reinterpret_cast<uint32_t *>(row + (size_t) e0 * 2) = (uint32_t) (v.q0 & 0xFFFF) | ((uint32_t) v.q1 << 16);
+        } else {
+            char * b = row + (size_t) (e0 / PKV_QK) * 34;
+            *reinterpret_cast<uint16_t *>(b + 2 + (e0 & 31)) = (uint16_t) ((v.q0 & 0xFF) | ((v.q1 & 0xFF) << 8));
+            if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(b) = v.d;
+        }
+    }
+}
+template <int T> __device__ __forceinline__ Q2 ref_read(const char * row, int lane, int D) {
+    Q2 r{0, 0, 0};
+    const int e0 = 2 * lane;
+    if (e0 >= D) return r;
+    if constexpr (T == PKV_TYPE_F16) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(row + (size_t) e0 * 2);
+        r.q0 = w & 0xFFFF; r.q1 = w >> 16;
+    } else if constexpr (T == PKV_TYPE_Q8_0) {
+        const char *   b  = row + (size_t) (e0 / PKV_QK) * 34;
+        const uint16_t pk = *reinterpret_cast<const uint16_t *>(b + 2 + (e0 & 31));
+        r.q0 = (int) (signed char) (pk & 0xFF); r.q1 = (int) (signed char) (pk >> 8);
+        r.d  = *reinterpret_cast<const uint16_t *>(b);
+    } else {
+        const char *   b  = row + (size_t) (e0 / PKV_QK) * 18;
+        const uint16_t pk = *reinterpret_cast<const uint16_t *>(b + 2 + 2 * ((lane & 15) & 7));
+        const int      sh = (lane & 15) < 8 ? 0 : 4;
+        r.q0 = (pk >> sh) & 0xF; r.q1 = (pk >> (8 + sh)) & 0xF;
+        r.d  = *reinterpret_cast<const uint16_t *>(b);
+    }
+    return r;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------
+struct StoreArgs {
+    const float * k_cur; const float * v_cur;
+    char * k_pool; char * v_pool;
+    const int32_t * slot_block; const int32_t * slot_off; const int32_t * pos;
+    int n_head_kv, block_size, has_rope;
+    RopeDev rope;
+};
+
+// grid (n_head_kv, n_tok, 2): z = 0 stores K (optionally roped), z = 1 stores V
+template <int KT, int VT, int D>
+__global__ void __launch_bounds__(64) kv_store_kernel(const StoreArgs a) {
+    const int h = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const bool is_v = blockIdx.z == 1;
+    const float * cur = is_v ? a.v_cur : a.k_cur;
+    if (!cur) return;
+    const int blk = a.slot_block[t];
+    if (blk < 0) return;
+    const int off = a.slot_off[t];
+    float2 x = make_float2(0.0f, 0.0f);
+    if (2 * lane < D) x = *reinterpret_cast<const float2 *>(cur + ((size_t) t * a.n_head_kv + h) * D + 2 * lane);
+    if (!is_v) {
+        if (a.has_rope) x = rope_row<D>(x, lane, a.pos[t], a.rope, 1.0f);
+        char * tile = a.k_pool + ((size_t) blk * a.n_head_kv + h) * tile_bytes(KT, a.block_size, D);
+        tile_write<KT, false>(tile, off, lane, quantize<KT>(x, lane), a.block_size, D);
+    } else {
+        char * tile = a.v_pool + ((size_t) blk * a.n_head_kv + h) * tile_bytes(VT, a.block_size, D);
+        tile_write<VT, true>(tile, off, lane, quantize<VT>(x, lane), a.block_size, D);
+    }
+}
+
+// grid (n_head_kv, n_cells): dequantize -> rope(delta) -> requantize in place (/ref/src/llama-context.cpp:447-496)
+template <int KT, int D>
+__global__ void __launch_bounds__(64) k_shift_kernel(char * k_pool, const int32_t * cell_block, const int32_t * cell_off,
+                                                     const int32_t * cell_delta, int n_head_kv, int block_size,
+                                                     const RopeDev rope) {
+    const int h = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const int delta = cell_delta[c];
+    if (delta == 0 || cell_block[c] < 0) return;
+    char * tile = k_pool + ((size_t) cell_block[c] * n_head_kv + h) * tile_bytes(KT, block_size, D);
+    float2 x = dequantize<KT>(tile_read<KT, false>(tile, cell_off[c], lane, block_size, D));
+    x = rope_row<D>(x, lane, delta, rope, 1.0f);
+    tile_write<KT, false>(tile, cell_off[c], lane, quantize<KT>(x, lane), block_size, D);
+}
+
+// grid (n_head_kv, n_tok): reference-format rows <-> tiles
+template <int T, bool IS_V, bool SCATTER, int D>
+__global__ void __launch_bounds__(64) rows_io_kernel(char * pool, char * rows, const int32_t * slot_block,
+                                                     const int32_t * slot_off, int n_head_kv, int block_size) {
+    const int h = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    if (slot_block[t] < 0) return;
+    char * tile = pool + ((size_t) slot_block[t] * n_head_kv + h) * tile_bytes(T, block_size, D);
+    char * row  = rows + ((size_t) t * n_head_kv + h) * row_size(T, D);
+    if (SCATTER) tile_write<T, IS_V>(tile, slot_off[t], lane, ref_read<T>(row, lane, D), block_size, D);
+    else         ref_write<T>(row, lane, tile_read<T, IS_V>(tile, slot_off[t], lane, block_size, D), D);
+}
+
+// grid (n_head_kv, n_cells): move single cells between blocks (seq_cp of unaligned ranges, defrag)
+template <int T, bool IS_V, int D>
+__global__ void __launch_bounds__(64) copy_cells_kernel(char * pool, const int32_t * sb, const int32_t * so,
+                                                        const int32_t * db, const int32_t * dof, int n_head_kv,
+                                                        int block_size) {
+    const int h = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    if (sb[c] < 0 || db[c] < 0) return;
+    const size_t tb = tile_bytes(T, block_size, D);
+    const Q2 v = tile_read<T, IS_V>(pool + ((size_t) sb[c] * n_head_kv + h) * tb, so[c], lane, block_size, D);
+    tile_write<T, IS_V>(pool + ((size_t) db[c] * n_head_kv + h) * tb, dof[c], lane, v, block_size, D);
+}
+
+__global__ void __launch_bounds__(256) copy_blocks_kernel(char * pool, size_t block_bytes, const int32_t * src,
+                                                          const int32_t * dst) {
+    const int i = blockIdx.y;
+    if (src[i] < 0 || dst[i] < 0 || src[i] == dst[i]) return;
+    const uint4 * s = reinterpret_cast<const uint4 *>(pool + (size_t) src[i] * block_bytes);
+    uint4 *       d = reinterpret_cast<uint4 *>(pool + (size_t) dst[i] * block_bytes);
+    const size_t  n = block_bytes / 16;
+    for (size_t j = (size_t) blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t) gridDim.x * 256) d[j] = s[j];
+}
+
+}  // namespace
+
+// ---- host launchers -------------------------------------------------------------------------------------------
+int make_rope(const pkv_rope_params * p, int head_dim, RopeDev * out) {
+    PKV_REQUIRE(p != nullptr, "rope params missing");
+    PKV_REQUIRE(p->n_dims > 0 && p->n_dims % 2 == 0 && p->n_dims <= head_dim, "rope: bad n_dims %d", p->n_dims);
+    if (p->mode != 0 && p->mode != 2) {
+        set_error("rope: mode %d not supported (NORM = 0, NEOX = 2)", p->mode);
+        return PKV_ERR_UNSUPPORTED;
+    }
+    out->n_dims = p->n_dims; out->mode = p->mode;
+    out->freq_scale = p->freq_scale; out->ext_factor = p->ext_factor; out->attn_factor = p->attn_factor;
+    out->theta_scale = powf(p->freq_base, -2.0f / p->n_dims);
+    // ggml_rope_yarn_corr_dims (/ref/ggml/src/ggml.c:3735-3747)
+    auto corr = [&](float n_rot) { return p->n_dims * logf(p->n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(p->freq_base)); };
+    out->corr0 = fmaxf(0.0f, floorf(corr(p->beta_fast)));
+    out->corr1 = fminf((float) (p->n_dims - 1), ceilf(corr(p->beta_slow)));
+    out->freq_factors = p->freq_factors;
+    return PKV_OK;
+}
+
+int launch_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, int n_head, int D, const RopeDev & r,
+                    int inverse, hipStream_t st) {
+    if (n_tok == 0) return PKV_OK;
+    hipLaunchKernelGGL(rope_f32_kernel, dim3(n_head, n_tok), dim3(64), 0, st, x, pos, out, n_head, D, r, inverse ? -1.0f : 1.0f);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+
+template <int KT, int VT>
+static int store_d(const StoreArgs & a, int n_tok, int D, hipStream_t st) {
+    dim3 grid(a.n_head_kv, n_tok, 2);
+    if (D == 128)      hipLaunchKernelGGL((kv_store_kernel<KT, VT, 128>), grid, dim3(64), 0, st, a);
+    else if (D == 64)  hipLaunchKernelGGL((kv_store_kernel<KT, VT, 64>), grid, dim3(64), 0, st, a);
+    else { set_error("pkv_kv_store: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+template <int KT>
+static int store_v(const StoreArgs & a, int type_v, int n_tok, int D, hipStream_t st) {
+    switch (type_v) {
+        case PKV_TYPE_F16:  return store_d<KT, PKV_TYPE_F16>(a, n_tok, D, st);
+        case PKV_TYPE_Q8_0: return store_d<KT, PKV_TYPE_Q8_0>(a, n_tok, D, st);
+        case PKV_TYPE_Q4_0: return store_d<KT, PKV_TYPE_Q4_0>(a, n_tok, D, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
+int launch_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
+                    const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos, const RopeDev * rope,
+                    int n_tok, int n_head_kv, int D, int block_size, hipStream_t st) {
+    if (n_tok == 0) return PKV_OK;
+    StoreArgs a{};
+    a.k_cur = k_cur; a.v_cur = v_cur; a.k_pool = (char *) k_pool; a.v_pool = (char *) v_pool;
+    a.slot_block = slot_block; a.slot_off = slot_off; a.pos = pos;
+    a.n_head_kv = n_head_kv; a.block_size = block_size; a.has_rope = rope != nullptr;
+    if (rope) {
+        a.rope = *rope;
+        if ((rope->mode & 2) && rope->n_dims != D) { set_error("fused NEOX rope needs n_dims == head_dim"); return PKV_ERR_UNSUPPORTED; }
+    }
+    switch (type_k) {
+        case PKV_TYPE_F16:  return store_v<PKV_TYPE_F16>(a, type_v, n_tok, D, st);
+        case PKV_TYPE_Q8_0: return store_v<PKV_TYPE_Q8_0>(a, type_v, n_tok, D, st);
+        case PKV_TYPE_Q4_0: return store_v<PKV_TYPE_Q4_0>(a, type_v, n_tok, D, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
+template <int KT>
+static int shift_d(void * k_pool, const int32_t * cb, const int32_t * co, const int32_t * cd, int n_cells, int n_head_kv,
+                   int D, int block_size, const RopeDev & r, hipStream_t st) {
+    dim3 grid(n_head_kv, n_cells);
+    if (D == 128)     hipLaunchKernelGGL((k_shift_kernel<KT, 128>), grid, dim3(64), 0, st, (char *) k_pool, cb, co, cd, n_head_kv, block_size, r);
+    else if (D == 64) hipLaunchKernelGGL((k_shift_kernel<KT, 64>), grid, dim3(64), 0, st, (char *) k_pool, cb, co, cd, n_head_kv, block_size, r);
+    else { set_error("pkv_k_shift: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+
+int launch_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,
+                   const int32_t * cell_delta, int n_cells, int n_head_kv, int D, int block_size, const RopeDev & r,
+                   hipStream_t st) {
+    if (n_cells == 0) return PKV_OK;
+    if ((r.mode & 2) && r.n_dims != D) { set_error("K-shift NEOX rope needs n_dims == head_dim"); return PKV_ERR_UNSUPPORTED; }
+    switch (type_k) {
+        case PKV_TYPE_F16:  return shift_d<PKV_TYPE_F16>(k_pool, cell_block, cell_off, cell_delta, n_cells, n_head_kv, D, block_size, r, st);
+        case PKV_TYPE_Q8_0: return shift_d<PKV_TYPE_Q8_0>(k_pool, cell_block, cell_off, cell_delta, n_cells, n_head_kv, D, block_size, r, st);
+        case PKV_TYPE_Q4_0: return shift_d<PKV_TYPE_Q4_0>(k_pool, cell_block, cell_off, cell_delta, n_cells, n_head_kv, D, block_size, r, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
+int launch_copy_blocks(void * pool, size_t block_bytes, const int32_t * src, const int32_t * dst, int n, hipStream_t st) {
+    if (n == 0) return PKV_OK;
+    const int gx = (int) ((block_bytes / 16 + 255) / 256);
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(gx < 64 ? gx : 64, n), dim3(256), 0, st, (char *) pool, block_bytes, src, dst);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+
+template <int T, bool IS_V>
+static int cells_d(void * pool, const int32_t * sb, const int32_t * so, const int32_t * db, const int32_t * dof, int n,
+                   int n_head_kv, int D, int block_size, hipStream_t st) {
+    dim3 grid(n_head_kv, n);
+    if (D == 128)     hipLaunchKernelGGL((copy_cells_kernel<T, IS_V, 128>), grid, dim3(64), 0, st, (char *) pool, sb, so, db, dof, n_head_kv, block_size);
+    else if (D == 64) hipLaunchKernelGGL((copy_cells_kernel<T, IS_V, 64>), grid, dim3(64), 0, st, (char *) pool, sb, so, db, dof, n_head_kv, block_size);
+    else { set_error("cell copy: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+
+int launch_copy_cells(void * pool, int type, int is_v, const int32_t * sb, const int32_t * so, const int32_t * db,
+                      const int32_t * dof, int n, int n_head_kv, int D, int block_size, hipStream_t st) {
+    if (n == 0) return PKV_OK;
+    switch (type) {
+        case PKV_TYPE_F16:  return cells_d<PKV_TYPE_F16, false>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st);
+        case PKV_TYPE_Q8_0: return is_v ? cells_d<PKV_TYPE_Q8_0, true>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st)
+                                        : cells_d<PKV_TYPE_Q8_0, false>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st);
+        case PKV_TYPE_Q4_0: return is_v ? cells_d<PKV_TYPE_Q4_0, true>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st)
+                                        : cells_d<PKV_TYPE_Q4_0, false>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
+template <int T, bool IS_V, bool SC>
+static int rows_d(void * pool, void * rows, const int32_t * sb, const int32_t * so, int n_tok, int n_head_kv, int D,
+                  int block_size, hipStream_t st) {
+    dim3 grid(n_head_kv, n_tok);
+    if (D == 128)     hipLaunchKernelGGL((rows_io_kernel<T, IS_V, SC, 128>), grid, dim3(64), 0, st, (char *) pool, (char *) rows, sb, so, n_head_kv, block_size);
+    else if (D == 64) hipLaunchKernelGGL((rows_io_kernel<T, IS_V, SC, 64>), grid, dim3(64), 0, st, (char *) pool, (char *) rows, sb, so, n_head_kv, block_size);
+    else { set_error("row I/O: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+template <int T>
+static int rows_t(void * pool, void * rows, const int32_t * sb, const int32_t * so, int n_tok, int n_head_kv, int D,
+                  int block_size, bool is_v, bool scatter, hipStream_t st) {
+    if (is_v) return scatter ? rows_d<T, true, true>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st)
+                             : rows_d<T, true, false>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st);
+    return scatter ? rows_d<T, false, true>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st)
+                   : rows_d<T, false, false>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st);
+}
+
+int launch_rows_io(void * pool, int type, int is_v, void * rows, const int32_t * slot_block, const int32_t * slot_off,
+                   int n_tok, int n_head_kv, int D, int block_size, bool scatter, hipStream_t st) {
+    if (n_tok == 0) return PKV_OK;
+    switch (type) {
+        case PKV_TYPE_F16:  return rows_t<PKV_TYPE_F16>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st);
+        case PKV_TYPE_Q8_0: return rows_t<PKV_TYPE_Q8_0>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st);
+        case PKV_TYPE_Q4_0: return rows_t<PKV_TYPE_Q4_0>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
+}  // namespace pkv

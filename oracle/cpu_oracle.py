@@ -155,20 +155,20 @@ def pool_alloc(t: int, n_blocks: int, n_head_kv: int, block_size: int, D: int) -
     return np.zeros((n_blocks, n_head_kv, tile_bytes(t, block_size, D)), np.uint8)
 
 
-def pool_store(pool, t, rows, slot_block, slot_off, *, D, block_size):
+def pool_store(pool, t, is_v, rows, slot_block, slot_off, *, D, block_size):
     """rows uint8 [n_tok][n_head_kv][row_size] scattered to (slot_block[t], slot_off[t])"""
     rows = np.ascontiguousarray(rows, np.uint8)
     sb = np.ascontiguousarray(slot_block, np.int32)
     so = np.ascontiguousarray(slot_off, np.int32)
     assert pool.flags.c_contiguous
-    port().pkv_o_pool_store(_p(pool), t, _p(rows), _p(sb), _p(so), rows.shape[0], rows.shape[1], D, block_size)
+    port().pkv_o_pool_store(_p(pool), t, int(is_v), _p(rows), _p(sb), _p(so), rows.shape[0], rows.shape[1], D, block_size)
 
 
-def pool_gather(pool, t, block_table, n_kv, *, D, block_size) -> np.ndarray:
+def pool_gather(pool, t, is_v, block_table, n_kv, *, D, block_size) -> np.ndarray:
     bt = np.ascontiguousarray(block_table, np.int32)
     n_head_kv = pool.shape[1]
     out = np.empty((n_head_kv, n_kv, row_size(t, D)), np.uint8)
-    port().pkv_o_pool_gather(_p(pool), t, _p(bt), n_kv, n_head_kv, D, block_size, _p(out))
+    port().pkv_o_pool_gather(_p(pool), t, int(is_v), _p(bt), n_kv, n_head_kv, D, block_size, _p(out))
     return out
 
 

@@ -1,0 +1,215 @@
+"""Pure-Python restatement of the reference's KV-cell bookkeeping.  TEST INFRASTRUCTURE ONLY (small cases).
+
+`UnifiedCells` follows llama_kv_cache_unified for transformer (non-recurrent) models, /root/reference/src/llama-kv-cache.cpp:
+clear :158-171, seq_rm :173-242, seq_cp :244-293, seq_keep :295-325, seq_add :327-383, seq_div :385-429,
+seq_pos_max :431-441, find_slot (non-recurrent branch) :622-672, get_n_tokens :133-141, get_used_cells (`used`).
+It is the oracle for WHAT each sequence can see (the multiset of positions per sequence) — the paged block manager
+must expose the same view through its block tables.
+
+`ToyBlockManager` / `ToyKVCacheManager` restate the fork prototype recovered in SURVEY.md §8(a-toy)
+(/root/reference/tests/test_block_manager.cpp, /root/reference/tests/test_kv_cache.cpp); the prototype's sources are
+absent from the reference tree and its tests assert nothing, so beyond the index sequences those tests print this
+part is "parity unpinned".
+"""
+from __future__ import annotations
+
+INT_MAX = 2 ** 31 - 1
+
+
+class Cell:
+    __slots__ = ("pos", "delta", "seq")
+
+    def __init__(self):
+        self.pos, self.delta, self.seq = -1, 0, set()
+
+
+class UnifiedCells:
+    def __init__(self, size: int):
+        self.size, self.head, self.used = size, 0, 0
+        self.cells = [Cell() for _ in range(size)]
+        self.has_shift = False
+
+    def clear(self):
+        for c in self.cells:
+            c.pos, c.seq = -1, set()
+        self.head = self.used = 0
+
+    def find_slot(self, seq_ids, poss) -> bool:
+        n = len(seq_ids)
+        if n > self.size:
+            return False
+        tested = 0
+        while True:
+            if self.head + n > self.size:
+                tested += self.size - self.head
+                self.head = 0
+                continue
+            found = True
+            for i in range(n):
+                if self.cells[self.head + i].pos >= 0:
+                    found = False
+                    self.head += i + 1
+                    tested += i + 1
+                    break
+            if found:
+                break
+            if tested >= self.size:
+                return False
+        for k in range(n):
+            c = self.cells[self.head + k]
+            c.pos = poss[k]
+            c.seq.add(seq_ids[k])
+        self.used += n
+        return True
+
+    def advance_head(self, n):  # llama_context::decode :1347-1352
+        self.head += n
+        if self.head >= self.size:
+            self.head = 0
+
+    @staticmethod
+    def _range(p0, p1):
+        return (0 if p0 < 0 else p0), (INT_MAX if p1 < 0 else p1)
+
+    def seq_rm(self, seq_id, p0, p1) -> bool:
+        p0, p1 = self._range(p0, p1)
+        new_head = self.size
+        for i, c in enumerate(self.cells):
+            if p0 <= c.pos < p1:
+                if seq_id < 0:
+                    c.seq.clear()
+                elif seq_id in c.seq:
+                    c.seq.discard(seq_id)
+                else:
+                    continue
+                if not c.seq:
+                    if c.pos >= 0:
+                        self.used -= 1
+                    c.pos = -1
+                    if new_head == self.size:
+                        new_head = i
+        if new_head != self.size and new_head < self.head:
+            self.head = new_head
+        return True
+
+    def seq_cp(self, src, dst, p0, p1):
+        if src == dst:
+            return
+        p0, p1 = self._range(p0, p1)
+        self.head = 0
+        for c in self.cells:
+            if src in c.seq and p0 <= c.pos < p1:
+                c.seq.add(dst)
+
+    def seq_keep(self, seq_id):
+        new_head = self.size
+        for i, c in enumerate(self.cells):
+            if seq_id not in c.seq:
+                if c.pos >= 0:
+                    self.used -= 1
+                c.pos = -1
+                c.seq.clear()
+                if new_head == self.size:
+                    new_head = i
+            else:
+                c.seq = {seq_id}
+        if new_head != self.size and new_head < self.head:
+            self.head = new_head
+
+    def seq_add(self, seq_id, p0, p1, delta):
+        if delta == 0:
+            return
+        p0, p1 = self._range(p0, p1)
+        if p0 == p1:
+            return
+        new_head = self.size
+        for i, c in enumerate(self.cells):
+            if seq_id in c.seq and p0 <= c.pos < p1:
+                self.has_shift = True
+                c.pos += delta
+                c.delta += delta
+                if c.pos < 0:
+                    if c.seq:
+                        self.used -= 1
+                    c.pos = -1
+                    c.seq.clear()
+                    if new_head == self.size:
+                        new_head = i
+        self.head = new_head if new_head != self.size else 0
+
+    def seq_div(self, seq_id, p0, p1, d):
+        if d == 1:
+            return
+        p0, p1 = self._range(p0, p1)
+        if p0 == p1:
+            return
+        for c in self.cells:
+            if seq_id in c.seq and p0 <= c.pos < p1:
+                self.has_shift = True
+                old = c.pos
+                c.pos //= d
+                c.delta += c.pos - old
+
+    def seq_pos_max(self, seq_id) -> int:
+        r = 0
+        for c in self.cells:
+            if seq_id in c.seq:
+                r = max(r, c.pos)
+        return r
+
+    def get_n_tokens(self) -> int:
+        return sum(len(c.seq) for c in self.cells)
+
+    def get_used_cells(self) -> int:
+        return self.used
+
+    # what a sequence attends to
+    def positions(self, seq_id):
+        return sorted(c.pos for c in self.cells if seq_id in c.seq)
+
+    def shared(self, seq_id) -> bool:
+        return any(seq_id in c.seq and len(c.seq) > 1 for c in self.cells)
+
+
+class ToyBlockManager:
+    def __init__(self, n):
+        self.used = [False] * n
+
+    def allocateBlock(self):
+        for i, u in enumerate(self.used):
+            if not u:
+                self.used[i] = True
+                return i
+        for i, u in enumerate(self.used):  # evictBlock: lowest allocated index, cleared then re-marked
+            if u:
+                return i
+        return -1
+
+    def freeBlock(self, i):
+        if 0 <= i < len(self.used):
+            self.used[i] = False
+
+    def getBlockStatus(self):
+        return list(self.used)
+
+
+class ToyKVCacheManager:
+    def __init__(self, cap):
+        self.cap, self.blocks = cap, [[False] * cap]
+
+    def insert(self):
+        for b, blk in enumerate(self.blocks):
+            for s, u in enumerate(blk):
+                if not u:
+                    blk[s] = True
+                    return b, s
+        self.blocks.append([False] * self.cap)
+        self.blocks[-1][0] = True
+        return len(self.blocks) - 1, 0
+
+    def free(self, e):
+        b, s = e
+        if 0 <= b < len(self.blocks) and 0 <= s < self.cap:
+            self.blocks[b][s] = False
+            return True
+        return False

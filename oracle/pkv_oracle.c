@@ -383,46 +383,74 @@ size_t pkv_o_tile_bytes(int type, int block_size, int D) {
     }
 }
 
-// one reference-format row (one kv head of one token) <-> its place inside a tile
-static void tile_put_row(uint8_t * tile, int type, int off, const uint8_t * row, int D, int block_size) {
-    if (type == PKV_O_F16) { memcpy(tile + (size_t) off * D * 2, row, (size_t) D * 2); return; }
-    const int nb = D / QK, qb = type == PKV_O_Q8_0 ? QK : QK / 2, bb = qb + 2;
-    uint8_t * qs = tile + (size_t) off * nb * qb;
-    uint8_t * ds = tile + (size_t) block_size * nb * qb + (size_t) off * nb * 2;
-    for (int b = 0; b < nb; ++b) {
-        memcpy(ds + b * 2, row + (size_t) b * bb, 2);
-        memcpy(qs + (size_t) b * qb, row + (size_t) b * bb + 2, qb);
+// one reference-format row (one kv head of one token) <-> its place inside a tile.
+// K tiles: quants [tok][...] then scales [tok][D/32].  V tiles of quantized types interleave TL tokens per 8-d group
+// (q8_0: TL 2, q4_0: TL 4 with byte m = d 2m | d 2m+1 << 4); scales [tok/TL][D/32][TL].  See include/mi355_paged_kv.h.
+static void tile_row(uint8_t * tile, int type, int is_v, int off, uint8_t * row, int D, int block_size, int put) {
+#define MOVE(tp, rp, n) do { if (put) memcpy((tp), (rp), (n)); else memcpy((rp), (tp), (n)); } while (0)
+    if (type == PKV_O_F16) { MOVE(tile + (size_t) off * D * 2, row, (size_t) D * 2); return; }
+    const int nb = D / QK;
+    uint8_t * sc = tile + (type == PKV_O_Q8_0 ? (size_t) block_size * D : (size_t) block_size * D / 2);
+    if (type == PKV_O_Q8_0) {
+        for (int b = 0; b < nb; ++b) {
+            uint8_t * rb = row + (size_t) b * 34;
+            if (!is_v) {
+                MOVE(sc + ((size_t) off * nb + b) * 2, rb, 2);
+                MOVE(tile + (size_t) off * D + b * QK, rb + 2, QK);
+            } else {
+                MOVE(sc + (((size_t) (off / 2) * nb + b) * 2 + (off & 1)) * 2, rb, 2);
+                for (int g = 0; g < 4; ++g)  // four 8-d groups per block
+                    MOVE(tile + (((size_t) (off / 2) * (D / 8) + b * 4 + g) * 2 + (off & 1)) * 8, rb + 2 + g * 8, 8);
+            }
+        }
+    } else {
+        for (int b = 0; b < nb; ++b) {
+            uint8_t * rb = row + (size_t) b * 18;
+            if (!is_v) {
+                MOVE(sc + ((size_t) off * nb + b) * 2, rb, 2);
+                MOVE(tile + (size_t) off * (D / 2) + b * 16, rb + 2, 16);
+            } else {
+                MOVE(sc + (((size_t) (off / 4) * nb + b) * 4 + (off & 3)) * 2, rb, 2);
+                // reference byte j = elem j | elem (j+16) << 4; tile byte m of group g = elem 8g+2m | elem 8g+2m+1 << 4
+                for (int g = 0; g < 4; ++g) {
+                    uint8_t * tp = tile + (((size_t) (off / 4) * (D / 8) + b * 4 + g) * 4 + (off & 3)) * 4;
+                    for (int m = 0; m < 4; ++m) {
+                        const int e0 = 8 * g + 2 * m, e1 = e0 + 1;
+                        if (put) {
+                            const int n0 = e0 < 16 ? rb[2 + e0] & 0xF : rb[2 + e0 - 16] >> 4;
+                            const int n1 = e1 < 16 ? rb[2 + e1] & 0xF : rb[2 + e1 - 16] >> 4;
+                            tp[m] = (uint8_t) (n0 | (n1 << 4));
+                        } else {
+                            const int n0 = tp[m] & 0xF, n1 = tp[m] >> 4;
+                            if (e0 < 16) rb[2 + e0] = (uint8_t) ((rb[2 + e0] & 0xF0) | n0); else rb[2 + e0 - 16] = (uint8_t) ((rb[2 + e0 - 16] & 0x0F) | (n0 << 4));
+                            if (e1 < 16) rb[2 + e1] = (uint8_t) ((rb[2 + e1] & 0xF0) | n1); else rb[2 + e1 - 16] = (uint8_t) ((rb[2 + e1 - 16] & 0x0F) | (n1 << 4));
+                        }
+                    }
+                }
+            }
+        }
     }
-}
-static void tile_get_row(const uint8_t * tile, int type, int off, uint8_t * row, int D, int block_size) {
-    if (type == PKV_O_F16) { memcpy(row, tile + (size_t) off * D * 2, (size_t) D * 2); return; }
-    const int nb = D / QK, qb = type == PKV_O_Q8_0 ? QK : QK / 2, bb = qb + 2;
-    const uint8_t * qs = tile + (size_t) off * nb * qb;
-    const uint8_t * ds = tile + (size_t) block_size * nb * qb + (size_t) off * nb * 2;
-    for (int b = 0; b < nb; ++b) {
-        memcpy(row + (size_t) b * bb, ds + b * 2, 2);
-        memcpy(row + (size_t) b * bb + 2, qs + (size_t) b * qb, qb);
-    }
+#undef MOVE
 }
 
-void pkv_o_pool_store(void * pool, int type, const void * rows, const int32_t * slot_block,
+void pkv_o_pool_store(void * pool, int type, int is_v, const void * rows, const int32_t * slot_block,
                       const int32_t * slot_off, int n_tok, int n_head_kv, int D, int block_size) {
     const size_t tb = pkv_o_tile_bytes(type, block_size, D), rb = pkv_o_row_size(type, D);
     for (int t = 0; t < n_tok; ++t) {
         if (slot_block[t] < 0) continue;
         for (int h = 0; h < n_head_kv; ++h)
-            tile_put_row((uint8_t *) pool + ((size_t) slot_block[t] * n_head_kv + h) * tb, type, slot_off[t],
-                         (const uint8_t *) rows + ((size_t) t * n_head_kv + h) * rb, D, block_size);
+            tile_row((uint8_t *) pool + ((size_t) slot_block[t] * n_head_kv + h) * tb, type, is_v, slot_off[t],
+                     (uint8_t *) rows + ((size_t) t * n_head_kv + h) * rb, D, block_size, 1);
     }
 }
 
-void pkv_o_pool_gather(const void * pool, int type, const int32_t * block_table, int n_kv,
+void pkv_o_pool_gather(const void * pool, int type, int is_v, const int32_t * block_table, int n_kv,
                        int n_head_kv, int D, int block_size, void * dst) {
     const size_t tb = pkv_o_tile_bytes(type, block_size, D), rb = pkv_o_row_size(type, D);
     for (int h = 0; h < n_head_kv; ++h)
         for (int i = 0; i < n_kv; ++i)
-            tile_get_row((const uint8_t *) pool + ((size_t) block_table[i / block_size] * n_head_kv + h) * tb, type,
-                         i % block_size, (uint8_t *) dst + ((size_t) h * n_kv + i) * rb, D, block_size);
+            tile_row((uint8_t *) pool + ((size_t) block_table[i / block_size] * n_head_kv + h) * tb, type, is_v,
+                     i % block_size, (uint8_t *) dst + ((size_t) h * n_kv + i) * rb, D, block_size, 0);
 }
 
 int pkv_o_attn_paged(const float * q, const void * k_pool, const void * v_pool,
@@ -437,8 +465,8 @@ int pkv_o_attn_paged(const float * q, const void * k_pool, const void * v_pool,
         void * kc = malloc(pkv_o_row_size(type_k, D) * (size_t) n_kv * n_head_kv);
         void * vc = malloc(pkv_o_row_size(type_v, D) * (size_t) n_kv * n_head_kv);
         uint16_t * mask = (uint16_t *) malloc(sizeof(uint16_t) * (size_t) n_q * n_kv);
-        pkv_o_pool_gather(k_pool, type_k, block_table + (size_t) s * max_blocks, n_kv, n_head_kv, D, block_size, kc);
-        pkv_o_pool_gather(v_pool, type_v, block_table + (size_t) s * max_blocks, n_kv, n_head_kv, D, block_size, vc);
+        pkv_o_pool_gather(k_pool, type_k, 0, block_table + (size_t) s * max_blocks, n_kv, n_head_kv, D, block_size, kc);
+        pkv_o_pool_gather(v_pool, type_v, 1, block_table + (size_t) s * max_blocks, n_kv, n_head_kv, D, block_size, vc);
         // causal mask as llm_graph_input_attn_kv_unified::set_input builds it (src/llama-graph.cpp:429-468):
         // 0 where cell.pos <= query pos, -inf otherwise
         for (int j = 0; j < n_q; ++j) {

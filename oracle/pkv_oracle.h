@@ -64,16 +64,16 @@ int pkv_o_flash_attn_f64(const float * q, const void * k, const void * v, const 
                          int type_k, int type_v, float scale, float logit_softcap);
 
 // ---- paged pool layout (defined by include/mi355_paged_kv.h "Pool layout") -------------------------
-// tile(block b, kv-head h) = [block_size tokens][D] of type; quantized types keep the quants first and the
-// per-32 f16 scales after them inside the tile.
+// tile(block b, kv-head h) = block_size tokens x D of type; quantized types keep the quants first and the
+// per-32 f16 scales after them inside the tile; V tiles of quantized types interleave tokens per 8-d group (is_v).
 size_t pkv_o_tile_bytes(int type, int block_size, int D);
 // scatter reference-format rows (rows: [n_tok][n_head_kv][row_size(type,D)], i.e. one KV-cache row per token,
 // src/llama-kv-cache.cpp:100) into the pool at (slot_block[t], slot_off[t]).
-void pkv_o_pool_store(void * pool, int type, const void * rows, const int32_t * slot_block,
+void pkv_o_pool_store(void * pool, int type, int is_v, const void * rows, const int32_t * slot_block,
                       const int32_t * slot_off, int n_tok, int n_head_kv, int D, int block_size);
 // de-page: logical token i of the sequence lives in block_table[i / block_size] at offset i % block_size.
 // dst: reference-format [n_head_kv][n_kv][row_size(type,D)] (the layout k/v have in pkv_o_flash_attn_ext).
-void pkv_o_pool_gather(const void * pool, int type, const int32_t * block_table, int n_kv,
+void pkv_o_pool_gather(const void * pool, int type, int is_v, const int32_t * block_table, int n_kv,
                        int n_head_kv, int D, int block_size, void * dst);
 // paged attention for n_seq independent sequences, one or more query tokens each, causal by position:
 // query j of sequence s (q_pos = seq_lens[s] - n_q + j) sees logical tokens i <= q_pos.

@@ -1,0 +1,45 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/*.h declares; compute entry points
+refuse to run without a device (there is no CPU fallback to fall into)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+
+def declared_functions(header_text):
+    text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pkv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(pkv):
+    names = declared_functions(open(pkv.HEADER_PATH).read())
+    assert len(names) > 40
+    L = pkv.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.pkv_abi_version() == 1
+
+
+def test_layout_helpers_match_reference_row_sizes(pkv, O):
+    for t in (pkv.F16, pkv.Q8_0, pkv.Q4_0):
+        for D in (64, 128):
+            assert pkv.row_size(t, D) == O.row_size(t, D)
+            assert pkv.tile_bytes(t, 128, D) == O.tile_bytes(t, 128, D) == 128 * pkv.row_size(t, D)
+    # bytes per 1024-element KV row
+    assert [pkv.row_size(t, 1024) for t in (pkv.F16, pkv.Q8_0, pkv.Q4_0)] == [2048, 1088, 576]
+    assert pkv.pool_bytes(pkv.F16, 32, 8, 128, 128) == 8 * 1024 * 1024    # 8B ctx 4096: 8 MiB K per layer
+
+
+def test_compute_refuses_without_device(pkv):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert pkv.device_count() == 0
+    a = pkv.AttnArgs()
+    assert pkv.lib().pkv_attn_decode(C.byref(a), None) == pkv.ERR_NO_DEVICE
+    assert b"no CPU path" in pkv.lib().pkv_last_error()
+    x = np.zeros(4, np.int32).ctypes.data_as(C.c_void_p)
+    assert pkv.lib().pkv_kv_store(x, x, x, x, pkv.F16, pkv.F16, x, x, x, None, 1, 1, 128, 128, None) == pkv.ERR_NO_DEVICE
+    with pytest.raises(pkv.PkvError):
+        pkv.PagedKVCache(n_blocks=4, n_layer=2)       # device pools need a device

@@ -1,0 +1,162 @@
+"""-m gpu: paged single-token decode (HIP, through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (north_star): attention output max-abs <= 1e-3 vs the reference CPU path AND NMSE <= 5e-4
+(tests/test-backend-ops.cpp:3216); against exact (f64) arithmetic the kernel must be at least as close as the
+reference itself is."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import cases_of
+from gpu_util import dev, make_paged_case, nmse
+
+pytestmark = pytest.mark.gpu
+TYPES = {"f16": 1, "q8_0": 8, "q4_0": 2}
+
+
+def run_decode(pkv, q, kp, vp, bt, sl, *, n_head_kv, tk, tv, bs=128, softcap=0.0, slot_pos=None, q_pos=None):
+    n_seq, n_head, D = q.shape
+    out = pkv.attn_decode(dev(q), dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=n_head_kv, type_k=tk, type_v=tv, block_size=bs,
+                          scale=D ** -0.5, max_seq_len=max(1, int(sl.max())), logit_softcap=softcap,
+                          slot_pos=None if slot_pos is None else dev(slot_pos), q_pos=None if q_pos is None else dev(q_pos))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("tk,tv", [("f16", "f16"), ("q8_0", "q8_0"), ("q4_0", "q4_0"), ("q8_0", "f16"), ("f16", "q8_0"), ("q4_0", "q8_0")])
+@pytest.mark.parametrize("D,n_head,n_head_kv", [(128, 32, 8), (128, 8, 1), (128, 4, 4), (64, 32, 4), (128, 4, 2)])
+def test_decode_matches_oracle(pkv, O, tk, tv, D, n_head, n_head_kv):
+    tk, tv = TYPES[tk], TYPES[tv]
+    rng = np.random.default_rng(D + n_head * 3 + tk + tv * 5)
+    lens = [1, 2, 31, 127, 128, 129, 255, 256, 300, 640]          # ragged: partial last blocks, single-token, multi-block
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=n_head, n_head_kv=n_head_kv, type_k=tk, type_v=tv)
+    q = rng.uniform(-1, 1, (len(lens), n_head, D)).astype(np.float32)
+    got = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=n_head_kv, tk=tk, tv=tv)
+    ref = O.attn_paged(q[:, :, None, :], kp, vp, bt, sl, n_q=1, type_k=tk, type_v=tv, block_size=128, scale=D ** -0.5)[:, 0]
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-3
+    assert nmse(got, ref) <= 5e-4
+    # accuracy yardstick: exact arithmetic on the same stored K/V
+    for s, n in enumerate(lens):
+        kc = O.pool_gather(kp, tk, 0, bt[s], n, D=D, block_size=128)
+        vc = O.pool_gather(vp, tv, 1, bt[s], n, D=D, block_size=128)
+        exact = O.flash_attn_f64(q[s][:, None, :], kc, vc, None, type_k=tk, type_v=tv, scale=D ** -0.5)[0]
+        e_ref = np.abs(ref[s] - exact).max()
+        e_gpu = np.abs(got[s] - exact).max()
+        assert e_gpu <= max(2.0 * e_ref, 2e-4), (s, n, e_gpu, e_ref)
+
+
+def test_decode_golden_vectors(pkv, O, golden):
+    """the reference's own outputs (tests/golden/flash_attn_ext.npz) for the single-query cases, K/V paged on the fly"""
+    g = golden["flash_attn_ext"]
+    rng = np.random.default_rng(0)
+    n_run = 0
+    for name in cases_of(g):
+        D, nh, nkv, n_kv, n_q, tk, tv = (int(x) for x in g[f"{name}__meta"])
+        if n_q != 1:
+            continue
+        nb = -(-n_kv // 128)
+        bt = rng.permutation(nb + 2)[:nb].astype(np.int32)[None]
+        kp, vp = O.pool_alloc(tk, nb + 2, nkv, 128, D), O.pool_alloc(tv, nb + 2, nkv, 128, D)
+        idx = np.arange(n_kv)
+        O.pool_store(kp, tk, 0, g[f"{name}__k"].transpose(1, 0, 2), bt[0][idx // 128], idx % 128, D=D, block_size=128)
+        O.pool_store(vp, tv, 1, g[f"{name}__v"].transpose(1, 0, 2), bt[0][idx // 128], idx % 128, D=D, block_size=128)
+        q = g[f"{name}__q"][:, 0, :][None]
+        got = run_decode(pkv, q, kp, vp, bt, np.array([n_kv], np.int32), n_head_kv=nkv, tk=tk, tv=tv,
+                         softcap=float(g[f"{name}__softcap"]))
+        ref = g[f"{name}__out"]
+        assert np.abs(got[0] - ref[0]).max() <= 1e-3, name
+        assert nmse(got[0], ref[0]) <= 5e-4, name
+        n_run += 1
+    assert n_run >= 6
+
+
+def test_decode_logits_within_1e3(pkv, O):
+    """north_star: 'within 1e-3 on the attention logits'.  The kernel's logits are recovered exactly from its own
+    output by using V = one-hot rows: out[h][d] = softmax(logits)[d] for the first D tokens."""
+    rng = np.random.default_rng(9)
+    D, nh, nkv, n = 128, 8, 2, 128
+    for tk in (1, 8, 2):
+        kr = O.from_float(tk, rng.uniform(-1, 1, (n, nkv, D)).astype(np.float32))
+        eye = np.zeros((n, nkv, D), np.float32)
+        eye[np.arange(n), :, np.arange(n)] = 1.0
+        vr = O.from_float(1, eye)
+        kp, vp = O.pool_alloc(tk, 1, nkv, 128, D), O.pool_alloc(1, 1, nkv, 128, D)
+        z = np.zeros(n, np.int32)
+        O.pool_store(kp, tk, 0, kr, z, np.arange(n), D=D, block_size=128)
+        O.pool_store(vp, 1, 1, vr, z, np.arange(n), D=D, block_size=128)
+        q = rng.uniform(-1, 1, (1, nh, D)).astype(np.float32)
+        got = run_decode(pkv, q, kp, vp, np.zeros((1, 1), np.int32), np.array([n], np.int32), n_head_kv=nkv, tk=tk, tv=1)[0]
+        _, lg = O.flash_attn_ext(q[0][:, None, :], kr.transpose(1, 0, 2), vr.transpose(1, 0, 2), None, type_k=tk, type_v=1,
+                                 scale=D ** -0.5, want_logits=True)
+        lg = lg[:, 0, :]                                           # [n_head][n_kv]
+        mine = np.log(np.maximum(got, 1e-30))                      # logits up to the per-head softmax constant
+        mine += (lg - mine).mean(axis=1, keepdims=True)
+        assert np.abs(mine - lg).max() <= 1e-3, tk
+
+
+def test_decode_irregular_sequence_mask(pkv, O):
+    """cells with holes / shifted positions (after seq_rm + seq_add): visibility = pos >= 0 && pos <= q_pos"""
+    rng = np.random.default_rng(4)
+    D, nh, nkv = 128, 8, 2
+    n = 300
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=[n], D=D, n_head=nh, n_head_kv=nkv, type_k=1, type_v=1)
+    pos = np.arange(n, dtype=np.int32)
+    pos[40:90] = -1                       # removed range
+    pos[90:] -= 50                        # slid down
+    pos[200] = 10_000                     # a future token (must be invisible)
+    slot_pos = np.full((1, bt.shape[1] * 128), -1, np.int32)
+    slot_pos[0, :n] = pos
+    q = rng.uniform(-1, 1, (1, nh, D)).astype(np.float32)
+    got = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=nkv, tk=1, tv=1, slot_pos=slot_pos, q_pos=np.array([249], np.int32))
+    kc = O.pool_gather(kp, 1, 0, bt[0], n, D=D, block_size=128)
+    vc = O.pool_gather(vp, 1, 1, bt[0], n, D=D, block_size=128)
+    mask = np.where((pos >= 0) & (pos <= 249), 0.0, -np.inf).astype(np.float16)[None]
+    ref = O.flash_attn_ext(q[0][:, None, :], kc, vc, mask, type_k=1, type_v=1, scale=D ** -0.5)
+    assert np.abs(got[0] - ref[0]).max() <= 1e-3
+
+
+def test_decode_full_size_properties(pkv, O):
+    """BASELINE config 2 shapes (Llama-3-8B, ctx 4096, 32 blocks): properties that need no CPU run of the full size:
+    (a) block-table permutation invariance, (b) linearity in V, (c) a constant-V cache returns that constant,
+    (d) agreement with the oracle on a few sampled heads."""
+    rng = np.random.default_rng(12)
+    D, nh, nkv, n = 128, 32, 8, 4096
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=[n], D=D, n_head=nh, n_head_kv=nkv, type_k=1, type_v=1, spare_blocks=5)
+    q = rng.uniform(-1, 1, (1, nh, D)).astype(np.float32)
+    base = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=nkv, tk=1, tv=1)
+    # (a) move every block somewhere else in the pool
+    perm = rng.permutation(kp.shape[0]).astype(np.int32)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    moved = run_decode(pkv, q, kp[perm], vp[perm], inv[bt], sl, n_head_kv=nkv, tk=1, tv=1)
+    assert np.array_equal(base, moved)                            # same arithmetic, bit for bit
+    # (b) linearity in V: out(2V) == 2 out(V) exactly (power-of-two scaling is exact in f16/f32)
+    vp2 = (vp.view(np.float16) * np.float16(2)).view(np.uint8)
+    dbl = run_decode(pkv, q, kp, vp2, bt, sl, n_head_kv=nkv, tk=1, tv=1)
+    assert np.array_equal(dbl, 2 * base)
+    # (c) constant V
+    vc = np.full(vp.shape, 0, np.uint8).view(np.float16)
+    vc[:] = np.float16(0.375)
+    cst = run_decode(pkv, q, kp, vc.view(np.uint8), bt, sl, n_head_kv=nkv, tk=1, tv=1)
+    assert np.abs(cst - 0.375).max() < 1e-6
+    # (d) oracle on the full length (a few seconds of CPU)
+    ref = O.attn_paged(q[:, :, None, :], kp, vp, bt, sl, n_q=1, type_k=1, type_v=1, block_size=128, scale=D ** -0.5,
+                       n_threads=8)[:, 0]
+    assert np.abs(base - ref).max() <= 1e-3 and nmse(base, ref) <= 5e-4
+
+
+def test_decode_rejects_bad_arguments(pkv, O):
+    rng = np.random.default_rng(1)
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=[100], D=128, n_head=4, n_head_kv=4, type_k=1, type_v=1)
+    q = dev(rng.uniform(-1, 1, (1, 4, 128)).astype(np.float32))
+    with pytest.raises(pkv.PkvError) as e:   # workspace too small
+        pkv.attn_decode(q, dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=4, type_k=1, type_v=1, block_size=128, scale=1.0,
+                        max_seq_len=100, workspace=torch.empty(16, dtype=torch.uint8, device="cuda"))
+    assert e.value.status == pkv.ERR_INVALID
+    with pytest.raises(pkv.PkvError):        # max_seq_len beyond the table
+        pkv.attn_decode(q, dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=4, type_k=1, type_v=1, block_size=128, scale=1.0,
+                        max_seq_len=1000)
+    with pytest.raises(pkv.PkvError):        # n_head not a multiple of n_head_kv
+        pkv.attn_decode(q, dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=3, type_k=1, type_v=1, block_size=128, scale=1.0,
+                        max_seq_len=100)

@@ -1,0 +1,47 @@
+"""Pins the CPU restatement against the reference itself, compiled in place (oracle/_ref).  Skipped where the
+compiled reference is not present (it is built in the dev container and travels prebuilt to the GPU box)."""
+import numpy as np
+import pytest
+
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("tk,tv", [(O.F16, O.F16), (O.Q8_0, O.Q8_0), (O.Q4_0, O.Q4_0), (O.Q8_0, O.F16), (O.F16, O.Q4_0)])
+@pytest.mark.parametrize("D,nh,nkv,n_kv,n_q", [(128, 8, 2, 512, 1), (128, 4, 4, 257, 7), (64, 8, 1, 300, 2)])
+def test_flash_attn_bit_exact(tk, tv, D, nh, nkv, n_kv, n_q):
+    rng = np.random.default_rng(n_kv * 31 + tk * 7 + tv)
+    q = rng.uniform(-1, 1, (nh, n_q, D)).astype(np.float32)
+    k = O.from_float(tk, rng.uniform(-1, 1, (nkv, n_kv, D)).astype(np.float32))
+    v = O.from_float(tv, rng.uniform(-1, 1, (nkv, n_kv, D)).astype(np.float32))
+    mask = np.zeros((n_q, n_kv), np.float16)
+    for j in range(n_q):
+        mask[j, n_kv - n_q + j + 1:] = -np.inf
+    mask[:, rng.integers(0, n_kv // 2, 5)] = -np.inf   # holes, as after seq_rm
+    for cap in (0.0, 8.0):
+        a = O.flash_attn_ext(q, k, v, mask, type_k=tk, type_v=tv, scale=D ** -0.5, softcap=cap, n_threads=3)
+        b = O.ref_flash_attn_ext(q, k, v, mask, type_k=tk, type_v=tv, scale=D ** -0.5, softcap=cap, n_threads=2)
+        assert np.array_equal(a, b)
+
+
+def test_codecs_bit_exact():
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((257, 128)) * rng.choice([1e-3, 1.0, 50.0], (257, 1))).astype(np.float32)
+    x[::17] = np.round(x[::17] * 4) / 4
+    for t in (O.F16, O.Q8_0, O.Q4_0):
+        assert np.array_equal(O.from_float(t, x), O.ref_cpy(t, x, n_threads=2))
+        b = O.from_float(t, x)
+        assert np.array_equal(O.to_float(t, b, 128), O.ref_to_float(t, b, 128))
+    assert np.array_equal(O.from_float(O.Q8_0, x, "ref"), O.ref_from_float_ref(O.Q8_0, x))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(freq_base=10000.0, mode=2), dict(freq_scale=0.5, ext_factor=1.0, attn_factor=0.9,
+                                                                            n_ctx_orig=2048, freq_base=10000.0)])
+def test_rope_bit_exact(kw):
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (9, 8, 128)).astype(np.float32)
+    pos = np.array([0, 1, 2, 63, 64, 1000, 4095, 8191, 32767], np.int32)
+    ff = rng.uniform(1, 4, 64).astype(np.float32)
+    for f in (None, ff):
+        assert np.array_equal(O.rope(x, pos, f, n_dims=128, **kw), O.ref_rope(x, pos, f, n_dims=128, **kw))
