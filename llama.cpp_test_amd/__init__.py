@@ -135,8 +135,10 @@ def rope_params(*, n_dims: int, mode: int = 0, n_ctx_orig: int = 8192, freq_base
                 freq_scale: float = 1.0, ext_factor: float = 0.0, attn_factor: float = 1.0, beta_fast: float = 32.0,
                 beta_slow: float = 1.0, freq_factors=None) -> RopeParams:
     """Defaults are Llama-3 (rope.freq_base 5e5, NORM pairs; /root/reference/src/llama-model.cpp:11798)."""
-    return RopeParams(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow,
-                      _ptr(freq_factors))
+    rp = RopeParams(n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow,
+                    _ptr(freq_factors))
+    rp._keepalive = freq_factors   # the struct only carries the device address
+    return rp
 
 
 # ---- ops (device tensors in, device tensors out) -----------------------------------------------------------------

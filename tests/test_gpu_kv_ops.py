@@ -32,9 +32,13 @@ def test_rope_golden(pkv, golden):
         ref = g[f"{name}__out"]
         assert np.abs(out.cpu().numpy() - ref).max() <= 2e-6, name
         assert nmse(out.cpu().numpy(), ref) <= 1e-7, name
-        # in place + inverse gives the input back
+        # in place + inverse gives the input back (times mscale^2 when YaRN / attn_factor scale the rotation)
         pkv.rope_f32(out, dev(g[f"{name}__pos"]), rp, inverse=True, out=out)
-        assert np.abs(out.cpu().numpy() - g[f"{name}__x"]).max() <= 1e-5, name
+        m = kw["attn_factor"] * (1.0 + 0.1 * np.log(1.0 / kw["freq_scale"]) if kw["ext_factor"] != 0 else 1.0)
+        back = out.cpu().numpy()
+        nd = kw["n_dims"]
+        assert np.abs(back[..., :nd] - g[f"{name}__x"][..., :nd] * m * m).max() <= 2e-5, name
+        assert np.array_equal(back[..., nd:], g[f"{name}__x"][..., nd:]), name
 
 
 @pytest.mark.parametrize("tk", TYPES)
