@@ -19,16 +19,16 @@
  *   block_size (128) consecutive logical tokens of ONE kv head, so the per-head tile the decode kernel
  *   streams is contiguous (the reference's per-head view is 256 B every 2048 B,
  *   /ref/src/llama-graph.cpp:1414-1419):
- *     f16  : half  e[block_size][D]                                  (32 KiB at 128x128)
- *     q8_0 : quants then half scales, 17 KiB -- block_q8_0 (/ref/ggml/src/ggml-common.h:203-208: 34 B,
- *            2-B aligned) split so that every 16-B lane load is aligned:
- *              K pool: int8 qs[tok][D],             half d[tok][D/32]
- *              V pool: int8 qs[tok/2][D/8][2][8],   half d[tok/2][D/32][2]   (token pairs interleaved per
- *                      8-d group: one 16-B load = 8 d of 2 tokens, so PV keeps 8 accumulators per lane)
- *     q4_0 : quants then half scales, 9 KiB (/ref/ggml/src/ggml-common.h:161-166):
- *              K pool: uint8 qs[tok][D/2] (per 32-block byte j = elem j | elem j+16 << 4, as block_q4_0),
- *                      half d[tok][D/32]
- *              V pool: uint8 qs[tok/4][D/8][4][4] (byte m = d 2m | d 2m+1 << 4), half d[tok/4][D/32][4]
+ *     K pools (a lane of the decode kernel reads 16 contiguous bytes of ONE token row):
+ *       f16  : half  e[tok][D]                                                              (32 KiB at 128x128)
+ *       q8_0 : int8  qs[tok][D], then half d[tok][D/32]                                     (17 KiB) -- block_q8_0
+ *              (/ref/ggml/src/ggml-common.h:203-208: 34 B, 2-B aligned) split so every 16-B load is aligned
+ *       q4_0 : uint8 qs[tok][D/2] (per 32-block byte j = elem j | elem j+16 << 4, as block_q4_0,
+ *              /ref/ggml/src/ggml-common.h:161-166), then half d[tok][D/32]                 ( 9 KiB)
+ *     V pools (token-interleaved so that P.V needs 4 accumulators per lane and, for f16, is a pure
+ *     v_dot2c_f32_f16 stream): uint32 w[tok/TL][D], the dword of one d holds its TL consecutive tokens,
+ *       f16  : TL 2 (half2 = tokens t, t+1)        q8_0 : TL 4 (4 x int8)        q4_0 : TL 8 (8 nibbles)
+ *       quantized types append half d[tok/TL][D/32][TL]
  *   tile offset = (b * n_head_kv + h) * pkv_tile_bytes(type, block_size, D); K and V tiles of a type have
  *   the same size; functions that touch tile contents take `is_v` to select the layout.
  *   Bytes per token are identical to the reference's row sizes (2048 / 1088 / 576 B per 1024 elems).

@@ -25,8 +25,6 @@ namespace {
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 constexpr int WG_TOK = 128;  // KV tokens per workgroup (== one block at block_size 128)
-constexpr int NWAVE  = 4;
-constexpr int TPW    = WG_TOK / NWAVE;  // tokens per wave
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
@@ -173,25 +171,82 @@ __device__ __forceinline__ void k_dot(const uint4 & kv, float kscale, const QFra
     }
 }
 
-// V side: a lane owns 8 consecutive d of TL tokens per 16-byte load; 16 lanes (D=128) cover the d range.
-//   f16 : TL = 1, tile = half[tok][D]
-//   q8_0: TL = 2, tile = int8[tok/2][D/8][2][8]  then half d[tok/2][D/32][2]
-//   q4_0: TL = 4, tile = nib [tok/4][D/8][4][8]  then half d[tok/4][D/32][4]   (byte m = d 2m | d 2m+1 << 4)
+// V side ("Pool layout"): tile = [tok/TL][D] dwords, every dword holds the TL tokens of one d
+//   f16 : TL 2 (half2 = tokens t, t+1)   q8_0 : TL 4 (4 int8)   q4_0 : TL 8 (8 nibbles), then half d[tok/TL][D/32][TL].
+// A lane owns 4 consecutive d (16 bytes) of TL tokens; D/4 lanes cover the head, so PV keeps only 4 accumulators per
+// query head and the f16 case is a pure v_dot2c_f32_f16 stream (P packed as half2 per token pair).
 template <int T> struct VTr;
-template <> struct VTr<PKV_TYPE_F16>  { static constexpr int TL = 1; };
-template <> struct VTr<PKV_TYPE_Q8_0> { static constexpr int TL = 2; };
-template <> struct VTr<PKV_TYPE_Q4_0> { static constexpr int TL = 4; };
+template <> struct VTr<PKV_TYPE_F16>  { static constexpr int TL = 2; };
+template <> struct VTr<PKV_TYPE_Q8_0> { static constexpr int TL = 4; };
+template <> struct VTr<PKV_TYPE_Q4_0> { static constexpr int TL = 8; };
 
-template <int KT, int VT, int D, int G>
-__global__ void __launch_bounds__(256) attn_decode_kernel(const DecodeArgs a) {
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+// One step of the logit reduce-scatter over the K lanes of a row: lanes whose DIST bit is clear keep the lower half
+// of the value list, the others the upper half, and each adds what its partner (DPP pattern CTRL) holds for it.
+template <int NV, int DIST, int CTRL>
+__device__ __forceinline__ void rs_step(float * x, int lane) {
+    if constexpr (NV >= 2) {
+        const bool hi = lane & DIST;
+#pragma unroll
+        for (int j = 0; j < NV / 2; ++j) {
+            const float keep = hi ? x[j + NV / 2] : x[j];
+            const float send = hi ? x[j] : x[j + NV / 2];
+            x[j] = keep + dpp_mov<CTRL>(send);
+        }
+    } else {
+        x[0] += dpp_mov<CTRL>(x[0]);
+    }
+}
+// NV partial sums per lane, LPR lanes per row -> NVF = max(1, NV/LPR) finished sums per lane;
+// finished x[j] is original index  j + NVF * (c >> (log2 LPR - NS)),  NS = min(log2 LPR, log2 NV), c = lane % LPR
+template <int NV, int LPR>
+__device__ __forceinline__ void reduce_scatter(float * x, int lane) {
+    constexpr int n1 = NV, n2 = LPR >= 16 ? imax(1, n1 / 2) : n1, n3 = LPR >= 8 ? imax(1, n2 / 2) : n2,
+                  n4 = LPR >= 4 ? imax(1, n3 / 2) : n3;
+    if constexpr (LPR >= 16) rs_step<n1, 8, 0x140>(x, lane);  // row_mirror
+    if constexpr (LPR >= 8)  rs_step<n2, 4, 0x141>(x, lane);  // row_half_mirror
+    if constexpr (LPR >= 4)  rs_step<n3, 2, 0x4E>(x, lane);   // quad_perm [2,3,0,1]
+    if constexpr (LPR >= 2)  rs_step<n4, 1, 0xB1>(x, lane);   // quad_perm [1,0,3,2]
+}
+
+// all-reduce over the lanes that hold the same query head: lane bits [log2(64/TPW), 6)
+template <int TPW_, bool IS_MAX>
+__device__ __forceinline__ float head_reduce(float x) {
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+    if constexpr (TPW_ >= 64) x = op(x, dpp_mov<0xB1>(x));
+    if constexpr (TPW_ >= 32) x = op(x, dpp_mov<0x4E>(x));
+    x = op(x, dpp_mov<0x124>(x));  // row_ror:4
+    x = op(x, dpp_mov<0x128>(x));  // row_ror:8   -> lanes i, i+4, i+8, i+12 of the row
+    x = op(x, __shfl_xor(x, 16));
+    x = op(x, __shfl_xor(x, 32));
+    return x;
+}
+
+template <int KT, int VT, int D>
+struct Geo {
     using KT_ = KTr<KT, D>;
-    constexpr int K_LPR = KT_::LPR, K_RPL = 64 / K_LPR, K_NL = TPW / K_RPL;
-    constexpr int V_LPR = D / 8, V_TL = VTr<VT>::TL, V_RPL = (64 / V_LPR) * V_TL, V_NL = TPW / V_RPL;
-    static_assert(K_NL >= 1 && V_NL >= 1, "tile too small for this type / head size");
+    static constexpr int K_LPR = KT_::LPR, K_RPL = 64 / K_LPR;
+    static constexpr int V_LPR = D / 4, V_TL = VTr<VT>::TL, V_RPL = (64 / V_LPR) * V_TL;
+    static constexpr int TPW = imax(16, imax(K_RPL, V_RPL));   // tokens per wave
+    static constexpr int NW  = WG_TOK / TPW;                   // waves per workgroup
+    static constexpr int K_NL = TPW / K_RPL, V_NL = TPW / V_RPL;
+};
 
-    __shared__ float sS[WG_TOK][G];        // logits, then probabilities
-    __shared__ float sRed[2][NWAVE][G];    // per-wave max / sum
-    __shared__ float sO[NWAVE][G][D];      // per-wave partial outputs
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS>
+__global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(const DecodeArgs a) {
+    using GE = Geo<KT, VT, D>;
+    using KT_ = KTr<KT, D>;
+    constexpr int K_LPR = GE::K_LPR, K_RPL = GE::K_RPL, K_NL = GE::K_NL;
+    constexpr int V_LPR = GE::V_LPR, V_TL = GE::V_TL, V_RPL = GE::V_RPL, V_NL = GE::V_NL;
+    constexpr int TPW = GE::TPW, NW = GE::NW, NT = 64 * NW;
+    constexpr int NV = K_NL * G, NS = ilog2(K_LPR) < ilog2(NV) ? ilog2(K_LPR) : ilog2(NV), NVF = NV >> NS;
+    constexpr bool P16 = VT == PKV_TYPE_F16;                   // P travels as half2 token pairs for the dot2 PV
+
+    __shared__ __attribute__((aligned(16))) float sP[NW][TPW * G / (P16 ? 2 : 1)];  // per-wave probabilities
+    __shared__ __attribute__((aligned(16))) float sO[NW][G][D];                     // per-wave partial outputs
+    __shared__ float sML[NW][G][2];                                                 // per-wave (max, sum)
 
     const int split = blockIdx.x, hk = blockIdx.y, s = blockIdx.z;
     const int seq_len = a.seq_lens[s];
@@ -201,208 +256,228 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const DecodeArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lb = base / a.block_size, boff = base % a.block_size;
     const int phys = a.block_table[(size_t) s * a.max_blocks + lb];
-    const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
-    const char * ktile = a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k;
-    const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v;
-    const int n_valid = min(WG_TOK, seq_len - base);
+    const char * ktile = a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(KT, a.block_size, D);
+    const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(VT, a.block_size, D);
+    const int n_valid = min(WG_TOK, seq_len - base);  // >= 1
 
-    // ---- issue every K and V load of this lane before anything else ----------------------------------
+    // ---- every K and V load of the lane is issued up front, unconditionally: rows past the end of the sequence are
+    //      clamped to the last valid row (in bounds, finite) and removed later by the mask / p = 0 ------------------
     const int kr = lane / K_LPR, kc = lane % K_LPR;
     uint4 kreg[K_NL];
     float ksc[K_NL];
 #pragma unroll
     for (int i = 0; i < K_NL; ++i) {
-        const int tw = wave * TPW + i * K_RPL + kr;
-        kreg[i] = make_uint4(0, 0, 0, 0);
+        const int row = boff + min(wave * TPW + i * K_RPL + kr, n_valid - 1);
+        kreg[i] = *reinterpret_cast<const uint4 *>(ktile + ((size_t) row * K_LPR + kc) * 16);
         ksc[i]  = 0.0f;
-        if (tw < n_valid) {
-            const int row = boff + tw;
-            kreg[i] = *reinterpret_cast<const uint4 *>(ktile + ((size_t) row * K_LPR + kc) * 16);
-            if constexpr (KT != PKV_TYPE_F16) {
-                const int blk = kc * KT_::E / PKV_QK;
-                ksc[i] = (float) *reinterpret_cast<const _Float16 *>(
-                    ktile + tile_quant_bytes(KT, a.block_size, D) + ((size_t) row * (D / PKV_QK) + blk) * 2);
-            }
-        }
+        if constexpr (KT != PKV_TYPE_F16)
+            ksc[i] = (float) *reinterpret_cast<const _Float16 *>(
+                ktile + tile_quant_bytes(KT, a.block_size, D) + ((size_t) row * (D / PKV_QK) + kc * KT_::E / PKV_QK) * 2);
     }
-    const int vr = lane / V_LPR, vc = lane % V_LPR;
+    const int vl = lane / V_LPR, vc = lane % V_LPR;
     uint4 vreg[V_NL];
     float vsc[V_NL][V_TL];
 #pragma unroll
     for (int i = 0; i < V_NL; ++i) {
-        const int tw = wave * TPW + i * V_RPL + vr * V_TL;  // first of the TL tokens of this lane-load
-        vreg[i] = make_uint4(0, 0, 0, 0);
+        const int tw  = wave * TPW + i * V_RPL + vl * V_TL;  // first token of this lane-load
+        const int grp = (boff + min(tw, n_valid - 1)) / V_TL;
+        vreg[i] = *reinterpret_cast<const uint4 *>(vtile + ((size_t) grp * D + vc * 4) * 4);
+        if constexpr (VT != PKV_TYPE_F16) {
+            const _Float16 * sp = reinterpret_cast<const _Float16 *>(
+                vtile + tile_quant_bytes(VT, a.block_size, D) + ((size_t) grp * (D / PKV_QK) + vc / 8) * V_TL * 2);
 #pragma unroll
-        for (int t = 0; t < V_TL; ++t) vsc[i][t] = 0.0f;
-        if (tw < n_valid) {
-            const int grp = (boff + tw) / V_TL;  // token group index inside the tile
-            vreg[i] = *reinterpret_cast<const uint4 *>(vtile + ((size_t) grp * V_LPR + vc) * 16);
-            if constexpr (VT != PKV_TYPE_F16) {
-                const _Float16 * sp = reinterpret_cast<const _Float16 *>(
-                    vtile + tile_quant_bytes(VT, a.block_size, D) + ((size_t) grp * (D / PKV_QK) + vc / 4) * V_TL * 2);
-#pragma unroll
-                for (int t = 0; t < V_TL; ++t) vsc[i][t] = tw + t < n_valid ? (float) sp[t] : 0.0f;
-            }
+            for (int t = 0; t < V_TL; ++t) vsc[i][t] = (float) sp[t];
         }
     }
 
-    // ---- Q fragment (L2-resident, 16 KiB for the whole launch) ----------------------------------------
+    // ---- Q fragment (L2-resident, 16 KiB for the whole launch) ----------------------------------------------------
     QFrag<KT, D, G> qf;
     qf.load(a.q + (size_t) s * a.q_stride_tok + (size_t) hk * G * a.q_stride_head, a.q_stride_head, kc);
 
-    // ---- QK^T: lane partials -> DPP all-reduce over the K_LPR lanes of a row -> logits in LDS -----------
-    const int32_t * spos = a.slot_pos ? a.slot_pos + (size_t) s * a.max_blocks * a.block_size + base : nullptr;
-    const int qpos = a.slot_pos ? a.q_pos[s] : 0;
+    // ---- QK^T: per-lane partial dots, then a DPP reduce-scatter: every lane ends with NVF finished logits ---------
+    float x[NV];
 #pragma unroll
     for (int i = 0; i < K_NL; ++i) {
         float sv[G];
         k_dot<KT, D, G>(kreg[i], ksc[i], qf, sv);
 #pragma unroll
-        for (int g = 0; g < G; ++g) sv[g] = group_sum<K_LPR>(sv[g]);
-        if (kc == 0) {
-            const int tw = wave * TPW + i * K_RPL + kr;
-            bool ok = tw < n_valid;
-            if (spos && ok) { const int p = spos[tw]; ok = p >= 0 && p <= qpos; }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float v = sv[g] * a.scale;                                  // :12359
-                if (a.softcap != 0.0f) v = a.softcap * tanhf(v);            // :12361-12363 (scale pre-divided on host)
-                sS[tw][g] = ok ? v : -INFINITY;                             // mask == -inf -> skipped cell (:12349)
-            }
-        }
+        for (int g = 0; g < G; ++g) x[i * G + g] = sv[g];
     }
-    __syncthreads();
+    reduce_scatter<NV, K_LPR>(x, lane);
 
-    // ---- softmax over the workgroup's 128 tokens: thread (tok, head pair) ---------------------------------
-    {
-        constexpr int GP = (G + 1) / 2;         // heads per thread
-        const int tok = tid & (WG_TOK - 1), gh = tid >> 7;
-        float sv[GP], m[GP];
+    const int32_t * spos = SLOTPOS ? a.slot_pos + (size_t) s * a.max_blocks * a.block_size + base : nullptr;
+    const int qpos = SLOTPOS ? a.q_pos[s] : 0;
+    const int cidx = NVF * (kc >> (ilog2(K_LPR) - NS));       // original index of x[0]
+    float mg[NVF], pj[NVF];
+    int   tok[NVF];
 #pragma unroll
-        for (int j = 0; j < GP; ++j) {
-            const int g = gh * GP + j;
-            sv[j] = g < G ? sS[tok][g] : -INFINITY;
-            m[j]  = wave_max(sv[j]);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < GP; ++j) if (gh * GP + j < G) sRed[0][wave][gh * GP + j] = m[j];
-        }
-        __syncthreads();
-        // waves 0,1 hold head group 0, waves 2,3 head group 1 (tok spans two waves)
-#pragma unroll
-        for (int j = 0; j < GP; ++j) {
-            const int g = gh * GP + j;
-            if (g < G) {
-                const float mm = fmaxf(sRed[0][gh * 2][g], sRed[0][gh * 2 + 1][g]);
-                const float p  = mm == -INFINITY ? 0.0f : __expf(sv[j] - mm);
-                sS[tok][g]     = p;
-                const float l  = wave_sum(p);
-                if (lane == 0) { sRed[1][wave][g] = l; }
-                m[j] = mm;
-            }
-        }
-        __syncthreads();
-        if (tid < G) {  // publish (m, l) of this split
-            const int g = tid, ghh = g / GP;
-            const float mm = fmaxf(sRed[0][ghh * 2][g], sRed[0][ghh * 2 + 1][g]);
-            const float l  = sRed[1][ghh * 2][g] + sRed[1][ghh * 2 + 1][g];
-            float * ml = a.part_ml + (((size_t) s * a.n_head + hk * G + g) * a.n_splits + split) * 2;
-            ml[0] = mm;
-            ml[1] = l;
-        }
+    for (int j = 0; j < NVF; ++j) {
+        const int idx = cidx + j;
+        tok[j] = wave * TPW + (idx / G) * K_RPL + kr;         // token inside the workgroup's 128
+        bool ok = tok[j] < n_valid;
+        if constexpr (SLOTPOS) { const int p = spos[min(tok[j], n_valid - 1)]; ok = ok && p >= 0 && p <= qpos; }
+        float v = x[j] * a.scale;                             // :12359
+        if constexpr (SOFTCAP) v = a.softcap * tanhf(v);      // :12361-12363 (scale pre-divided on the host)
+        x[j]  = ok ? v : -INFINITY;                           // mask == -inf -> skipped cell (:12349)
+        mg[j] = head_reduce<TPW, true>(x[j]);                 // wave-local max of this head
+        pj[j] = mg[j] == -INFINITY ? 0.0f : __expf(x[j] - mg[j]);
     }
+    // probabilities -> this wave's LDS strip, in the layout the PV loop reads (when there are fewer logits than K
+    // lanes the low lane bits hold duplicates: they write the same value to the same place)
+#pragma unroll
+    for (int j = 0; j < NVF; ++j) {
+        const int g = (cidx + j) % G, t = tok[j] - wave * TPW;
+        if constexpr (P16) reinterpret_cast<_Float16 *>(sP[wave])[((t >> 1) * G + g) * 2 + (t & 1)] = (_Float16) pj[j];
+        else               sP[wave][t * G + g] = pj[j];
+        const float l = head_reduce<TPW, false>(pj[j]);       // sums over the token bits of the lane id only
+        if ((lane >> ilog2(64 / TPW)) == 0) { sML[wave][g][0] = mg[j]; sML[wave][g][1] = l; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // LDS strip is read back by other lanes of this wave only
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- PV: f32 accumulators, lane owns 8 d of its tokens -------------------------------------------------
-    float acc[G][8];
+    // ---- PV: 4 f32 accumulators per query head, lane owns 4 d of TL tokens per load ---------------------------------
+    float acc[G][4];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[g][j] = 0.0f;
-
+        for (int j = 0; j < 4; ++j) acc[g][j] = 0.0f;
 #pragma unroll
     for (int i = 0; i < V_NL; ++i) {
-        const int tw = wave * TPW + i * V_RPL + vr * V_TL;
+        const int t0 = i * V_RPL + vl * V_TL;                 // first token (inside the wave) of this lane-load
+        const uint32_t * vw = reinterpret_cast<const uint32_t *>(&vreg[i]);
+        if constexpr (P16) {
+            half2_t pp[G];
 #pragma unroll
-        for (int t = 0; t < V_TL; ++t) {
-            float p[G];
+            for (int g = 0; g < G; ++g) pp[g] = reinterpret_cast<const half2_t *>(sP[wave])[(t0 >> 1) * G + g];
+            uint32_t w[4] = {vw[0], vw[1], vw[2], vw[3]};
+            if (wave * TPW + t0 + 1 >= n_valid) {             // odd tail: the pair's second token is not part of the sequence
 #pragma unroll
-            for (int g = 0; g < G; ++g) p[g] = sS[tw + t][g];
-            float vf[8];
-            if constexpr (VT == PKV_TYPE_F16) {
-                const _Float16 * vh = reinterpret_cast<const _Float16 *>(&vreg[i]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vf[j] = (float) vh[j];
-            } else if constexpr (VT == PKV_TYPE_Q8_0) {
-                const int * vw = reinterpret_cast<const int *>(&vreg[i]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vf[j] = (float) (int) (signed char) (vw[t * 2 + j / 4] >> (8 * (j & 3)));
-#pragma unroll
-                for (int g = 0; g < G; ++g) p[g] *= vsc[i][t];
-            } else {
-                const uint32_t vw = reinterpret_cast<const uint32_t *>(&vreg[i])[t];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vf[j] = (float) ((int) ((vw >> (4 * j)) & 0xF) - 8);
-#pragma unroll
-                for (int g = 0; g < G; ++g) p[g] *= vsc[i][t];
+                for (int j = 0; j < 4; ++j) w[j] &= 0x0000FFFFu;
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[g][j] = fmaf(p[g], vf[j], acc[g][j]);
+                for (int j = 0; j < 4; ++j)
+                    acc[g][j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const half2_t *>(&w[j]), pp[g], acc[g][j], false);
+        } else {
+#pragma unroll
+            for (int t = 0; t < V_TL; ++t) {
+                float p[G];
+                const bool live = wave * TPW + t0 + t < n_valid;
+#pragma unroll
+                for (int g = 0; g < G; ++g) p[g] = live ? sP[wave][(t0 + t) * G + g] * vsc[i][t] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float vf;
+                    if constexpr (VT == PKV_TYPE_Q8_0) vf = (float) (int) (signed char) (vw[j] >> (8 * t));
+                    else                               vf = (float) ((int) ((vw[j] >> (4 * t)) & 0xF) - 8);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g][j] = fmaf(p[g], vf, acc[g][j]);
+                }
+            }
         }
     }
-    // sum the lane-rows of the wave (lanes with equal vc), then the waves through LDS
+    // sum the lane-rows of the wave (lanes with equal vc), then hand the wave's partial to the workgroup
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             float v = acc[g][j];
-            if (V_LPR <= 8)  v += __shfl_xor(v, 8);
-            if (V_LPR <= 16) v += __shfl_xor(v, 16);
+            if constexpr (V_LPR <= 16) v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             acc[g][j] = v;
         }
-    if (vr == 0) {
+    if (vl == 0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            *reinterpret_cast<float4 *>(&sO[wave][g][vc * 8])     = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-            *reinterpret_cast<float4 *>(&sO[wave][g][vc * 8 + 4]) = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
-        }
+        for (int g = 0; g < G; ++g)
+            *reinterpret_cast<float4 *>(&sO[wave][g][vc * 4]) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
     }
     __syncthreads();
-    for (int e = tid; e < G * D; e += 256) {
+
+    // ---- merge the waves (each has its own max) and publish one (m, l, O) partial per workgroup -------------------
+    for (int e = tid; e < G * D; e += NT) {
         const int g = e / D, d = e % D;
-        const float v = sO[0][g][d] + sO[1][g][d] + sO[2][g][d] + sO[3][g][d];
-        a.part_o[(((size_t) s * a.n_head + hk * G + g) * a.n_splits + split) * D + d] = v;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, sML[w][g][0]);
+        float o = 0.0f, l = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float f = sML[w][g][0] == -INFINITY ? 0.0f : __expf(sML[w][g][0] - M);
+            o = fmaf(sO[w][g][d], f, o);
+            l = fmaf(sML[w][g][1], f, l);
+        }
+        const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
+        a.part_o[pi * D + d] = o;
+        if (d == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = l; }
     }
 }
 
-// merge the per-block partials: out = sum_j O_j e^{m_j - M} / sum_j l_j e^{m_j - M}
+// merge the per-block partials: out = sum_j O_j e^{m_j - M} / sum_j l_j e^{m_j - M}.
+// One workgroup per (sequence, query head); the split weights are computed once (thread j <-> split j) and shared
+// through LDS so that the D threads then stream their column with independent loads.
 template <int D>
 __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
-    const int h = blockIdx.x, s = blockIdx.y, d = threadIdx.x;
+    constexpr int CH = D;  // splits handled per pass (ctx 16384 -> 128 splits = one pass at D = 128)
+    __shared__ float sW[CH];
+    __shared__ float sRed[2][D / 64];
+    const int h = blockIdx.x, s = blockIdx.y, d = threadIdx.x, wave = d >> 6, lane = d & 63;
     const int seq_len = a.seq_lens[s];
     const int ns = (seq_len + WG_TOK - 1) / WG_TOK;
     float * o = a.out + ((size_t) s * a.n_head + h) * D;
     if (ns <= 0) { o[d] = 0.0f; return; }
     const float * ml = a.part_ml + ((size_t) s * a.n_head + h) * a.n_splits * 2;
     const float * po = a.part_o + ((size_t) s * a.n_head + h) * a.n_splits * D;
-    float M = -INFINITY;
-    for (int j = 0; j < ns; ++j) M = fmaxf(M, ml[j * 2]);
+    // global max over all splits
+    float m = -INFINITY;
+    for (int j = d; j < ns; j += D) m = fmaxf(m, ml[j * 2]);
+    m = wave_max(m);
+    if (lane == 0) sRed[0][wave] = m;
+    __syncthreads();
+    float M = sRed[0][0];
+#pragma unroll
+    for (int w = 1; w < D / 64; ++w) M = fmaxf(M, sRed[0][w]);
     float L = 0.0f, acc = 0.0f;
-    for (int j = 0; j < ns; ++j) {
-        const float w = M == -INFINITY ? 0.0f : __expf(ml[j * 2] - M);
-        L += ml[j * 2 + 1] * w;
-        acc = fmaf(po[(size_t) j * D + d], w, acc);
+    for (int j0 = 0; j0 < ns; j0 += CH) {
+        const int j = j0 + d;
+        float w = 0.0f, lw = 0.0f;
+        if (j < ns) {
+            const float2 v = *reinterpret_cast<const float2 *>(ml + j * 2);
+            w  = v.x == -INFINITY ? 0.0f : __expf(v.x - M);
+            lw = v.y * w;
+        }
+        __syncthreads();  // previous pass finished reading sW
+        sW[d] = w;
+        L += lw;
+        __syncthreads();
+        const int n = min(CH, ns - j0);
+        int jj = 0;
+        for (; jj + 4 <= n; jj += 4) {  // 4 independent loads in flight per thread
+            const float p0 = po[(size_t) (j0 + jj) * D + d], p1 = po[(size_t) (j0 + jj + 1) * D + d];
+            const float p2 = po[(size_t) (j0 + jj + 2) * D + d], p3 = po[(size_t) (j0 + jj + 3) * D + d];
+            acc = fmaf(p0, sW[jj], acc); acc = fmaf(p1, sW[jj + 1], acc);
+            acc = fmaf(p2, sW[jj + 2], acc); acc = fmaf(p3, sW[jj + 3], acc);
+        }
+        for (; jj < n; ++jj) acc = fmaf(po[(size_t) (j0 + jj) * D + d], sW[jj], acc);
     }
-    o[d] = acc / L;  // all cells masked -> 0/0 = NaN, like the reference's 1/S with S == 0
+    L = wave_sum(L);
+    if (lane == 0) sRed[1][wave] = L;
+    __syncthreads();
+    float Ls = sRed[1][0];
+#pragma unroll
+    for (int w = 1; w < D / 64; ++w) Ls += sRed[1][w];
+    o[d] = acc / Ls;  // all cells masked -> 0/0 = NaN, like the reference's 1/S with S == 0
 }
 
 template <int KT, int VT, int D, int G>
 int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     dim3 grid(da.n_splits, da.n_head_kv, n_seq);
-    hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G>), grid, dim3(256), 0, st, da);
+    const dim3 block(64 * Geo<KT, VT, D>::NW);
+    const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr;
+    if (!cap && !sp)      hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, false>), grid, block, 0, st, da);
+    else if (!cap && sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, true>), grid, block, 0, st, da);
+    else if (cap && !sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, false>), grid, block, 0, st, da);
+    else                  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, true>), grid, block, 0, st, da);
     if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
     PKV_HIP(hipGetLastError());
     return PKV_OK;

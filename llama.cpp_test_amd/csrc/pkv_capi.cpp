@@ -93,7 +93,7 @@ int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void *
     PKV_REQUIRE(!k_cur || k_pool, "pkv_kv_store: k_cur without k_pool");
     PKV_REQUIRE(!v_cur || v_pool, "pkv_kv_store: v_cur without v_pool");
     PKV_REQUIRE(kv_type_ok(type_k) && kv_type_ok(type_v), "pkv_kv_store: KV types must be f16/q8_0/q4_0");
-    PKV_REQUIRE(n_tok >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 4 == 0, "pkv_kv_store: bad sizes");
+    PKV_REQUIRE(n_tok >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 8 == 0, "pkv_kv_store: bad sizes");
     PKV_REQUIRE(!rope || pos, "pkv_kv_store: fused rope needs pos");
     RopeDev r;
     if (rope) { if (int rc = make_rope(rope, head_dim, &r)) return rc; }

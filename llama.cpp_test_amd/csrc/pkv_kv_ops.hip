@@ -133,38 +133,48 @@ template <int T> __device__ __forceinline__ float2 dequantize(const Q2 & v) {
 }
 
 // K-layout / V-layout tile access ("Pool layout", include/mi355_paged_kv.h; V interleave in pkv_attn_decode.hip)
+// V tiles: [tok/TL][D] dwords, each dword = the TL tokens of one d (f16 TL 2, q8_0 TL 4, q4_0 TL 8); scales
+// half d[tok/TL][D/32][TL] after the quants.
 template <int T, bool IS_V>
 __device__ __forceinline__ void tile_write(char * tile, int row, int lane, const Q2 & v, int BS, int D) {
     const int e0 = 2 * lane;
+    if constexpr (T == PKV_TYPE_Q4_0 && !IS_V) {  // byte j of the block = elem j | elem (j+16) << 4  (block_q4_0)
+        const int p0 = __shfl_xor(v.q0, 8), p1 = __shfl_xor(v.q1, 8);
+        if (e0 >= D) return;
+        const int nb = D / PKV_QK, blk = e0 / PKV_QK;
+        if ((lane & 15) < 8)
+            *reinterpret_cast<uint16_t *>(tile + (size_t) row * (D / 2) + blk * 16 + 2 * (lane & 15)) =
+                (uint16_t) ((v.q0 | (p0 << 4)) | ((v.q1 | (p1 << 4)) << 8));
+        if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(tile + tile_quant_bytes(T, BS, D) + ((size_t) row * nb + blk) * 2) = v.d;
+        return;
+    }
     if (e0 >= D) return;
+    const int nb = D / PKV_QK, blk = e0 / PKV_QK;
+    char *    sc = tile + tile_quant_bytes(T, BS, D);
     if constexpr (T == PKV_TYPE_F16) {
-        *reinterpret_cast<uint32_t *>(tile + ((size_t) row * D + e0) * 2) = (uint32_t) (v.q0 & 0xFFFF) | ((uint32_t) v.q1 << 16);
-    } else {
-        const int    nb = D / PKV_QK, blk = e0 / PKV_QK;
-        char *       sc = tile + tile_quant_bytes(T, BS, D);
-        if constexpr (T == PKV_TYPE_Q8_0) {
-            const uint16_t pk = (uint16_t) ((v.q0 & 0xFF) | ((v.q1 & 0xFF) << 8));
-            if (!IS_V) {
-                *reinterpret_cast<uint16_t *>(tile + (size_t) row * D + e0) = pk;
-                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + ((size_t) row * nb + blk) * 2) = v.d;
-            } else {  // int8[row/2][D/8][2][8]; half d[row/2][D/32][2]
-                *reinterpret_cast<uint16_t *>(tile + (((size_t) (row / 2) * (D / 8) + e0 / 8) * 2 + (row & 1)) * 8 + (e0 & 7)) = pk;
-                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + (((size_t) (row / 2) * nb + blk) * 2 + (row & 1)) * 2) = v.d;
-            }
+        if (!IS_V) {
+            *reinterpret_cast<uint32_t *>(tile + ((size_t) row * D + e0) * 2) = (uint32_t) (v.q0 & 0xFFFF) | ((uint32_t) v.q1 << 16);
         } else {
-            if (!IS_V) {  // byte j of the block = elem j | elem (j+16) << 4  (block_q4_0)
-                const int p0 = __shfl_xor(v.q0, 8), p1 = __shfl_xor(v.q1, 8);
-                if ((lane & 15) < 8) {
-                    const uint16_t pk = (uint16_t) ((v.q0 | (p0 << 4)) | ((v.q1 | (p1 << 4)) << 8));
-                    *reinterpret_cast<uint16_t *>(tile + (size_t) row * (D / 2) + blk * 16 + 2 * (lane & 15)) = pk;
-                }
-                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + ((size_t) row * nb + blk) * 2) = v.d;
-            } else {  // nib[row/4][D/8][4][4 bytes]: byte m = d 2m | d 2m+1 << 4; half d[row/4][D/32][4]
-                *reinterpret_cast<uint8_t *>(tile + (((size_t) (row / 4) * (D / 8) + e0 / 8) * 4 + (row & 3)) * 4 + (e0 & 7) / 2) =
-                    (uint8_t) (v.q0 | (v.q1 << 4));
-                if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + (((size_t) (row / 4) * nb + blk) * 4 + (row & 3)) * 2) = v.d;
-            }
+            char * p = tile + ((size_t) (row / 2) * D + e0) * 4 + (row & 1) * 2;
+            *reinterpret_cast<uint16_t *>(p)     = (uint16_t) v.q0;
+            *reinterpret_cast<uint16_t *>(p + 4) = (uint16_t) v.q1;
         }
+    } else if constexpr (T == PKV_TYPE_Q8_0) {
+        if (!IS_V) {
+            *reinterpret_cast<uint16_t *>(tile + (size_t) row * D + e0) = (uint16_t) ((v.q0 & 0xFF) | ((v.q1 & 0xFF) << 8));
+            if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + ((size_t) row * nb + blk) * 2) = v.d;
+        } else {
+            char * p = tile + ((size_t) (row / 4) * D + e0) * 4 + (row & 3);
+            p[0] = (char) v.q0;
+            p[4] = (char) v.q1;
+            if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + (((size_t) (row / 4) * nb + blk) * 4 + (row & 3)) * 2) = v.d;
+        }
+    } else {  // q4_0 V: eight tokens share a dword -> update only this token's nibble, atomically
+        uint32_t * w = reinterpret_cast<uint32_t *>(tile + ((size_t) (row / 8) * D + e0) * 4);
+        const int  sh = 4 * (row & 7);
+        atomicXor(w,     ((w[0] >> sh & 0xFu) ^ (uint32_t) v.q0) << sh);   // own nibble only changes through this lane
+        atomicXor(w + 1, ((w[1] >> sh & 0xFu) ^ (uint32_t) v.q1) << sh);
+        if ((lane & 15) == 0) *reinterpret_cast<uint16_t *>(sc + (((size_t) (row / 8) * nb + blk) * 8 + (row & 7)) * 2) = v.d;
     }
 }
 template <int T, bool IS_V>
@@ -172,34 +182,39 @@ __device__ __forceinline__ Q2 tile_read(const char * tile, int row, int lane, in
     Q2 r{0, 0, 0};
     const int e0 = 2 * lane;
     if (e0 >= D) return r;
+    const int    nb = D / PKV_QK, blk = e0 / PKV_QK;
+    const char * sc = tile + tile_quant_bytes(T, BS, D);
     if constexpr (T == PKV_TYPE_F16) {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(tile + ((size_t) row * D + e0) * 2);
-        r.q0 = w & 0xFFFF; r.q1 = w >> 16;
-    } else {
-        const int    nb = D / PKV_QK, blk = e0 / PKV_QK;
-        const char * sc = tile + tile_quant_bytes(T, BS, D);
-        if constexpr (T == PKV_TYPE_Q8_0) {
-            uint16_t pk;
-            if (!IS_V) {
-                pk  = *reinterpret_cast<const uint16_t *>(tile + (size_t) row * D + e0);
-                r.d = *reinterpret_cast<const uint16_t *>(sc + ((size_t) row * nb + blk) * 2);
-            } else {
-                pk  = *reinterpret_cast<const uint16_t *>(tile + (((size_t) (row / 2) * (D / 8) + e0 / 8) * 2 + (row & 1)) * 8 + (e0 & 7));
-                r.d = *reinterpret_cast<const uint16_t *>(sc + (((size_t) (row / 2) * nb + blk) * 2 + (row & 1)) * 2);
-            }
-            r.q0 = (int) (signed char) (pk & 0xFF); r.q1 = (int) (signed char) (pk >> 8);
+        if (!IS_V) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(tile + ((size_t) row * D + e0) * 2);
+            r.q0 = w & 0xFFFF; r.q1 = w >> 16;
         } else {
-            if (!IS_V) {
-                const int      j  = (lane & 15) & 7;  // lanes 0..7 read low nibbles, 8..15 the high nibbles of the same bytes
-                const uint16_t pk = *reinterpret_cast<const uint16_t *>(tile + (size_t) row * (D / 2) + blk * 16 + 2 * j);
-                const int      sh = (lane & 15) < 8 ? 0 : 4;
-                r.q0 = (pk >> sh) & 0xF; r.q1 = (pk >> (8 + sh)) & 0xF;
-                r.d  = *reinterpret_cast<const uint16_t *>(sc + ((size_t) row * nb + blk) * 2);
-            } else {
-                const uint8_t b = *reinterpret_cast<const uint8_t *>(tile + (((size_t) (row / 4) * (D / 8) + e0 / 8) * 4 + (row & 3)) * 4 + (e0 & 7) / 2);
-                r.q0 = b & 0xF; r.q1 = b >> 4;
-                r.d  = *reinterpret_cast<const uint16_t *>(sc + (((size_t) (row / 4) * nb + blk) * 4 + (row & 3)) * 2);
-            }
+            const char * p = tile + ((size_t) (row / 2) * D + e0) * 4 + (row & 1) * 2;
+            r.q0 = *reinterpret_cast<const uint16_t *>(p);
+            r.q1 = *reinterpret_cast<const uint16_t *>(p + 4);
+        }
+    } else if constexpr (T == PKV_TYPE_Q8_0) {
+        if (!IS_V) {
+            const uint16_t pk = *reinterpret_cast<const uint16_t *>(tile + (size_t) row * D + e0);
+            r.q0 = (int) (signed char) (pk & 0xFF); r.q1 = (int) (signed char) (pk >> 8);
+            r.d  = *reinterpret_cast<const uint16_t *>(sc + ((size_t) row * nb + blk) * 2);
+        } else {
+            const char * p = tile + ((size_t) (row / 4) * D + e0) * 4 + (row & 3);
+            r.q0 = (int) (signed char) p[0]; r.q1 = (int) (signed char) p[4];
+            r.d  = *reinterpret_cast<const uint16_t *>(sc + (((size_t) (row / 4) * nb + blk) * 4 + (row & 3)) * 2);
+        }
+    } else {
+        if (!IS_V) {
+            const int      j  = (lane & 15) & 7;  // lanes 0..7 read low nibbles, 8..15 the high nibbles of the same bytes
+            const uint16_t pk = *reinterpret_cast<const uint16_t *>(tile + (size_t) row * (D / 2) + blk * 16 + 2 * j);
+            const int      sh = (lane & 15) < 8 ? 0 : 4;
+            r.q0 = (pk >> sh) & 0xF; r.q1 = (pk >> (8 + sh)) & 0xF;
+            r.d  = *reinterpret_cast<const uint16_t *>(sc + ((size_t) row * nb + blk) * 2);
+        } else {
+            const uint32_t * w = reinterpret_cast<const uint32_t *>(tile + ((size_t) (row / 8) * D + e0) * 4);
+            const int sh = 4 * (row & 7);
+            r.q0 = (w[0] >> sh) & 0xF; r.q1 = (w[1] >> sh) & 0xF;
+            r.d  = *reinterpret_cast<const uint16_t *>(sc + (((size_t) (row / 8) * nb + blk) * 8 + (row & 7)) * 2);
         }
     }
     return r;
@@ -440,7 +455,8 @@ int launch_copy_cells(void * pool, int type, int is_v, const int32_t * sb, const
                       const int32_t * dof, int n, int n_head_kv, int D, int block_size, hipStream_t st) {
     if (n == 0) return PKV_OK;
     switch (type) {
-        case PKV_TYPE_F16:  return cells_d<PKV_TYPE_F16, false>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st);
+        case PKV_TYPE_F16:  return is_v ? cells_d<PKV_TYPE_F16, true>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st)
+                                        : cells_d<PKV_TYPE_F16, false>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st);
         case PKV_TYPE_Q8_0: return is_v ? cells_d<PKV_TYPE_Q8_0, true>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st)
                                         : cells_d<PKV_TYPE_Q8_0, false>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st);
         case PKV_TYPE_Q4_0: return is_v ? cells_d<PKV_TYPE_Q4_0, true>(pool, sb, so, db, dof, n, n_head_kv, D, block_size, st)

@@ -384,48 +384,45 @@ size_t pkv_o_tile_bytes(int type, int block_size, int D) {
 }
 
 // one reference-format row (one kv head of one token) <-> its place inside a tile.
-// K tiles: quants [tok][...] then scales [tok][D/32].  V tiles of quantized types interleave TL tokens per 8-d group
-// (q8_0: TL 2, q4_0: TL 4 with byte m = d 2m | d 2m+1 << 4); scales [tok/TL][D/32][TL].  See include/mi355_paged_kv.h.
+// K tiles: quants [tok][...] then scales [tok][D/32].
+// V tiles: [tok/TL][D] dwords, each dword = the TL tokens of one d (f16 TL 2, q8_0 TL 4, q4_0 TL 8 nibbles), then
+// scales [tok/TL][D/32][TL].  See include/mi355_paged_kv.h "Pool layout".
+static inline int q4_get(const uint8_t * rb, int e) { return e < 16 ? rb[2 + e] & 0xF : rb[2 + e - 16] >> 4; }
+static inline void q4_set(uint8_t * rb, int e, int n) {
+    if (e < 16) rb[2 + e] = (uint8_t) ((rb[2 + e] & 0xF0) | n);
+    else        rb[2 + e - 16] = (uint8_t) ((rb[2 + e - 16] & 0x0F) | (n << 4));
+}
 static void tile_row(uint8_t * tile, int type, int is_v, int off, uint8_t * row, int D, int block_size, int put) {
 #define MOVE(tp, rp, n) do { if (put) memcpy((tp), (rp), (n)); else memcpy((rp), (tp), (n)); } while (0)
-    if (type == PKV_O_F16) { MOVE(tile + (size_t) off * D * 2, row, (size_t) D * 2); return; }
     const int nb = D / QK;
+    if (type == PKV_O_F16) {
+        if (!is_v) { MOVE(tile + (size_t) off * D * 2, row, (size_t) D * 2); return; }
+        for (int d = 0; d < D; ++d) MOVE(tile + (((size_t) (off / 2) * D + d) * 2 + (off & 1)) * 2, row + (size_t) d * 2, 2);
+        return;
+    }
     uint8_t * sc = tile + (type == PKV_O_Q8_0 ? (size_t) block_size * D : (size_t) block_size * D / 2);
-    if (type == PKV_O_Q8_0) {
-        for (int b = 0; b < nb; ++b) {
+    for (int b = 0; b < nb; ++b) {
+        if (type == PKV_O_Q8_0) {
             uint8_t * rb = row + (size_t) b * 34;
             if (!is_v) {
                 MOVE(sc + ((size_t) off * nb + b) * 2, rb, 2);
                 MOVE(tile + (size_t) off * D + b * QK, rb + 2, QK);
             } else {
-                MOVE(sc + (((size_t) (off / 2) * nb + b) * 2 + (off & 1)) * 2, rb, 2);
-                for (int g = 0; g < 4; ++g)  // four 8-d groups per block
-                    MOVE(tile + (((size_t) (off / 2) * (D / 8) + b * 4 + g) * 2 + (off & 1)) * 8, rb + 2 + g * 8, 8);
+                MOVE(sc + (((size_t) (off / 4) * nb + b) * 4 + (off & 3)) * 2, rb, 2);
+                for (int e = 0; e < QK; ++e) MOVE(tile + ((size_t) (off / 4) * D + b * QK + e) * 4 + (off & 3), rb + 2 + e, 1);
             }
-        }
-    } else {
-        for (int b = 0; b < nb; ++b) {
+        } else {
             uint8_t * rb = row + (size_t) b * 18;
             if (!is_v) {
                 MOVE(sc + ((size_t) off * nb + b) * 2, rb, 2);
                 MOVE(tile + (size_t) off * (D / 2) + b * 16, rb + 2, 16);
             } else {
-                MOVE(sc + (((size_t) (off / 4) * nb + b) * 4 + (off & 3)) * 2, rb, 2);
-                // reference byte j = elem j | elem (j+16) << 4; tile byte m of group g = elem 8g+2m | elem 8g+2m+1 << 4
-                for (int g = 0; g < 4; ++g) {
-                    uint8_t * tp = tile + (((size_t) (off / 4) * (D / 8) + b * 4 + g) * 4 + (off & 3)) * 4;
-                    for (int m = 0; m < 4; ++m) {
-                        const int e0 = 8 * g + 2 * m, e1 = e0 + 1;
-                        if (put) {
-                            const int n0 = e0 < 16 ? rb[2 + e0] & 0xF : rb[2 + e0 - 16] >> 4;
-                            const int n1 = e1 < 16 ? rb[2 + e1] & 0xF : rb[2 + e1 - 16] >> 4;
-                            tp[m] = (uint8_t) (n0 | (n1 << 4));
-                        } else {
-                            const int n0 = tp[m] & 0xF, n1 = tp[m] >> 4;
-                            if (e0 < 16) rb[2 + e0] = (uint8_t) ((rb[2 + e0] & 0xF0) | n0); else rb[2 + e0 - 16] = (uint8_t) ((rb[2 + e0 - 16] & 0x0F) | (n0 << 4));
-                            if (e1 < 16) rb[2 + e1] = (uint8_t) ((rb[2 + e1] & 0xF0) | n1); else rb[2 + e1 - 16] = (uint8_t) ((rb[2 + e1 - 16] & 0x0F) | (n1 << 4));
-                        }
-                    }
+                MOVE(sc + (((size_t) (off / 8) * nb + b) * 8 + (off & 7)) * 2, rb, 2);
+                for (int e = 0; e < QK; ++e) {
+                    uint8_t * tp = tile + ((size_t) (off / 8) * D + b * QK + e) * 4 + (off & 7) / 2;  // nibble (off & 7) of the dword
+                    const int sh = 4 * (off & 1);
+                    if (put) *tp = (uint8_t) ((*tp & ~(0xF << sh)) | (q4_get(rb, e) << sh));
+                    else     q4_set(rb, e, (*tp >> sh) & 0xF);
                 }
             }
         }
