@@ -86,10 +86,9 @@ class Workload:
 
     def layer_step(self, l, flags=0):
         pkv, g = self.pkv, self.g
-        pkv.rope_f32(self.q[l], self.pos, self.rope, out=self.q[l])
-        pkv.kv_store(self.k_cur[l], self.v_cur[l], self.k_pools[l], self.v_pools[l], type_k=self.tk, type_v=self.tv,
-                     slot_block=self.slot_block, slot_off=self.slot_off, block_size=g["block_size"], pos=self.pos,
-                     rope=self.rope)
+        pkv.qkv_prepare(self.q[l], self.k_cur[l], self.v_cur[l], self.k_pools[l], self.v_pools[l], type_k=self.tk,
+                        type_v=self.tv, slot_block=self.slot_block, slot_off=self.slot_off, block_size=g["block_size"],
+                        pos=self.pos, rope=self.rope)
         self.attn(l, flags)
 
     def attn(self, l, flags=0):
@@ -186,7 +185,7 @@ def main():
     t = pkv.TYPE_BY_NAME[args.kv_type]
     w = Workload(pkv, torch, ctx=args.ctx, n_seq=args.n_seq, type_k=t, type_v=t, seed=1234 + rank)
 
-    # one decode step = 32 layers x (rope, store, split-KV attention, merge); captured once, replayed per step
+    # one decode step = 32 layers x (fused RoPE(Q)+RoPE(K)+KV store, split-KV attention, merge); captured once, replayed per step
     side = torch.cuda.Stream()
     graph = None
     with torch.cuda.stream(side):

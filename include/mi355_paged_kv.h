@@ -95,6 +95,14 @@ int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void *
                  const int32_t * pos, const pkv_rope_params * rope,
                  int n_tok, int n_head_kv, int head_dim, int block_size, void * stream);
 
+/* The three per-token ops that precede attention in a decoder layer, in ONE launch: RoPE(Q) in place
+ * (ggml_rope_ext, /ref/src/llama-model.cpp:4091-4096) + RoPE(K) + KV store (= pkv_kv_store with `rope`).
+ * q: device f32 [n_tok][n_head][head_dim], rotated in place with pos[t]. */
+int pkv_qkv_prepare(float * q, int n_head, const float * k_cur, const float * v_cur, void * k_pool, void * v_pool,
+                    int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off,
+                    const int32_t * pos, const pkv_rope_params * rope,
+                    int n_tok, int n_head_kv, int head_dim, int block_size, void * stream);
+
 /* Paged attention, one launch for all sequences of a micro-batch: replaces the K/V "gather" views +
  * ggml_flash_attn_ext of build_attn / build_attn_mha (/ref/src/llama-graph.cpp:1404-1432, :1160-1250),
  * CPU kernel ggml_compute_forward_flash_attn_ext_f16 (/ref/ggml/src/ggml-cpu/ggml-cpu.c:12219), and the dense

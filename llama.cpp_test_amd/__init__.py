@@ -163,6 +163,16 @@ def kv_store(k_cur, v_cur, k_pool, v_pool, *, type_k: int, type_v: int, slot_blo
                              n_tok, n_head_kv, D, block_size, C.c_void_p(_stream(stream))))
 
 
+def qkv_prepare(q, k_cur, v_cur, k_pool, v_pool, *, type_k: int, type_v: int, slot_block, slot_off, block_size: int,
+                pos, rope: RopeParams, stream=None) -> None:
+    """RoPE(Q) in place + RoPE(K) + KV store in one launch (llm_build_llama :4091-4102 + build_attn :1367-1398)."""
+    n_tok, n_head, D = q.shape
+    check(lib().pkv_qkv_prepare(C.c_void_p(_ptr(q)), n_head, C.c_void_p(_ptr(k_cur)), C.c_void_p(_ptr(v_cur)),
+                                C.c_void_p(_ptr(k_pool)), C.c_void_p(_ptr(v_pool)), type_k, type_v,
+                                C.c_void_p(_ptr(slot_block)), C.c_void_p(_ptr(slot_off)), C.c_void_p(_ptr(pos)),
+                                C.byref(rope), n_tok, k_cur.shape[1], D, block_size, C.c_void_p(_stream(stream))))
+
+
 def attn_workspace_bytes(n_tok: int, n_head: int, head_dim: int, max_seq_len: int, block_size: int) -> int:
     return lib().pkv_attn_workspace_bytes(n_tok, n_head, head_dim, max_seq_len, block_size)
 

@@ -290,6 +290,8 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         }
     }
 
+    __builtin_amdgcn_sched_barrier(0);  // keep the KV stream ahead of everything else in program order
+
     // ---- Q fragment (L2-resident, 16 KiB for the whole launch) ----------------------------------------------------
     QFrag<KT, D, G> qf;
     qf.load(a.q + (size_t) s * a.q_stride_tok + (size_t) hk * G * a.q_stride_head, a.q_stride_head, kc);
@@ -321,6 +323,7 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         x[j]  = ok ? v : -INFINITY;                           // mask == -inf -> skipped cell (:12349)
         mg[j] = head_reduce<TPW, true>(x[j]);                 // wave-local max of this head
         pj[j] = mg[j] == -INFINITY ? 0.0f : __expf(x[j] - mg[j]);
+        if constexpr (P16) pj[j] = (float) (_Float16) pj[j];  // the weight PV really applies; l is summed from the same values
     }
     // probabilities -> this wave's LDS strip, in the layout the PV loop reads (when there are fewer logits than K
     // lanes the low lane bits hold duplicates: they write the same value to the same place)
@@ -452,11 +455,12 @@ __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
         __syncthreads();
         const int n = min(CH, ns - j0);
         int jj = 0;
-        for (; jj + 4 <= n; jj += 4) {  // 4 independent loads in flight per thread
-            const float p0 = po[(size_t) (j0 + jj) * D + d], p1 = po[(size_t) (j0 + jj + 1) * D + d];
-            const float p2 = po[(size_t) (j0 + jj + 2) * D + d], p3 = po[(size_t) (j0 + jj + 3) * D + d];
-            acc = fmaf(p0, sW[jj], acc); acc = fmaf(p1, sW[jj + 1], acc);
-            acc = fmaf(p2, sW[jj + 2], acc); acc = fmaf(p3, sW[jj + 3], acc);
+        for (; jj + 8 <= n; jj += 8) {  // 8 independent loads in flight per thread
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = po[(size_t) (j0 + jj + u) * D + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(pv[u], sW[jj + u], acc);
         }
         for (; jj < n; ++jj) acc = fmaf(po[(size_t) (j0 + jj) * D + d], sW[jj], acc);
     }

@@ -97,8 +97,21 @@ int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void *
     PKV_REQUIRE(!rope || pos, "pkv_kv_store: fused rope needs pos");
     RopeDev r;
     if (rope) { if (int rc = make_rope(rope, head_dim, &r)) return rc; }
-    return launch_kv_store(k_cur, v_cur, k_pool, v_pool, type_k, type_v, slot_block, slot_off, pos, rope ? &r : nullptr,
-                           n_tok, n_head_kv, head_dim, block_size, (hipStream_t) stream);
+    return launch_kv_store(nullptr, 0, k_cur, v_cur, k_pool, v_pool, type_k, type_v, slot_block, slot_off, pos,
+                           rope ? &r : nullptr, n_tok, n_head_kv, head_dim, block_size, (hipStream_t) stream);
+}
+
+int pkv_qkv_prepare(float * q, int n_head, const float * k_cur, const float * v_cur, void * k_pool, void * v_pool,
+                    int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
+                    const pkv_rope_params * rope, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(q && k_cur && v_cur && k_pool && v_pool && slot_block && slot_off && pos && rope, "pkv_qkv_prepare: null pointer");
+    PKV_REQUIRE(kv_type_ok(type_k) && kv_type_ok(type_v), "pkv_qkv_prepare: KV types must be f16/q8_0/q4_0");
+    PKV_REQUIRE(n_tok >= 0 && n_head > 0 && n_head_kv > 0 && block_size > 0 && block_size % 8 == 0, "pkv_qkv_prepare: bad sizes");
+    RopeDev r;
+    if (int rc = make_rope(rope, head_dim, &r)) return rc;
+    return launch_kv_store(q, n_head, k_cur, v_cur, k_pool, v_pool, type_k, type_v, slot_block, slot_off, pos, &r, n_tok,
+                           n_head_kv, head_dim, block_size, (hipStream_t) stream);
 }
 
 size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq_len, int block_size) {

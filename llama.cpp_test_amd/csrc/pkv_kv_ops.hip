@@ -263,6 +263,7 @@ template <int T> __device__ __forceinline__ Q2 ref_read(const char * row, int la
 
 // ---- kernels ----------------------------------------------------------------------------------------------
 struct StoreArgs {
+    float * q; int n_head_q;
     const float * k_cur; const float * v_cur;
     char * k_pool; char * v_pool;
     const int32_t * slot_block; const int32_t * slot_off; const int32_t * pos;
@@ -270,10 +271,23 @@ struct StoreArgs {
     RopeDev rope;
 };
 
-// grid (n_head_kv, n_tok, 2): z = 0 stores K (optionally roped), z = 1 stores V
+// grid (max(n_head_kv, n_head_q), n_tok, 2 or 3): z = 0 stores K (optionally roped), z = 1 stores V,
+// z = 2 rotates the Q heads in place (pkv_qkv_prepare: the three per-token ops of a decode step in ONE launch)
 template <int KT, int VT, int D>
 __global__ void __launch_bounds__(64) kv_store_kernel(const StoreArgs a) {
     const int h = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    if (blockIdx.z == 2) {
+        if (h >= a.n_head_q || 2 * lane >= D) return;
+        float2 * qp = reinterpret_cast<float2 *>(a.q + ((size_t) t * a.n_head_q + h) * D + 2 * lane);
+        float2   x  = *qp;
+        if ((a.rope.mode & 2) == 0) {
+            if (2 * lane < a.rope.n_dims) *qp = rope_row<D>(x, lane, a.pos[t], a.rope, 1.0f);
+        } else {
+            *qp = rope_row<D>(x, lane, a.pos[t], a.rope, 1.0f);
+        }
+        return;
+    }
+    if (h >= a.n_head_kv) return;
     const bool is_v = blockIdx.z == 1;
     const float * cur = is_v ? a.v_cur : a.k_cur;
     if (!cur) return;
@@ -371,7 +385,7 @@ int launch_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok
 
 template <int KT, int VT>
 static int store_d(const StoreArgs & a, int n_tok, int D, hipStream_t st) {
-    dim3 grid(a.n_head_kv, n_tok, 2);
+    dim3 grid(a.q ? (a.n_head_q > a.n_head_kv ? a.n_head_q : a.n_head_kv) : a.n_head_kv, n_tok, a.q ? 3 : 2);
     if (D == 128)      hipLaunchKernelGGL((kv_store_kernel<KT, VT, 128>), grid, dim3(64), 0, st, a);
     else if (D == 64)  hipLaunchKernelGGL((kv_store_kernel<KT, VT, 64>), grid, dim3(64), 0, st, a);
     else { set_error("pkv_kv_store: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
@@ -388,11 +402,12 @@ static int store_v(const StoreArgs & a, int type_v, int n_tok, int D, hipStream_
     return PKV_ERR_UNSUPPORTED;
 }
 
-int launch_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
-                    const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos, const RopeDev * rope,
-                    int n_tok, int n_head_kv, int D, int block_size, hipStream_t st) {
+int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * v_cur, void * k_pool, void * v_pool,
+                    int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
+                    const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st) {
     if (n_tok == 0) return PKV_OK;
     StoreArgs a{};
+    a.q = q; a.n_head_q = n_head_q;
     a.k_cur = k_cur; a.v_cur = v_cur; a.k_pool = (char *) k_pool; a.v_pool = (char *) v_pool;
     a.slot_block = slot_block; a.slot_off = slot_off; a.pos = pos;
     a.n_head_kv = n_head_kv; a.block_size = block_size; a.has_rope = rope != nullptr;

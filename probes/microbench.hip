@@ -23,14 +23,30 @@ __global__ void __launch_bounds__(BLOCK) k_read(const uint4 * __restrict__ src, 
 }
 
 template <int NL, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_read_nt(const uint4 * __restrict__ src, uint32_t * __restrict__ dst) {
+    const size_t base = (size_t) blockIdx.x * BLOCK * NL + threadIdx.x;
+    uint4 v[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const uint4 * p = src + base + (size_t) i * BLOCK;
+        v[i].x = __builtin_nontemporal_load(&p->x); v[i].y = __builtin_nontemporal_load(&p->y);
+        v[i].z = __builtin_nontemporal_load(&p->z); v[i].w = __builtin_nontemporal_load(&p->w);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    if (acc == 0x12345678u) dst[blockIdx.x] = acc;
+}
+
+template <int NL, int BLOCK, bool NT = false>
 void run_read(const char * name, const std::vector<uint4 *> & bufs, uint32_t * dst, size_t bytes, int iters) {
     const int grid = (int) (bytes / ((size_t) BLOCK * NL * 16));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 4; ++i) hipLaunchKernelGGL((k_read<NL, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, bufs[i % bufs.size()], dst);
+    for (int i = 0; i < 4; ++i) if (NT) hipLaunchKernelGGL((k_read_nt<NL, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, bufs[i % bufs.size()], dst); else hipLaunchKernelGGL((k_read<NL, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, bufs[i % bufs.size()], dst);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_read<NL, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, bufs[i % bufs.size()], dst);
+    for (int i = 0; i < iters; ++i) { if (NT) hipLaunchKernelGGL((k_read_nt<NL, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, bufs[i % bufs.size()], dst); else hipLaunchKernelGGL((k_read<NL, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, bufs[i % bufs.size()], dst); }
     CK(hipEventRecord(b));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, a, b));
@@ -61,5 +77,8 @@ int main(int argc, char ** argv) {
     run_read<4, 512>("read 512wg(512t) x 4", bufs, dst, bytes, iters);
     run_read<16, 64>("read 1024wg(64t) x 16", bufs, dst, bytes, iters);
     run_read<8, 64>("read 2048wg(64t) x 8", bufs, dst, bytes, iters);
+    run_read<8, 512, true>("nt read 256wg(512t) x 8", bufs, dst, bytes, iters);
+    run_read<2, 256, true>("nt read 2048wg x 2", bufs, dst, bytes, iters);
+    run_read<16, 256, true>("nt read 256wg x 16", bufs, dst, bytes, iters);
     return 0;
 }

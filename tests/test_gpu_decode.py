@@ -139,7 +139,7 @@ def test_decode_full_size_properties(pkv, O):
     vc = np.full(vp.shape, 0, np.uint8).view(np.float16)
     vc[:] = np.float16(0.375)
     cst = run_decode(pkv, q, kp, vc.view(np.uint8), bt, sl, n_head_kv=nkv, tk=1, tv=1)
-    assert np.abs(cst - 0.375).max() < 1e-6
+    assert np.abs(cst - 0.375).max() < 1e-6   # numerator and denominator use the same (f16-rounded) weights
     # (d) oracle on the full length (a few seconds of CPU)
     ref = O.attn_paged(q[:, :, None, :], kp, vp, bt, sl, n_q=1, type_k=1, type_v=1, block_size=128, scale=D ** -0.5,
                        n_threads=8)[:, 0]

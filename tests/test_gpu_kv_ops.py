@@ -248,3 +248,25 @@ def test_cache_device_update_cow_shift_defrag(pkv, O, tk, tv):
     assert c.seq_slot_pos(0).tolist() == list(range(161))
     check(quantum)
     c.close()
+
+
+@pytest.mark.parametrize("tk,tv", [(1, 1), (8, 8), (2, 2)])
+def test_qkv_prepare_equals_separate_ops(pkv, tk, tv):
+    """the one-launch RoPE(Q)+RoPE(K)+store must write exactly what rope_f32 + kv_store(rope) write"""
+    rng = np.random.default_rng(77)
+    D, nh, nkv, bs, n_tok = 128, 32, 8, 128, 5
+    q = dev(rng.uniform(-1, 1, (n_tok, nh, D)).astype(np.float32))
+    k = dev(rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32))
+    v = dev(rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32))
+    pos = dev(np.array([0, 17, 4095, 4096, 9000], np.int32))
+    sb, so = dev(np.array([1, 0, 1, 0, 1], np.int32)), dev(np.array([5, 9, 127, 0, 64], np.int32))
+    rp = pkv.rope_params(n_dims=D)
+    pools = [[torch.zeros(pkv.pool_bytes(t, 2, nkv, bs, D), dtype=torch.uint8, device="cuda") for t in (tk, tv)] for _ in range(2)]
+    q1 = pkv.rope_f32(q, pos, rp)
+    pkv.kv_store(k, v, pools[0][0], pools[0][1], type_k=tk, type_v=tv, slot_block=sb, slot_off=so, block_size=bs, pos=pos, rope=rp)
+    q2 = q.clone()
+    pkv.qkv_prepare(q2, k, v, pools[1][0], pools[1][1], type_k=tk, type_v=tv, slot_block=sb, slot_off=so, block_size=bs,
+                    pos=pos, rope=rp)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q2)
+    assert torch.equal(pools[0][0], pools[1][0]) and torch.equal(pools[0][1], pools[1][1])
