@@ -69,8 +69,9 @@ class Workload:
         self.slot_block = self.block_table[:, last // BS].contiguous()
         self.slot_off = torch.full((n_seq,), last % BS, dtype=torch.int32, device=dev)
         self.rope = pkv.rope_params(n_dims=D)                              # llama-3: NORM pairs, freq_base 5e5
-        self.ws = torch.empty(max(16, pkv.attn_workspace_bytes(n_seq, H, D, ctx, BS)), dtype=torch.uint8, device=dev)
+        self.ws = pkv.attn_workspace(n_seq, H, D, ctx, BS)
         self.scale = D ** -0.5
+        self.step_flags = 0
 
     def _random_pool(self, t, gen):
         torch, pkv, g = self.torch, self.pkv, self.g
@@ -84,7 +85,8 @@ class Workload:
         scales = (torch.rand((nb, HK, BS * D // 32), generator=gen, device="cuda") * 0.01 + 0.001).to(torch.float16)
         return torch.cat([quants, scales.view(torch.uint8).reshape(nb, HK, -1)], dim=2).contiguous()
 
-    def layer_step(self, l, flags=0):
+    def layer_step(self, l, flags=None):
+        flags = self.step_flags if flags is None else flags
         pkv, g = self.pkv, self.g
         pkv.qkv_prepare(self.q[l], self.k_cur[l], self.v_cur[l], self.k_pools[l], self.v_pools[l], type_k=self.tk,
                         type_v=self.tv, slot_block=self.slot_block, slot_off=self.slot_off, block_size=g["block_size"],
@@ -103,19 +105,21 @@ class Workload:
 
 
 def measure_dominant_kernel(w: Workload, torch, reps: int):
-    """average duration of ONE launch of the dominant kernel (the split-KV paged decode kernel, merge launch skipped),
+    """average duration of ONE launch of the dominant kernel — the paged decode kernel exactly as the timed step runs
+    it (with the in-kernel merge when that is on; otherwise the split-KV kernel alone, merge launch skipped) —
     bracketed by HIP events on the stream the kernel runs on; layers are cycled so every launch reads cold KV."""
     st = torch.cuda.current_stream()
     L = w.g["n_layer"]
+    kflags = w.step_flags if w.step_flags & w.pkv.ATTN_FUSED_COMBINE else w.pkv.ATTN_NO_COMBINE
     for l in range(L):
-        w.attn(l, flags=w.pkv.ATTN_NO_COMBINE)
+        w.attn(l, flags=kflags)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps * L)]
     i = 0
     for _ in range(reps):
         for l in range(L):
             evs[i][0].record(st)
-            w.attn(l, flags=w.pkv.ATTN_NO_COMBINE)
+            w.attn(l, flags=kflags)
             evs[i][1].record(st)
             i += 1
     torch.cuda.synchronize()
@@ -163,6 +167,7 @@ def main():
     ap.add_argument("--kv-type", default="f16", choices=["f16", "q8_0", "q4_0"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-launch-merge", action="store_true", help="merge the split-KV partials in a second launch instead of inside the decode kernel")
     ap.add_argument("--kernel-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -184,6 +189,7 @@ def main():
 
     t = pkv.TYPE_BY_NAME[args.kv_type]
     w = Workload(pkv, torch, ctx=args.ctx, n_seq=args.n_seq, type_k=t, type_v=t, seed=1234 + rank)
+    w.step_flags = 0 if args.two_launch_merge else pkv.ATTN_FUSED_COMBINE
 
     # one decode step = 32 layers x (fused RoPE(Q)+RoPE(K)+KV store, split-KV attention, merge); captured once, replayed per step
     side = torch.cuda.Stream()
@@ -229,7 +235,7 @@ def main():
         "config": {"workload": f"Llama-3-8B geometry, {args.n_seq} seq/GPU, ctx {args.ctx} paged decode "
                                f"(block_size 128, {args.kv_type} KV), attention path of all 32 layers per token",
                    "n_layer": 32, "n_head": 32, "n_head_kv": 8, "head_dim": 128, "block_size": 128, "ctx": args.ctx,
-                   "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "eager" if graph is None else "hipGraph",
+                   "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "eager" if graph is None else "hipGraph", "merge": "second launch" if args.two_launch_merge else "in-kernel (last-arriving workgroup)",
                    "parallelism": f"replicas x{world} (no collective on the data path)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

@@ -132,8 +132,14 @@ typedef struct pkv_attn_args {
 /* leave the per-block (m, l, O) partials in `workspace` and skip the merge launch (measurement / callers that
  * merge elsewhere); `out` is not written */
 #define PKV_ATTN_NO_COMBINE 1
+/* merge the per-block partials INSIDE the decode launch (the last-arriving workgroup of each (sequence, kv head) does
+ * it; arrival tickets live at the end of `workspace`).  Contract: `workspace` was zeroed once by
+ * pkv_attn_workspace_init() and is used by one launch at a time.  Ignored (two-launch path) with softcap / slot_pos. */
+#define PKV_ATTN_FUSED_COMBINE 2
 
 size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq_len, int block_size);
+/* zero a fresh workspace (asynchronously, on `stream`); required once before PKV_ATTN_FUSED_COMBINE is used with it */
+int    pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream);
 /* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks */
 int pkv_attn_decode(const pkv_attn_args * args, void * stream);
 /* batched prefill (many query tokens per sequence, causal): MFMA QK^T / PV */

@@ -31,6 +31,7 @@ TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0}
 # enum pkv_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SPACE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 ATTN_NO_COMBINE = 1
+ATTN_FUSED_COMBINE = 2
 
 
 class PkvError(RuntimeError):
@@ -186,13 +187,22 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
     out = torch.empty((n_tok, n_head, D), dtype=torch.float32, device=q.device) if out is None else out
     need = attn_workspace_bytes(n_tok, n_head, D, max_seq_len, block_size)
     if workspace is None:
-        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+        workspace = torch.zeros(max(need, 16), dtype=torch.uint8, device=q.device)   # zeroed: valid for ATTN_FUSED_COMBINE
     a = AttnArgs(_ptr(q), q.stride(0), q.stride(1), _ptr(out), _ptr(k_pool), _ptr(v_pool), _ptr(block_table),
                  _ptr(seq_lens), _ptr(q_start), _ptr(slot_pos), _ptr(q_pos), _ptr(workspace), workspace.numel(),
                  n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
                  scale, logit_softcap, max_seq_len, flags)
     check(fn(C.byref(a), C.c_void_p(_stream(stream))))
     return out
+
+
+def attn_workspace(n_tok: int, n_head: int, head_dim: int, max_seq_len: int, block_size: int, device="cuda"):
+    """a workspace that is valid for every flag combination (zeroed through pkv_attn_workspace_init)"""
+    import torch
+    ws = torch.empty(max(16, attn_workspace_bytes(n_tok, n_head, head_dim, max_seq_len, block_size)), dtype=torch.uint8,
+                     device=device)
+    check(lib().pkv_attn_workspace_init(C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), C.c_void_p(_stream())))
+    return ws
 
 
 def attn_decode(q, k_pool, v_pool, block_table, seq_lens, **kw):

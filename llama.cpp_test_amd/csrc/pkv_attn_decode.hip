@@ -72,7 +72,8 @@ struct DecodeArgs {
     float *         part_o;   // [n_seq][n_head][n_splits][D]
     float *         part_ml;  // [n_seq][n_head][n_splits][2]
     float *         out;      // [n_seq][n_head][D]
-    int   n_head, n_head_kv, block_size, max_blocks, n_splits;
+    unsigned *      counters; // [n_seq][n_head_kv] arrival tickets (fused merge), zero between launches
+    int   n_head, n_head_kv, block_size, max_blocks, n_splits, bs_shift;  // block_size = WG_TOK << bs_shift
     float scale, softcap;
 };
 
@@ -234,7 +235,7 @@ struct Geo {
     static constexpr int K_NL = TPW / K_RPL, V_NL = TPW / V_RPL;
 };
 
-template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS>
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED>
 __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(const DecodeArgs a) {
     using GE = Geo<KT, VT, D>;
     using KT_ = KTr<KT, D>;
@@ -249,13 +250,18 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     __shared__ float sML[NW][G][2];                                                 // per-wave (max, sum)
 
     const int split = blockIdx.x, hk = blockIdx.y, s = blockIdx.z;
+    const int base  = split * WG_TOK;
+    // the two scalar loads every KV address depends on are independent of each other: issue both, then branch
+    // (the table entry of a split past the end of the sequence is in bounds — grid.x <= max_blocks — and unused)
+    const int lb = split >> a.bs_shift, boff = (split & ((1 << a.bs_shift) - 1)) * WG_TOK;
+    const int phys    = a.block_table[(size_t) s * a.max_blocks + lb];
     const int seq_len = a.seq_lens[s];
-    const int base    = split * WG_TOK;
+    // everything the KV addresses need is requested before the branch (hipcc otherwise sinks the table load and the
+    // remaining kernel-argument loads below it, one scalar round trip each)
+    asm volatile("" ::"s"(phys), "s"(seq_len), "s"(a.k_pool), "s"(a.v_pool), "s"(a.q));
     if (base >= seq_len) return;  // workgroup-uniform
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int lb = base / a.block_size, boff = base % a.block_size;
-    const int phys = a.block_table[(size_t) s * a.max_blocks + lb];
     const char * ktile = a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(KT, a.block_size, D);
     const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(VT, a.block_size, D);
     const int n_valid = min(WG_TOK, seq_len - base);  // >= 1
@@ -398,6 +404,9 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     __syncthreads();
 
     // ---- merge the waves (each has its own max) and publish one (m, l, O) partial per workgroup -------------------
+    // FUSED: the partials are handed to the last-arriving workgroup of this (sequence, kv head) inside the launch, so
+    // they leave as agent-scope write-through stores (global_store ... sc1): no release fence, and the reader uses
+    // sc1 loads (cdna_hip_programming.md §5 "In-launch split-K reduction", the sc1 form).
     for (int e = tid; e < G * D; e += NT) {
         const int g = e / D, d = e % D;
         float M = -INFINITY;
@@ -411,8 +420,50 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
             l = fmaf(sML[w][g][1], f, l);
         }
         const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
-        a.part_o[pi * D + d] = o;
-        if (d == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = l; }
+        if constexpr (FUSED) {
+            __hip_atomic_store(&a.part_o[pi * D + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) {
+                __hip_atomic_store(&a.part_ml[pi * 2], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.part_ml[pi * 2 + 1], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            a.part_o[pi * D + d] = o;
+            if (d == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = l; }
+        }
+    }
+    if constexpr (FUSED) {
+        __shared__ unsigned sLast;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores ...
+        __syncthreads();                                       // ... before ONE lane signals for the workgroup
+        const unsigned n_act = (unsigned) (seq_len + WG_TOK - 1) / WG_TOK;   // workgroups that arrive for this (s, hk)
+        if (tid == 0) {
+            // wrapping ticket: 0, 1, ..., n_act-1, then back to 0 by itself -> no per-launch reset of the counter
+            const unsigned old = atomicInc(a.counters + (size_t) s * a.n_head_kv + hk, n_act - 1);
+            sLast = old == n_act - 1;
+        }
+        __syncthreads();
+        if (!sLast) return;
+        // last arriver: merge the n_act partials of its G query heads (sc1 loads only) and write the output rows
+        const int ns = (int) n_act;
+        for (int e = tid; e < G * D; e += NT) {
+            const int g = e / D, d = e % D;
+            const size_t pb = ((size_t) s * a.n_head + hk * G + g) * a.n_splits;
+            float M = -INFINITY;
+#pragma unroll 8
+            for (int j = 0; j < ns; ++j)
+                M = fmaxf(M, __hip_atomic_load(&a.part_ml[(pb + j) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            float L = 0.0f, acc = 0.0f;
+#pragma unroll 8
+            for (int j = 0; j < ns; ++j) {
+                const float mj = __hip_atomic_load(&a.part_ml[(pb + j) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float lj = __hip_atomic_load(&a.part_ml[(pb + j) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float oj = __hip_atomic_load(&a.part_o[(pb + j) * D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float w  = mj == -INFINITY ? 0.0f : __expf(mj - M);
+                L   = fmaf(lj, w, L);
+                acc = fmaf(oj, w, acc);
+            }
+            a.out[((size_t) s * a.n_head + hk * G + g) * D + d] = acc / L;
+        }
     }
 }
 
@@ -478,11 +529,15 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     dim3 grid(da.n_splits, da.n_head_kv, n_seq);
     const dim3 block(64 * Geo<KT, VT, D>::NW);
     const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr;
-    if (!cap && !sp)      hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, false>), grid, block, 0, st, da);
-    else if (!cap && sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, true>), grid, block, 0, st, da);
-    else if (cap && !sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, false>), grid, block, 0, st, da);
-    else                  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, true>), grid, block, 0, st, da);
-    if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
+    if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
+        hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, false, true>), grid, block, 0, st, da);
+    } else {
+        if (!cap && !sp)      hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, false, false>), grid, block, 0, st, da);
+        else if (!cap && sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, true, false>), grid, block, 0, st, da);
+        else if (cap && !sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, false, false>), grid, block, 0, st, da);
+        else                  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, true, false>), grid, block, 0, st, da);
+        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
+    }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
@@ -521,16 +576,17 @@ int launch_v(const DecodeArgs & da, int VT, int D, int G, int n_seq, hipStream_t
 
 }  // namespace
 
+// [part_o f32 n_tok*n_head*ns*D][part_ml f32 n_tok*n_head*ns*2][tickets u32 n_tok*n_head]
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len) {
     const size_t ns = (size_t) (max_seq_len + WG_TOK - 1) / WG_TOK;
-    return (size_t) n_tok * n_head * (ns ? ns : 1) * (D + 2) * sizeof(float);
+    return (size_t) n_tok * n_head * (ns ? ns : 1) * (D + 2) * sizeof(float) + (size_t) n_tok * n_head * sizeof(unsigned);
 }
 
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.q && (a.out || (a.flags & PKV_ATTN_NO_COMBINE)) && a.k_pool && a.v_pool && a.block_table && a.seq_lens, "pkv_attn_decode: null pointer");
     PKV_REQUIRE(a.q_start == nullptr && a.n_tok == a.n_seq, "pkv_attn_decode: one query token per sequence (use pkv_attn_prefill)");
     PKV_REQUIRE(a.n_seq > 0 && a.n_head > 0 && a.n_head_kv > 0 && a.n_head % a.n_head_kv == 0, "pkv_attn_decode: bad head counts");
-    PKV_REQUIRE(a.block_size > 0 && a.block_size % WG_TOK == 0, "pkv_attn_decode: block_size must be a multiple of %d", WG_TOK);
+    PKV_REQUIRE(a.block_size >= WG_TOK && (a.block_size & (a.block_size - 1)) == 0, "pkv_attn_decode: block_size must be a power of two >= %d", WG_TOK);
     PKV_REQUIRE(kv_type_ok(a.type_k) && kv_type_ok(a.type_v), "pkv_attn_decode: KV types must be f16/q8_0/q4_0");
     PKV_REQUIRE(a.max_seq_len > 0 && a.max_seq_len <= a.max_blocks * a.block_size, "pkv_attn_decode: max_seq_len out of range");
     PKV_REQUIRE((a.q_stride_head % 4) == 0 && (a.q_stride_tok % 4) == 0 && ((uintptr_t) a.q % 16) == 0, "pkv_attn_decode: q must be 16-byte aligned");
@@ -544,9 +600,14 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {
     da.block_table = a.block_table; da.seq_lens = a.seq_lens; da.slot_pos = a.slot_pos; da.q_pos = a.q_pos;
     da.n_head = a.n_head; da.n_head_kv = a.n_head_kv; da.block_size = a.block_size; da.max_blocks = a.max_blocks;
     da.n_splits = (a.max_seq_len + WG_TOK - 1) / WG_TOK;
+    da.bs_shift = 0;
+    while ((WG_TOK << da.bs_shift) < a.block_size) ++da.bs_shift;
     da.part_o  = (float *) a.workspace;
     da.part_ml = da.part_o + (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim;
     da.out = (a.flags & PKV_ATTN_NO_COMBINE) ? nullptr : a.out;
+    da.counters = nullptr;
+    if ((a.flags & PKV_ATTN_FUSED_COMBINE) && !(a.flags & PKV_ATTN_NO_COMBINE) && a.logit_softcap == 0.0f && !a.slot_pos)
+        da.counters = reinterpret_cast<unsigned *>(da.part_ml + (size_t) a.n_tok * a.n_head * da.n_splits * 2);
     da.softcap = a.logit_softcap;
     da.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;  // :12290-12292
     const int G = a.n_head / a.n_head_kv;

@@ -121,6 +121,13 @@ size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq
     return a > b ? a : b;
 }
 
+int pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(workspace != nullptr, "pkv_attn_workspace_init: null workspace");
+    PKV_HIP(hipMemsetAsync(workspace, 0, bytes, (hipStream_t) stream));
+    return PKV_OK;
+}
+
 int pkv_attn_decode(const pkv_attn_args * args, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(args != nullptr, "pkv_attn_decode: null args");

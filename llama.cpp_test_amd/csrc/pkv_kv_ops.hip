@@ -6,6 +6,10 @@
 // lanes = one DPP row) use DPP only.
 #include "pkv_common.h"
 
+// every kernel of this file must round a given expression the same way (bit-exact parity between the fused and
+// the separate launches): no implicit FMA contraction
+#pragma clang fp contract(off)
+
 #include <math.h>
 
 namespace pkv {
@@ -42,6 +46,10 @@ __device__ __forceinline__ float2 rope_cs(int pos, int ip, const RopeDev & r, fl
     return make_float2(cosf(th) * mscale, sinf(th) * mscale * sin_sign);
 }
 
+// one rotation, with the contraction spelled out so that every kernel (and every call site) rounds identically
+__device__ __forceinline__ float rot0(float x0, float x1, float c, float sn) { return __fmaf_rn(x0, c, -(x1 * sn)); }
+__device__ __forceinline__ float rot1(float x0, float x1, float c, float sn) { return __fmaf_rn(x0, sn, x1 * c); }
+
 // rotate the wave's row in registers: lane i holds (x0, x1) = elements (2i, 2i+1) of a row of D elements
 template <int D>
 __device__ __forceinline__ float2 rope_row(float2 x, int lane, int pos, const RopeDev & r, float sin_sign) {
@@ -49,7 +57,7 @@ __device__ __forceinline__ float2 rope_row(float2 x, int lane, int pos, const Ro
     if ((r.mode & 2) == 0) {  // NORM: pairs (2i, 2i+1)
         if (e0 < r.n_dims) {
             const float2 cs = rope_cs(pos, lane, r, sin_sign);
-            return make_float2(x.x * cs.x - x.y * cs.y, x.x * cs.y + x.y * cs.x);
+            return make_float2(rot0(x.x, x.y, cs.x, cs.y), rot1(x.x, x.y, cs.x, cs.y));
         }
         return x;
     }
@@ -59,8 +67,8 @@ __device__ __forceinline__ float2 rope_row(float2 x, int lane, int pos, const Ro
     const bool  lo = lane < HL;
     const int   ic = lo ? e0 : e0 - D / 2;
     const float2 c0 = rope_cs(pos, ic, r, sin_sign), c1 = rope_cs(pos, ic + 1, r, sin_sign);
-    return lo ? make_float2(x.x * c0.x - px * c0.y, x.y * c1.x - py * c1.y)
-              : make_float2(px * c0.y + x.x * c0.x, py * c1.y + x.y * c1.x);
+    return lo ? make_float2(rot0(x.x, px, c0.x, c0.y), rot0(x.y, py, c1.x, c1.y))
+              : make_float2(rot1(px, x.x, c0.x, c0.y), rot1(py, x.y, c1.x, c1.y));
 }
 
 __global__ void __launch_bounds__(64) rope_f32_kernel(const float * x, const int32_t * pos, float * out, int n_head,
@@ -75,8 +83,8 @@ __global__ void __launch_bounds__(64) rope_f32_kernel(const float * x, const int
             const float2 cs = rope_cs(p, ip, r, sin_sign);
             const int i0 = neox ? ip : 2 * ip, i1 = neox ? ip + r.n_dims / 2 : 2 * ip + 1;
             const float x0 = src[i0], x1 = src[i1];
-            dst[i0] = x0 * cs.x - x1 * cs.y;
-            dst[i1] = x0 * cs.y + x1 * cs.x;
+            dst[i0] = rot0(x0, x1, cs.x, cs.y);
+            dst[i1] = rot1(x0, x1, cs.x, cs.y);
         } else {  // pass-through channels (:10841-10847)
             dst[2 * ip]     = src[2 * ip];
             dst[2 * ip + 1] = src[2 * ip + 1];

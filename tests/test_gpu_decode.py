@@ -160,3 +160,29 @@ def test_decode_rejects_bad_arguments(pkv, O):
     with pytest.raises(pkv.PkvError):        # n_head not a multiple of n_head_kv
         pkv.attn_decode(q, dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=3, type_k=1, type_v=1, block_size=128, scale=1.0,
                         max_seq_len=100)
+
+
+@pytest.mark.parametrize("tk", [1, 8])
+def test_decode_fused_merge_matches_two_launch(pkv, O, tk):
+    """PKV_ATTN_FUSED_COMBINE: the last-arriving workgroup merges inside the decode launch; the arrival tickets wrap back
+    to zero by themselves, so the same workspace serves launch after launch (ragged lengths, several sequences)."""
+    rng = np.random.default_rng(31 + tk)
+    D, nh, nkv = 128, 32, 8
+    lens = [4096, 1, 129, 640, 128, 2000]
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
+    q = rng.uniform(-1, 1, (len(lens), nh, D)).astype(np.float32)
+    base = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=nkv, tk=tk, tv=tk)
+    ws = pkv.attn_workspace(len(lens), nh, D, int(sl.max()), 128)
+    dq, dk, dv, dbt, dsl = dev(q), dev(kp), dev(vp), dev(bt), dev(sl)
+    for it in range(4):                                           # same workspace, back to back
+        out = pkv.attn_decode(dq, dk, dv, dbt, dsl, n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5,
+                              max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - base).max() <= 2e-6, it
+    # shorter sequences afterwards: fewer arrivals per ticket, still consistent
+    sl2 = np.minimum(sl, 200).astype(np.int32)
+    base2 = run_decode(pkv, q, kp, vp, bt, sl2, n_head_kv=nkv, tk=tk, tv=tk)
+    out2 = pkv.attn_decode(dq, dk, dv, dbt, dev(sl2), n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5,
+                           max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
+    torch.cuda.synchronize()
+    assert np.abs(out2.cpu().numpy() - base2).max() <= 2e-6
