@@ -292,7 +292,10 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
             const _Float16 * sp = reinterpret_cast<const _Float16 *>(
                 vtile + tile_quant_bytes(VT, a.block_size, D) + ((size_t) grp * (D / PKV_QK) + vc / 8) * V_TL * 2);
 #pragma unroll
-            for (int t = 0; t < V_TL; ++t) vsc[i][t] = (float) sp[t];
+            for (int t = 0; t < V_TL; ++t) {
+                const float sc = (float) sp[t];               // unconditional load, then a select: no branch
+                vsc[i][t] = tw + t < n_valid ? sc : 0.0f;     // a stale scale of a cell past the end must not reach 0 * NaN
+            }
         }
     }
 
@@ -371,10 +374,9 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         } else {
 #pragma unroll
             for (int t = 0; t < V_TL; ++t) {
-                float p[G];
-                const bool live = wave * TPW + t0 + t < n_valid;
+                float p[G];   // p is already 0 for cells past the end of the sequence, and so is their scale
 #pragma unroll
-                for (int g = 0; g < G; ++g) p[g] = live ? sP[wave][(t0 + t) * G + g] * vsc[i][t] : 0.0f;
+                for (int g = 0; g < G; ++g) p[g] = sP[wave][(t0 + t) * G + g] * vsc[i][t];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float vf;
