@@ -142,6 +142,10 @@ size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq
 int    pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream);
 /* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks */
 int pkv_attn_decode(const pkv_attn_args * args, void * stream);
+/* measurement aid: same launch, but blocks until it is done and returns the duration of the split-KV decode kernel
+ * alone, taken from the dispatch's own GPU start/stop timestamps (hipExtLaunchKernel events) — the quantity
+ * rocprofv3 --kernel-trace reports.  Not for the serving path (it synchronises the stream). */
+int pkv_attn_decode_profiled(const pkv_attn_args * args, void * stream, float * kernel_ms);
 /* batched prefill (many query tokens per sequence, causal): MFMA QK^T / PV */
 int pkv_attn_prefill(const pkv_attn_args * args, void * stream);
 

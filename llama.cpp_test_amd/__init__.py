@@ -192,6 +192,10 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
                  _ptr(seq_lens), _ptr(q_start), _ptr(slot_pos), _ptr(q_pos), _ptr(workspace), workspace.numel(),
                  n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
                  scale, logit_softcap, max_seq_len, flags)
+    if fn is lib().pkv_attn_decode_profiled:
+        ms = C.c_float()
+        check(fn(C.byref(a), C.c_void_p(_stream(stream)), C.byref(ms)))
+        return out, ms.value
     check(fn(C.byref(a), C.c_void_p(_stream(stream))))
     return out
 
@@ -209,6 +213,11 @@ def attn_decode(q, k_pool, v_pool, block_table, seq_lens, **kw):
     """Paged single-token decode: ggml_flash_attn_ext for one query per sequence
     (/root/reference/src/llama-graph.cpp:1187-1197).  q f32 [n_seq][n_head][D] -> out f32 [n_seq][n_head][D]."""
     return _attn(lib().pkv_attn_decode, q, k_pool, v_pool, block_table, seq_lens, **kw)
+
+
+def attn_decode_profiled(q, k_pool, v_pool, block_table, seq_lens, **kw):
+    """attn_decode that blocks and also returns the split-KV kernel's own GPU duration in milliseconds (measurement)"""
+    return _attn(lib().pkv_attn_decode_profiled, q, k_pool, v_pool, block_table, seq_lens, **kw)
 
 
 def attn_prefill(q, k_pool, v_pool, block_table, seq_lens, q_start, **kw):

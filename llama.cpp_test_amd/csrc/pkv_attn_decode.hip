@@ -19,6 +19,8 @@
 //   A second tiny kernel merges the per-block partials (flash-decoding).
 #include "pkv_common.h"
 
+#include <hip/hip_ext.h>
+
 namespace pkv {
 namespace {
 
@@ -526,18 +528,28 @@ __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
     o[d] = acc / Ls;  // all cells masked -> 0/0 = NaN, like the reference's 1/S with S == 0
 }
 
+// measurement hook (pkv_attn_decode_profiled): when set, the split-KV kernel is launched with start/stop events that
+// carry the dispatch's own GPU timestamps (what rocprofv3 --kernel-trace reports), not host-side event records
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
+template <typename K>
+void launch_kernel(K kernel, dim3 grid, dim3 block, hipStream_t st, const DecodeArgs & da) {
+    if (g_prof_start) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, g_prof_start, g_prof_stop, 0, da);
+    else              hipLaunchKernelGGL(kernel, grid, block, 0, st, da);
+}
+
 template <int KT, int VT, int D, int G>
 int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     dim3 grid(da.n_splits, da.n_head_kv, n_seq);
     const dim3 block(64 * Geo<KT, VT, D>::NW);
     const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr;
     if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
-        hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, false, true>), grid, block, 0, st, da);
+        launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true>, grid, block, st, da);
     } else {
-        if (!cap && !sp)      hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, false, false>), grid, block, 0, st, da);
-        else if (!cap && sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, false, true, false>), grid, block, 0, st, da);
-        else if (cap && !sp)  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, false, false>), grid, block, 0, st, da);
-        else                  hipLaunchKernelGGL((attn_decode_kernel<KT, VT, D, G, true, true, false>), grid, block, 0, st, da);
+        if (!cap && !sp)      launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false>, grid, block, st, da);
+        else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false>, grid, block, st, da);
+        else if (cap && !sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, false, false>, grid, block, st, da);
+        else                  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, true, false>, grid, block, st, da);
         if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
     }
     PKV_HIP(hipGetLastError());
@@ -582,6 +594,23 @@ int launch_v(const DecodeArgs & da, int VT, int D, int G, int n_seq, hipStream_t
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len) {
     const size_t ns = (size_t) (max_seq_len + WG_TOK - 1) / WG_TOK;
     return (size_t) n_tok * n_head * (ns ? ns : 1) * (D + 2) * sizeof(float) + (size_t) n_tok * n_head * sizeof(unsigned);
+}
+
+int launch_attn_decode_profiled(const pkv_attn_args & a, hipStream_t st, float * kernel_ms) {
+    hipEvent_t e0, e1;
+    PKV_HIP(hipEventCreate(&e0));
+    PKV_HIP(hipEventCreate(&e1));
+    g_prof_start = e0; g_prof_stop = e1;
+    const int rc = launch_attn_decode(a, st);
+    g_prof_start = g_prof_stop = nullptr;
+    if (rc == PKV_OK) {
+        PKV_HIP(hipEventSynchronize(e1));
+        PKV_HIP(hipStreamSynchronize(st));
+        PKV_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    }
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    return rc;
 }
 
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {

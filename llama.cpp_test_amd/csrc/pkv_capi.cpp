@@ -134,6 +134,12 @@ int pkv_attn_decode(const pkv_attn_args * args, void * stream) {
     return launch_attn_decode(*args, (hipStream_t) stream);
 }
 
+int pkv_attn_decode_profiled(const pkv_attn_args * args, void * stream, float * kernel_ms) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args != nullptr && kernel_ms != nullptr, "pkv_attn_decode_profiled: null argument");
+    return launch_attn_decode_profiled(*args, (hipStream_t) stream, kernel_ms);
+}
+
 int pkv_attn_prefill(const pkv_attn_args * args, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(args != nullptr, "pkv_attn_prefill: null args");
