@@ -112,15 +112,23 @@ def measure_dominant_kernel(w: Workload, torch, reps: int):
     pkv, g = w.pkv, w.g
     L = g["n_layer"]
     flags = w.step_flags if w.step_flags & pkv.ATTN_FUSED_COMBINE else 0
-    ms = []
-    for r in range(reps + 1):
-        for l in range(L):
-            _, t = pkv.attn_decode_profiled(w.q[l], w.k_pools[l], w.v_pools[l], w.block_table, w.seq_lens,
-                                            n_head_kv=g["n_head_kv"], type_k=w.tk, type_v=w.tv, block_size=g["block_size"],
-                                            scale=w.scale, max_seq_len=w.ctx, out=w.out[l], workspace=w.ws, flags=flags)
-            if r > 0:
-                ms.append(t)
-    ms = np.array(ms)
+    timer = pkv.KernelTimer(reps * L)
+
+    def launch(l, ev=None):
+        pkv.attn_decode(w.q[l], w.k_pools[l], w.v_pools[l], w.block_table, w.seq_lens, n_head_kv=g["n_head_kv"],
+                        type_k=w.tk, type_v=w.tv, block_size=g["block_size"], scale=w.scale, max_seq_len=w.ctx,
+                        out=w.out[l], workspace=w.ws, flags=flags, events=ev)
+    for l in range(L):
+        launch(l)
+    torch.cuda.synchronize()
+    # Python enqueues slower than the GPU drains; park the stream behind a spin kernel while the launches queue up so
+    # that they then execute back to back — the regime of the timed (graph-replayed) step — instead of from an idle GPU
+    torch.cuda._sleep(int(reps * L * 6e4) + 20_000_000)
+    for i in range(reps * L):
+        launch(i % L, timer.pair(i))
+    torch.cuda.synchronize()
+    ms = np.array(timer.elapsed_ms())
+    timer.close()
     return float(np.mean(ms)) * 1e-3, float(np.median(ms)) * 1e-3, float(np.min(ms)) * 1e-3
 
 
@@ -223,6 +231,11 @@ def main():
 
         k_mean, k_med, k_min = measure_dominant_kernel(w, torch, args.kernel_reps)
 
+    traffic = None
+    try:   # PMC traffic cannot be collected from inside the run: taken from the committed rocprofv3 passes, if this workload has one
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{args.kv_type}_ctx{args.ctx}_nseq{args.n_seq}")
+    except Exception:
+        pass
     tok_s = world * args.n_seq * args.steps / dt
     bytes_launch = args.n_seq * algorithmic_bytes(args.ctx, t, t, pkv)
     achieved = bytes_launch / k_mean / 1e9
@@ -237,7 +250,8 @@ def main():
                    "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "eager" if graph is None else "hipGraph", "merge": "in-kernel (last-arriving workgroup)" if args.fused_merge else "second launch",
                    "parallelism": f"replicas x{world} (no collective on the data path)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
                      "kernel": "pkv::attn_decode_kernel (split-KV paged decode, one launch per layer)",
                      "algorithmic_bytes_per_launch": bytes_launch,
                      "kernel_us": {"mean": round(k_mean * 1e6, 3), "median": round(k_med * 1e6, 3), "min": round(k_min * 1e6, 3)},

@@ -127,6 +127,9 @@ typedef struct pkv_attn_args {
     float   logit_softcap;        /* op_params[2]; 0 = off.  max_bias (ALiBi) != 0 is PKV_ERR_UNSUPPORTED       */
     int32_t max_seq_len;          /* upper bound of seq_lens[] known on the host (sizes the split-KV grid)      */
     int32_t flags;                /* PKV_ATTN_* bits                                                            */
+    void *  ev_start;             /* optional hipEvent_t pair bound to the split-KV decode launch itself          */
+    void *  ev_stop;              /* (hipExtLaunchKernel): elapsed = the dispatch's own GPU duration, as rocprofv3 */
+                                  /* --kernel-trace reports it.  NULL = plain launch.                              */
 } pkv_attn_args;
 
 /* leave the per-block (m, l, O) partials in `workspace` and skip the merge launch (measurement / callers that
@@ -142,10 +145,11 @@ size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq
 int    pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream);
 /* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks */
 int pkv_attn_decode(const pkv_attn_args * args, void * stream);
-/* measurement aid: same launch, but blocks until it is done and returns the duration of the split-KV decode kernel
- * alone, taken from the dispatch's own GPU start/stop timestamps (hipExtLaunchKernel events) — the quantity
- * rocprofv3 --kernel-trace reports.  Not for the serving path (it synchronises the stream). */
-int pkv_attn_decode_profiled(const pkv_attn_args * args, void * stream, float * kernel_ms);
+/* measurement aid: raw hipEvent_t handles for pkv_attn_args.ev_start / ev_stop */
+void * pkv_event_create(void);
+void   pkv_event_destroy(void * ev);
+int    pkv_event_synchronize(void * ev);
+int    pkv_event_elapsed_ms(void * ev_start, void * ev_stop, float * ms);
 /* batched prefill (many query tokens per sequence, causal): MFMA QK^T / PV */
 int pkv_attn_prefill(const pkv_attn_args * args, void * stream);
 

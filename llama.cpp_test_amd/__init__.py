@@ -56,7 +56,8 @@ class AttnArgs(C.Structure):
                 ("n_seq", C.c_int32), ("n_tok", C.c_int32), ("max_q_per_seq", C.c_int32), ("n_head", C.c_int32),
                 ("n_head_kv", C.c_int32), ("head_dim", C.c_int32), ("block_size", C.c_int32), ("max_blocks", C.c_int32),
                 ("type_k", C.c_int32), ("type_v", C.c_int32), ("scale", C.c_float), ("logit_softcap", C.c_float),
-                ("max_seq_len", C.c_int32), ("flags", C.c_int32)]
+                ("max_seq_len", C.c_int32), ("flags", C.c_int32),
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
 class CacheParams(C.Structure):
@@ -180,7 +181,7 @@ def attn_workspace_bytes(n_tok: int, n_head: int, head_dim: int, max_seq_len: in
 
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
-          stream=None, flags=0):
+          stream=None, flags=0, events=None):
     import torch
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
@@ -191,11 +192,7 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
     a = AttnArgs(_ptr(q), q.stride(0), q.stride(1), _ptr(out), _ptr(k_pool), _ptr(v_pool), _ptr(block_table),
                  _ptr(seq_lens), _ptr(q_start), _ptr(slot_pos), _ptr(q_pos), _ptr(workspace), workspace.numel(),
                  n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
-                 scale, logit_softcap, max_seq_len, flags)
-    if fn is lib().pkv_attn_decode_profiled:
-        ms = C.c_float()
-        check(fn(C.byref(a), C.c_void_p(_stream(stream)), C.byref(ms)))
-        return out, ms.value
+                 scale, logit_softcap, max_seq_len, flags, events[0] if events else None, events[1] if events else None)
     check(fn(C.byref(a), C.c_void_p(_stream(stream))))
     return out
 
@@ -215,9 +212,34 @@ def attn_decode(q, k_pool, v_pool, block_table, seq_lens, **kw):
     return _attn(lib().pkv_attn_decode, q, k_pool, v_pool, block_table, seq_lens, **kw)
 
 
-def attn_decode_profiled(q, k_pool, v_pool, block_table, seq_lens, **kw):
-    """attn_decode that blocks and also returns the split-KV kernel's own GPU duration in milliseconds (measurement)"""
-    return _attn(lib().pkv_attn_decode_profiled, q, k_pool, v_pool, block_table, seq_lens, **kw)
+class KernelTimer:
+    """pairs of raw hipEvent_t that `attn_decode(..., events=timer.pair(i))` binds to the decode launch itself"""
+
+    def __init__(self, n: int):
+        L = lib()
+        L.pkv_event_create.restype = C.c_void_p
+        L.pkv_event_destroy.restype = None
+        self.ev = [(L.pkv_event_create(), L.pkv_event_create()) for _ in range(n)]
+        if any(a is None or b is None for a, b in self.ev):
+            raise PkvError(ERR_NO_DEVICE, "cannot create HIP events")
+
+    def pair(self, i):
+        return self.ev[i]
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.ev:
+            check(lib().pkv_event_synchronize(C.c_void_p(b)))
+            ms = C.c_float()
+            check(lib().pkv_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b), C.byref(ms)))
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        for a, b in self.ev:
+            lib().pkv_event_destroy(C.c_void_p(a))
+            lib().pkv_event_destroy(C.c_void_p(b))
+        self.ev = []
 
 
 def attn_prefill(q, k_pool, v_pool, block_table, seq_lens, q_start, **kw):

@@ -596,23 +596,6 @@ size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len) {
     return (size_t) n_tok * n_head * (ns ? ns : 1) * (D + 2) * sizeof(float) + (size_t) n_tok * n_head * sizeof(unsigned);
 }
 
-int launch_attn_decode_profiled(const pkv_attn_args & a, hipStream_t st, float * kernel_ms) {
-    hipEvent_t e0, e1;
-    PKV_HIP(hipEventCreate(&e0));
-    PKV_HIP(hipEventCreate(&e1));
-    g_prof_start = e0; g_prof_stop = e1;
-    const int rc = launch_attn_decode(a, st);
-    g_prof_start = g_prof_stop = nullptr;
-    if (rc == PKV_OK) {
-        PKV_HIP(hipEventSynchronize(e1));
-        PKV_HIP(hipStreamSynchronize(st));
-        PKV_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
-    }
-    (void) hipEventDestroy(e0);
-    (void) hipEventDestroy(e1);
-    return rc;
-}
-
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.q && (a.out || (a.flags & PKV_ATTN_NO_COMBINE)) && a.k_pool && a.v_pool && a.block_table && a.seq_lens, "pkv_attn_decode: null pointer");
     PKV_REQUIRE(a.q_start == nullptr && a.n_tok == a.n_seq, "pkv_attn_decode: one query token per sequence (use pkv_attn_prefill)");
@@ -624,6 +607,12 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.slot_pos == nullptr || a.q_pos != nullptr, "pkv_attn_decode: slot_pos needs q_pos");
     const size_t need = decode_workspace_bytes(a.n_tok, a.n_head, a.head_dim, a.max_seq_len);
     PKV_REQUIRE(a.workspace && a.workspace_bytes >= need, "pkv_attn_decode: workspace too small (%zu < %zu)", a.workspace_bytes, need);
+
+    // measurement hook: events bound to the split-KV launch itself (see pkv_attn_args.ev_start)
+    struct ProfScope {
+        ProfScope(void * e0, void * e1) { g_prof_start = (hipEvent_t) e0; g_prof_stop = (hipEvent_t) e1; }
+        ~ProfScope() { g_prof_start = g_prof_stop = nullptr; }
+    } prof_scope(a.ev_start && a.ev_stop ? a.ev_start : nullptr, a.ev_start && a.ev_stop ? a.ev_stop : nullptr);
 
     DecodeArgs da;
     da.q = a.q; da.q_stride_tok = a.q_stride_tok; da.q_stride_head = a.q_stride_head;

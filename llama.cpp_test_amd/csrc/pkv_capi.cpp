@@ -134,10 +134,18 @@ int pkv_attn_decode(const pkv_attn_args * args, void * stream) {
     return launch_attn_decode(*args, (hipStream_t) stream);
 }
 
-int pkv_attn_decode_profiled(const pkv_attn_args * args, void * stream, float * kernel_ms) {
-    if (int rc = ensure_device()) return rc;
-    PKV_REQUIRE(args != nullptr && kernel_ms != nullptr, "pkv_attn_decode_profiled: null argument");
-    return launch_attn_decode_profiled(*args, (hipStream_t) stream, kernel_ms);
+// raw hipEvent_t helpers for callers without a HIP binding (bench.py measures the decode kernel with them)
+void * pkv_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (ensure_device() != PKV_OK || hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void pkv_event_destroy(void * e) { if (e) (void) hipEventDestroy((hipEvent_t) e); }
+int  pkv_event_synchronize(void * e) { PKV_HIP(hipEventSynchronize((hipEvent_t) e)); return PKV_OK; }
+int  pkv_event_elapsed_ms(void * start, void * stop, float * ms) {
+    PKV_REQUIRE(start && stop && ms, "pkv_event_elapsed_ms: null argument");
+    PKV_HIP(hipEventElapsedTime(ms, (hipEvent_t) start, (hipEvent_t) stop));
+    return PKV_OK;
 }
 
 int pkv_attn_prefill(const pkv_attn_args * args, void * stream) {

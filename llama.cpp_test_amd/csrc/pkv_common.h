@@ -57,7 +57,6 @@ int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * 
                     int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
                     const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st);
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st);
-int launch_attn_decode_profiled(const pkv_attn_args & a, hipStream_t st, float * kernel_ms);
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);

@@ -1,0 +1,78 @@
+"""N > 1 without GPUs: the replica launcher logic of bench.py on 2 gloo ranks (CPU).
+
+The path shards by sequence (one block pool + one block manager per GPU, no exchange step), so what has to be right
+for N > 1 is (a) the partition of sequences over ranks, (b) independent per-rank block managers, and (c) the
+barrier / max-over-ranks timing and whole-job aggregation bench.py prints."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_seqs, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _load_pkg
+    pkv = _load_pkg.load()
+    mine = [s for s in range(n_seqs) if s % world == rank]             # sequence s -> GPU s mod N
+    c = pkv.PagedKVCache(n_blocks=64, block_size=128, n_seq_max=len(mine), n_layer=0)
+    tabs = {}
+    for i, s in enumerate(mine):                                       # prefill 300 + s tokens, then 5 decode steps
+        n = 300 + s
+        c.find_slot([i] * n, list(range(n)))
+    for step in range(5):
+        c.find_slot(list(range(len(mine))), [300 + s + step for s in mine])
+    for i, s in enumerate(mine):
+        tabs[s] = (c.seq_blocks(i).tolist(), c.seq_len(i))
+    # timing protocol of bench.py: barrier, local time, MAX over ranks, whole-job aggregate
+    dist.barrier()
+    local_dt = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(local_dt, op=dist.ReduceOp.MAX)
+    tok = torch.tensor([len(mine) * 5], dtype=torch.float64)
+    dist.all_reduce(tok, op=dist.ReduceOp.SUM)
+    q.put((rank, tabs, float(local_dt.item()), float(tok.item()), c.get_n_tokens()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_replicas():
+    world, n_seqs = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_seqs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = {}
+    for rank, tabs, dt, tok, n_tok in res:
+        assert dt == pytest.approx(0.020)          # max over ranks
+        assert tok == n_seqs * 5                    # whole-job aggregate
+        assert n_tok == sum(300 + s + 5 for s in tabs)
+        for s, (blocks, ln) in tabs.items():
+            assert s % world == rank and ln == 300 + s + 5
+            assert len(blocks) == -(-ln // 128) and len(set(blocks)) == len(blocks)
+            seen[s] = blocks
+        # pools are per rank: block ids only need to be unique inside a rank
+        flat = [b for blocks, _ in tabs.values() for b in blocks]
+        assert len(flat) == len(set(flat))
+    assert sorted(seen) == list(range(n_seqs))
