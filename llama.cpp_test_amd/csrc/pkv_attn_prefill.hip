@@ -1,12 +1,311 @@
-// pkv_attn_prefill.hip — batched-prefill paged attention (flash-style, MFMA).  Placeholder until the MFMA kernel lands.
+// pkv_attn_prefill.hip — batched-prefill paged attention for gfx950: flash-style, MFMA (v_mfma_f32_32x32x16_f16).
+//
+// Replaces, for many query tokens per sequence, the K/V gather views + GGML_OP_FLASH_ATTN_EXT + dense causal KQ_mask
+// of the reference (/ref/src/llama-graph.cpp:1404-1432, :403-468; CPU kernel /ref/ggml/src/ggml-cpu/ggml-cpu.c:12219).
+//
+// Decomposition: one workgroup per (sequence, kv head, 32-query tile); wave g of the workgroup owns query head
+// hk*G + g, so the K/V tile staged in LDS is read from HBM once for all G = n_head/n_head_kv query heads.
+// Per 64-token KV tile (half a 128-token block — tiles never straddle blocks, the block table is consulted per tile):
+//   S^T[kv][q] = K[kv][:] . Q^T       A = K rows from LDS (XOR-swizzled 16-B chunks, conflict-free ds_read_b128),
+//                                     B = Q^T fragments held in registers for the whole kernel;
+//                                     the accumulator has the QUERY on the lane, so the online-softmax state (m, l)
+//                                     is per lane and the row max/sum needs one cross-half exchange only
+//   O^T[d][q] += V^T[d][kv] . P^T     B = P^T straight from the S^T accumulators (cdna_hip_programming.md §3
+//                                     "An accumulator tile as the next MFMA's operand", permuted k order),
+//                                     A = V^T from the token-pair-interleaved V tile ([pair][d] dwords: the two halves of
+//                                     a dword are two consecutive tokens of one d -> conflict-free ds_read_b32)
+// Causal structure replaces the mask: KV tiles past the tile's last query position are never visited; the diagonal tile
+// masks per element.  Quantized K/V (q8_0, q4_0) are dequantized to f16 while staging (Q stays f16: closer to exact
+// arithmetic than the reference's q8_0-quantized Q; tolerance in tests/test_gpu_prefill.py).
 #include "pkv_common.h"
 
 namespace pkv {
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int QT  = 32;  // query rows per workgroup tile (one MFMA N dimension)
+constexpr int KVT = 64;  // KV tokens per LDS tile
+
+struct PrefillArgs {
+    const float *   q;
+    int64_t         q_stride_tok, q_stride_head;
+    float *         out;
+    const char *    k_pool;
+    const char *    v_pool;
+    const int32_t * block_table;
+    const int32_t * seq_lens;
+    const int32_t * q_start;
+    int   n_head, n_head_kv, block_size, max_blocks;
+    float scale, softcap;
+};
+
+__device__ __forceinline__ int crow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }  // C/D row of register i
+
+// stage one 64-token K tile into LDS as f16 rows of D halfs, 16-byte chunk c of row r stored at chunk c ^ (r & 15)
+template <int KT, int D, int NT>
+__device__ __forceinline__ void stage_k(char * lds, const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
+    constexpr int CPR = D / 8;  // 16-byte chunks per f16 row
+    for (int c = tid; c < KVT * CPR; c += NT) {
+        const int r = c / CPR, cc = c % CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < n_rows_valid) {
+            const int row = row0 + r;
+            if constexpr (KT == PKV_TYPE_F16) {
+                v = *reinterpret_cast<const uint4 *>(tile + ((size_t) row * D + cc * 8) * 2);
+            } else {
+                const float d = (float) *reinterpret_cast<const _Float16 *>(
+                    tile + tile_quant_bytes(KT, block_size, D) + ((size_t) row * (D / PKV_QK) + cc * 8 / PKV_QK) * 2);
+                _Float16 o[8];
+                if constexpr (KT == PKV_TYPE_Q8_0) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(tile + (size_t) row * D + cc * 8);
+                    const uint32_t ww[2] = {w.x, w.y};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) (int) (signed char) (ww[j >> 2] >> (8 * (j & 3))) * d);
+                } else {  // q4_0: byte j of the 32-block = elem j | elem j+16 << 4
+                    const int blk = cc * 8 / PKV_QK, e0 = cc * 8 % PKV_QK;  // elements e0..e0+7 of the block
+                    const uint2 w = *reinterpret_cast<const uint2 *>(tile + (size_t) row * (D / 2) + blk * 16 + (e0 & 15));
+                    const uint32_t ww[2] = {w.x, w.y};
+                    const int sh = e0 < 16 ? 0 : 4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) ((int) ((ww[j >> 2] >> (8 * (j & 3) + sh)) & 0xF) - 8) * d);
+                }
+                v = *reinterpret_cast<const uint4 *>(o);
+            }
+        }
+        *reinterpret_cast<uint4 *>(lds + (size_t) r * D * 2 + ((cc ^ (r & 15)) & (CPR - 1)) * 16) = v;
+    }
+}
+
+// stage one 64-token V tile into LDS as [32 token pairs][D] dwords (half2 = tokens 2p, 2p+1 of one d)
+template <int VT, int D, int NT>
+__device__ __forceinline__ void stage_v(char * lds, const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
+    constexpr int CPP = D / 4;  // 16-byte chunks per pair row (D dwords)
+    for (int c = tid; c < (KVT / 2) * CPP; c += NT) {
+        const int p = c / CPP, cc = c % CPP;  // pair inside the tile, chunk = 4 consecutive d
+        const int t0 = 2 * p;                 // first token of the pair inside the tile
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t0 < n_rows_valid) {
+            const int row = row0 + t0;
+            if constexpr (VT == PKV_TYPE_F16) {
+                v = *reinterpret_cast<const uint4 *>(tile + ((size_t) (row / 2) * D + cc * 4) * 4);
+            } else {
+                constexpr int TL = VT == PKV_TYPE_Q8_0 ? 4 : 8;
+                const int grp = row / TL, tl = row % TL;  // tokens tl, tl+1 of the group (row is even)
+                const uint4 w = *reinterpret_cast<const uint4 *>(tile + ((size_t) grp * D + cc * 4) * 4);
+                const _Float16 * sp = reinterpret_cast<const _Float16 *>(
+                    tile + tile_quant_bytes(VT, block_size, D) + ((size_t) grp * (D / PKV_QK) + cc * 4 / PKV_QK) * TL * 2);
+                const float d0 = (float) sp[tl], d1 = (float) sp[tl + 1];
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a, b;
+                    if constexpr (VT == PKV_TYPE_Q8_0) {
+                        a = (float) (int) (signed char) (ww[j] >> (8 * tl)) * d0;
+                        b = (float) (int) (signed char) (ww[j] >> (8 * (tl + 1))) * d1;
+                    } else {
+                        a = (float) ((int) ((ww[j] >> (4 * tl)) & 0xF) - 8) * d0;
+                        b = (float) ((int) ((ww[j] >> (4 * (tl + 1))) & 0xF) - 8) * d1;
+                    }
+                    const _Float16 ha = (_Float16) a, hb = (_Float16) b;
+                    o[j] = (uint32_t) *reinterpret_cast<const uint16_t *>(&ha) | ((uint32_t) *reinterpret_cast<const uint16_t *>(&hb) << 16);
+                }
+                v = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            if (t0 + 1 >= n_rows_valid) {  // the pair's second token is past the end of the sequence
+                v.x &= 0xFFFFu; v.y &= 0xFFFFu; v.z &= 0xFFFFu; v.w &= 0xFFFFu;
+            }
+        }
+        *reinterpret_cast<uint4 *>(lds + ((size_t) p * D + cc * 4) * 4) = v;
+    }
+}
+
+template <int KT, int VT, int D, int G>
+__global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs a) {
+    constexpr int NT = 64 * G, KS = D / 16, DT = D / 32;  // k-steps of QK^T, 32-row d tiles of O^T
+    __shared__ __attribute__((aligned(16))) char sK[KVT * D * 2];
+    __shared__ __attribute__((aligned(16))) char sV[KVT * D * 2];
+
+    const int tile = blockIdx.x, hk = blockIdx.y, s = blockIdx.z;
+    const int tok0 = a.q_start[s], n_q = a.q_start[s + 1] - tok0;
+    if (tile * QT >= n_q) return;
+    const int seq_len = a.seq_lens[s];
+    const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int head = hk * G + g;
+    const int jr = tile * QT + r;            // this lane's query inside the sequence's new tokens
+    const bool q_ok = jr < n_q;
+    const int qpos = seq_len - n_q + jr;     // position = index of the last KV cell it sees
+    const int kv_end = min(seq_len, seq_len - n_q + tile * QT + QT);  // workgroup-uniform bound
+
+    // ---- Q^T fragments, rounded to f16 (GGML_FP32_TO_FP16 of the reference's q_to_vec_dot for f16 K) ---------------
+    half8_t qf[KS];
+    {
+        const float * qp = a.q + (size_t) (tok0 + (q_ok ? jr : 0)) * a.q_stride_tok + (size_t) head * a.q_stride_head;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float4 x0 = make_float4(0, 0, 0, 0), x1 = x0;
+            if (q_ok) {
+                x0 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8);
+                x1 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8 + 4);
+            }
+            qf[ks] = half8_t{(_Float16) x0.x, (_Float16) x0.y, (_Float16) x0.z, (_Float16) x0.w,
+                             (_Float16) x1.x, (_Float16) x1.y, (_Float16) x1.z, (_Float16) x1.w};
+        }
+    }
+
+    floatx16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+
+    const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
+    for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
+        const int phys = a.block_table[(size_t) s * a.max_blocks + kv0 / a.block_size];
+        const int row0 = kv0 % a.block_size;
+        const int nval = min(KVT, seq_len - kv0);
+        __syncthreads();  // previous tile fully consumed
+        stage_k<KT, D, NT>(sK, a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k, row0, nval, a.block_size, tid);
+        stage_v<VT, D, NT>(sV, a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v, row0, nval, a.block_size, tid);
+        __syncthreads();
+
+        // ---- S^T = K . Q^T : two 32-row kv tiles ---------------------------------------------------------------
+        floatx16 sacc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[mt][i] = 0.0f;
+            const int row = mt * 32 + r;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8_t kf = *reinterpret_cast<const half8_t *>(sK + (size_t) row * D * 2 + (((2 * ks + h) ^ (row & 15)) & (D / 8 - 1)) * 16);
+                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mt], 0, 0, 0);
+            }
+        }
+        // ---- scale, causal mask, online softmax (query on the lane) ------------------------------------------------
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sacc[mt][i] * a.scale;
+                if (a.softcap != 0.0f) v = a.softcap * tanhf(v);
+                const int kv = kv0 + mt * 32 + crow(i, h);
+                v = kv <= qpos ? v : -INFINITY;
+                sacc[mt][i] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = m_new == -INFINITY ? 1.0f : __expf(m - m_new);
+        m = m_new;
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        // ---- O^T += V^T . P^T ------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8_t pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = m == -INFINITY ? 0.0f : __expf(sacc[mt][8 * s2 + j] - m);
+                    pf[j] = (_Float16) p;
+                    l += (float) pf[j];   // the weight PV really applies
+                }
+                const int p0 = mt * 16 + 8 * s2 + 2 * h;  // token pairs p0, p0+1, p0+4, p0+5 = this half's k order
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const uint32_t * vb = reinterpret_cast<const uint32_t *>(sV) + dt * 32 + r;
+                    uint32_t w[4] = {vb[(size_t) p0 * D], vb[(size_t) (p0 + 1) * D], vb[(size_t) (p0 + 4) * D], vb[(size_t) (p0 + 5) * D]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(w), pf, o[dt], 0, 0, 0);
+                }
+            }
+    }
+    // ---- normalise and write out[tok][head][d] -----------------------------------------------------------------------------
+    l += __shfl_xor(l, 32);
+    if (q_ok) {
+        const float inv = 1.0f / l;
+        float * op = a.out + ((size_t) (tok0 + jr) * a.n_head + head) * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                const int d = dt * 32 + crow(i, h);  // registers i..i+3 are 4 consecutive rows (d)
+                *reinterpret_cast<float4 *>(op + d) = make_float4(o[dt][i] * inv, o[dt][i + 1] * inv, o[dt][i + 2] * inv, o[dt][i + 3] * inv);
+            }
+    }
+}
+
+template <int KT, int VT, int D, int G>
+int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
+    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+template <int KT, int VT, int D>
+int launch_g(const PrefillArgs & pa, int G, int n_tiles, int n_seq, hipStream_t st) {
+    switch (G) {
+        case 1: return launch_one<KT, VT, D, 1>(pa, n_tiles, n_seq, st);
+        case 2: return launch_one<KT, VT, D, 2>(pa, n_tiles, n_seq, st);
+        case 4: return launch_one<KT, VT, D, 4>(pa, n_tiles, n_seq, st);
+        case 8: return launch_one<KT, VT, D, 8>(pa, n_tiles, n_seq, st);
+    }
+    set_error("pkv_attn_prefill: unsupported gqa ratio %d (supported 1,2,4,8)", G);
+    return PKV_ERR_UNSUPPORTED;
+}
+template <int KT, int VT>
+int launch_d(const PrefillArgs & pa, int D, int G, int n_tiles, int n_seq, hipStream_t st) {
+    switch (D) {
+        case 64:  return launch_g<KT, VT, 64>(pa, G, n_tiles, n_seq, st);
+        case 128: return launch_g<KT, VT, 128>(pa, G, n_tiles, n_seq, st);
+    }
+    set_error("pkv_attn_prefill: unsupported head_dim %d (supported 64,128)", D);
+    return PKV_ERR_UNSUPPORTED;
+}
+template <int KT>
+int launch_v(const PrefillArgs & pa, int VT, int D, int G, int n_tiles, int n_seq, hipStream_t st) {
+    switch (VT) {
+        case PKV_TYPE_F16:  return launch_d<KT, PKV_TYPE_F16>(pa, D, G, n_tiles, n_seq, st);
+        case PKV_TYPE_Q8_0: return launch_d<KT, PKV_TYPE_Q8_0>(pa, D, G, n_tiles, n_seq, st);
+        case PKV_TYPE_Q4_0: return launch_d<KT, PKV_TYPE_Q4_0>(pa, D, G, n_tiles, n_seq, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
+}  // namespace
 
 size_t prefill_workspace_bytes(int, int, int) { return 0; }
 
-int launch_attn_prefill(const pkv_attn_args &, hipStream_t) {
-    set_error("pkv_attn_prefill: not built yet");
+int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
+    PKV_REQUIRE(a.q && a.out && a.k_pool && a.v_pool && a.block_table && a.seq_lens && a.q_start, "pkv_attn_prefill: null pointer");
+    PKV_REQUIRE(a.n_seq > 0 && a.n_tok > 0 && a.max_q_per_seq > 0, "pkv_attn_prefill: bad token counts");
+    PKV_REQUIRE(a.n_head > 0 && a.n_head_kv > 0 && a.n_head % a.n_head_kv == 0, "pkv_attn_prefill: bad head counts");
+    PKV_REQUIRE(a.block_size >= KVT && a.block_size % KVT == 0, "pkv_attn_prefill: block_size must be a multiple of %d", KVT);
+    PKV_REQUIRE(kv_type_ok(a.type_k) && kv_type_ok(a.type_v), "pkv_attn_prefill: KV types must be f16/q8_0/q4_0");
+    PKV_REQUIRE(a.max_seq_len > 0 && a.max_seq_len <= a.max_blocks * a.block_size, "pkv_attn_prefill: max_seq_len out of range");
+    PKV_REQUIRE((a.q_stride_head % 4) == 0 && (a.q_stride_tok % 4) == 0 && ((uintptr_t) a.q % 16) == 0 && ((uintptr_t) a.out % 16) == 0,
+                "pkv_attn_prefill: q/out must be 16-byte aligned");
+    if (a.slot_pos) { set_error("pkv_attn_prefill: irregular sequences (slot_pos) are not supported yet; defrag first"); return PKV_ERR_UNSUPPORTED; }
+    PrefillArgs pa;
+    pa.q = a.q; pa.q_stride_tok = a.q_stride_tok; pa.q_stride_head = a.q_stride_head; pa.out = a.out;
+    pa.k_pool = (const char *) a.k_pool; pa.v_pool = (const char *) a.v_pool;
+    pa.block_table = a.block_table; pa.seq_lens = a.seq_lens; pa.q_start = a.q_start;
+    pa.n_head = a.n_head; pa.n_head_kv = a.n_head_kv; pa.block_size = a.block_size; pa.max_blocks = a.max_blocks;
+    pa.softcap = a.logit_softcap;
+    pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
+    const int n_tiles = (a.max_q_per_seq + QT - 1) / QT, G = a.n_head / a.n_head_kv;
+    switch (a.type_k) {
+        case PKV_TYPE_F16:  return launch_v<PKV_TYPE_F16>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);
+        case PKV_TYPE_Q8_0: return launch_v<PKV_TYPE_Q8_0>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);
+        case PKV_TYPE_Q4_0: return launch_v<PKV_TYPE_Q4_0>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);
+    }
     return PKV_ERR_UNSUPPORTED;
 }
 

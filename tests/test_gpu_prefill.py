@@ -1,0 +1,118 @@
+"""-m gpu: batched-prefill paged attention (MFMA, through the C ABI) against the CPU oracle.
+
+Bar: f16 KV — max-abs <= 1e-3 and NMSE <= 5e-4 vs the reference semantics (tests/test-backend-ops.cpp:3216), and at
+least as close to exact (f64) arithmetic as the reference is.  Quantized KV: the kernel keeps Q in f16 where the
+reference quantizes Q to q8_0 (ggml-cpu.c:12343), so it is compared with NMSE <= 5e-4 against the reference semantics
+and must be closer to the f64 result than the reference is."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, make_paged_case, nmse
+
+pytestmark = pytest.mark.gpu
+
+
+def run_prefill(pkv, O, rng, *, lens, n_qs, D, nh, nkv, tk, tv, softcap=0.0):
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tv)
+    q_start = np.concatenate([[0], np.cumsum(n_qs)]).astype(np.int32)
+    n_tok = int(q_start[-1])
+    q = rng.uniform(-1, 1, (n_tok, nh, D)).astype(np.float32)
+    out = pkv.attn_prefill(dev(q), dev(kp), dev(vp), dev(bt), dev(sl), dev(q_start), n_head_kv=nkv, type_k=tk, type_v=tv,
+                           block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()), max_q_per_seq=int(max(n_qs)),
+                           logit_softcap=softcap)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    refs, exacts = [], []
+    for s, (n, nq) in enumerate(zip(lens, n_qs)):
+        kc = O.pool_gather(kp, tk, 0, bt[s], n, D=D, block_size=128)
+        vc = O.pool_gather(vp, tv, 1, bt[s], n, D=D, block_size=128)
+        qs = q[q_start[s]:q_start[s + 1]].transpose(1, 0, 2)               # [n_head][n_q][D]
+        mask = np.zeros((nq, n), np.float16)
+        for j in range(nq):
+            mask[j, n - nq + j + 1:] = -np.inf
+        refs.append(O.flash_attn_ext(qs, kc, vc, mask, type_k=tk, type_v=tv, scale=D ** -0.5, softcap=softcap, n_threads=8))
+        exacts.append(O.flash_attn_f64(qs, kc, vc, mask, type_k=tk, type_v=tv, scale=D ** -0.5, softcap=softcap))
+    return got, np.concatenate(refs), np.concatenate(exacts)
+
+
+@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (128, 8, 1), (128, 4, 4), (64, 32, 4), (128, 4, 2)])
+def test_prefill_f16_matches_oracle(pkv, O, D, nh, nkv):
+    rng = np.random.default_rng(D + nh + nkv)
+    lens = [1, 31, 32, 33, 100, 128, 129, 300, 512]          # whole prompt in one ubatch: n_q == seq_len
+    got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=lens, D=D, nh=nh, nkv=nkv, tk=1, tv=1)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-3
+    assert nmse(got, ref) <= 5e-4
+    assert np.abs(got - exact).max() <= max(2.0 * np.abs(ref - exact).max(), 2e-4)
+
+
+def test_prefill_chunked_with_past(pkv, O):
+    """second ubatch of a long prompt: n_q new tokens attend to seq_len - n_q cached ones plus themselves (causal)"""
+    rng = np.random.default_rng(2)
+    lens, n_qs = [600, 257, 1000, 64], [88, 1, 512, 33]
+    got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=n_qs, D=128, nh=8, nkv=2, tk=1, tv=1)
+    assert np.abs(got - ref).max() <= 1e-3 and nmse(got, ref) <= 5e-4
+    assert np.abs(got - exact).max() <= max(2.0 * np.abs(ref - exact).max(), 2e-4)
+
+
+@pytest.mark.parametrize("tk,tv", [(8, 8), (2, 2), (8, 1), (1, 8)])
+def test_prefill_quantized_kv(pkv, O, tk, tv):
+    rng = np.random.default_rng(10 * tk + tv)
+    lens, n_qs = [200, 129, 64, 512], [200, 40, 64, 130]
+    got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=n_qs, D=128, nh=8, nkv=2, tk=tk, tv=tv)
+    assert np.isfinite(got).all()
+    assert nmse(got, ref) <= 5e-4
+    assert np.abs(got - ref).max() <= 3e-3                   # Q is f16 here, q8_0-quantized in the reference
+    assert np.abs(got - exact).max() <= np.abs(ref - exact).max() + 1e-4   # ... which makes us the closer one to exact
+
+
+def test_prefill_equals_decode_for_single_query(pkv, O):
+    """n_q == 1 per sequence: the MFMA prefill path and the split-KV decode path must agree"""
+    rng = np.random.default_rng(8)
+    lens = [300, 129, 640]
+    D, nh, nkv = 128, 32, 8
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=1, type_v=1)
+    q = rng.uniform(-1, 1, (3, nh, D)).astype(np.float32)
+    a = pkv.attn_prefill(dev(q), dev(kp), dev(vp), dev(bt), dev(sl), dev(np.arange(4, dtype=np.int32)), n_head_kv=nkv, type_k=1,
+                         type_v=1, block_size=128, scale=D ** -0.5, max_seq_len=640, max_q_per_seq=1)
+    b = pkv.attn_decode(dev(q), dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=nkv, type_k=1, type_v=1, block_size=128,
+                        scale=D ** -0.5, max_seq_len=640)
+    torch.cuda.synchronize()
+    assert np.abs(a.cpu().numpy() - b.cpu().numpy()).max() <= 2e-4
+
+
+def test_prefill_pp512_properties(pkv, O):
+    """BASELINE config 3 prompt shape (pp512, 8B geometry): causality — perturbing the K/V of position p only changes
+    query rows >= p — and block-permutation invariance, without running the CPU on the full size"""
+    rng = np.random.default_rng(5)
+    D, nh, nkv, n = 128, 32, 8, 512
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=[n], D=D, n_head=nh, n_head_kv=nkv, type_k=1, type_v=1, spare_blocks=4)
+    q = rng.uniform(-1, 1, (n, nh, D)).astype(np.float32)
+    qs = dev(np.array([0, n], np.int32))
+
+    def run(kpool, vpool, table):
+        o = pkv.attn_prefill(dev(q), dev(kpool), dev(vpool), dev(table), dev(sl), qs, n_head_kv=nkv, type_k=1, type_v=1,
+                             block_size=128, scale=D ** -0.5, max_seq_len=n, max_q_per_seq=n)
+        torch.cuda.synchronize()
+        return o.cpu().numpy()
+    base = run(kp, vp, bt)
+    perm = rng.permutation(kp.shape[0]).astype(np.int32)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    assert np.array_equal(base, run(kp[perm], vp[perm], inv[bt]))
+    p = 300
+    kp2 = kp.copy()
+    rows = O.from_float(1, rng.uniform(-1, 1, (1, nkv, D)).astype(np.float32))
+    O.pool_store(kp2, 1, 0, rows, bt[0][[p // 128]], np.array([p % 128], np.int32), D=D, block_size=128)
+    pert = run(kp2, vp, bt)
+    assert np.array_equal(pert[:p], base[:p])
+    assert np.abs(pert[p:] - base[p:]).max() > 0
+    # a handful of rows against the oracle
+    kc = O.pool_gather(kp, 1, 0, bt[0], n, D=D, block_size=128)
+    vc = O.pool_gather(vp, 1, 1, bt[0], n, D=D, block_size=128)
+    for j in (0, 31, 32, 255, 511):
+        mask = np.zeros((1, n), np.float16)
+        mask[0, j + 1:] = -np.inf
+        ref = O.flash_attn_ext(q[j][:, None, :], kc, vc, mask, type_k=1, type_v=1, scale=D ** -0.5)[0]
+        assert np.abs(base[j] - ref).max() <= 1e-3
