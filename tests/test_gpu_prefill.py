@@ -1,7 +1,8 @@
 """-m gpu: batched-prefill paged attention (MFMA, through the C ABI) against the CPU oracle.
 
-Bar: f16 KV — max-abs <= 1e-3 and NMSE <= 5e-4 vs the reference semantics (tests/test-backend-ops.cpp:3216), and at
-least as close to exact (f64) arithmetic as the reference is.  Quantized KV: the kernel keeps Q in f16 where the
+Bar: f16 KV — NMSE <= 5e-4 vs the reference semantics (tests/test-backend-ops.cpp:3216); max-abs distance to the
+reference no larger than the reference's own distance to exact (f64) arithmetic + 3e-4 (the reference accumulates f16-V
+in f16: on short rows with O(1) outputs its own error reaches 1e-3), and at least as close to exact as the reference.  Quantized KV: the kernel keeps Q in f16 where the
 reference quantizes Q to q8_0 (ggml-cpu.c:12343), so it is compared with NMSE <= 5e-4 against the reference semantics
 and must be closer to the f64 result than the reference is."""
 import numpy as np
@@ -42,9 +43,10 @@ def test_prefill_f16_matches_oracle(pkv, O, D, nh, nkv):
     lens = [1, 31, 32, 33, 100, 128, 129, 300, 512]          # whole prompt in one ubatch: n_q == seq_len
     got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=lens, D=D, nh=nh, nkv=nkv, tk=1, tv=1)
     assert np.isfinite(got).all()
-    assert np.abs(got - ref).max() <= 1e-3
+    ref_err = np.abs(ref - exact).max()
+    assert np.abs(got - ref).max() <= ref_err + 3e-4
     assert nmse(got, ref) <= 5e-4
-    assert np.abs(got - exact).max() <= max(2.0 * np.abs(ref - exact).max(), 2e-4)
+    assert np.abs(got - exact).max() <= max(ref_err, 2e-4)    # never further from exact than the reference is
 
 
 def test_prefill_chunked_with_past(pkv, O):
@@ -52,8 +54,9 @@ def test_prefill_chunked_with_past(pkv, O):
     rng = np.random.default_rng(2)
     lens, n_qs = [600, 257, 1000, 64], [88, 1, 512, 33]
     got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=n_qs, D=128, nh=8, nkv=2, tk=1, tv=1)
-    assert np.abs(got - ref).max() <= 1e-3 and nmse(got, ref) <= 5e-4
-    assert np.abs(got - exact).max() <= max(2.0 * np.abs(ref - exact).max(), 2e-4)
+    ref_err = np.abs(ref - exact).max()
+    assert np.abs(got - ref).max() <= ref_err + 3e-4 and nmse(got, ref) <= 5e-4
+    assert np.abs(got - exact).max() <= max(ref_err, 2e-4)
 
 
 @pytest.mark.parametrize("tk,tv", [(8, 8), (2, 2), (8, 1), (1, 8)])
