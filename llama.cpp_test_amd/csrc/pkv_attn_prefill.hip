@@ -43,86 +43,113 @@ struct PrefillArgs {
 
 __device__ __forceinline__ int crow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }  // C/D row of register i
 
-// stage one 64-token K tile into LDS as f16 rows of D halfs, 16-byte chunk c of row r stored at chunk c ^ (r & 15)
+// stage one 64-token K tile into LDS as f16 rows of D halfs, 16-byte chunk c of row r stored at chunk c ^ (r & 15).
+// Loads are unconditional (rows past the end of the sequence are clamped to the last valid row and masked later by
+// the causal test), and all of a thread's loads are issued before its first LDS write.
 template <int KT, int D, int NT>
 __device__ __forceinline__ void stage_k(char * lds, const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
-    constexpr int CPR = D / 8;  // 16-byte chunks per f16 row
-    for (int c = tid; c < KVT * CPR; c += NT) {
-        const int r = c / CPR, cc = c % CPR;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < n_rows_valid) {
-            const int row = row0 + r;
-            if constexpr (KT == PKV_TYPE_F16) {
-                v = *reinterpret_cast<const uint4 *>(tile + ((size_t) row * D + cc * 8) * 2);
-            } else {
-                const float d = (float) *reinterpret_cast<const _Float16 *>(
-                    tile + tile_quant_bytes(KT, block_size, D) + ((size_t) row * (D / PKV_QK) + cc * 8 / PKV_QK) * 2);
-                _Float16 o[8];
-                if constexpr (KT == PKV_TYPE_Q8_0) {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(tile + (size_t) row * D + cc * 8);
-                    const uint32_t ww[2] = {w.x, w.y};
+    constexpr int CPR = D / 8;            // 16-byte chunks per f16 row
+    constexpr int NI  = KVT * CPR / NT;   // chunks per thread
+    static_assert(KVT * CPR % NT == 0, "tile must divide evenly over the workgroup");
+    uint2 raw[NI][2];
+    float dsc[NI];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) (int) (signed char) (ww[j >> 2] >> (8 * (j & 3))) * d);
-                } else {  // q4_0: byte j of the 32-block = elem j | elem j+16 << 4
-                    const int blk = cc * 8 / PKV_QK, e0 = cc * 8 % PKV_QK;  // elements e0..e0+7 of the block
-                    const uint2 w = *reinterpret_cast<const uint2 *>(tile + (size_t) row * (D / 2) + blk * 16 + (e0 & 15));
-                    const uint32_t ww[2] = {w.x, w.y};
-                    const int sh = e0 < 16 ? 0 : 4;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) ((int) ((ww[j >> 2] >> (8 * (j & 3) + sh)) & 0xF) - 8) * d);
-                }
-                v = *reinterpret_cast<const uint4 *>(o);
+    for (int i = 0; i < NI; ++i) {
+        const int c = tid + i * NT, r = c / CPR, cc = c % CPR;
+        const int row = row0 + min(r, n_rows_valid - 1);
+        dsc[i] = 0.0f;
+        if constexpr (KT == PKV_TYPE_F16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(tile + ((size_t) row * D + cc * 8) * 2);
+            raw[i][0] = make_uint2(v.x, v.y); raw[i][1] = make_uint2(v.z, v.w);
+        } else {
+            dsc[i] = (float) *reinterpret_cast<const _Float16 *>(
+                tile + tile_quant_bytes(KT, block_size, D) + ((size_t) row * (D / PKV_QK) + cc * 8 / PKV_QK) * 2);
+            if constexpr (KT == PKV_TYPE_Q8_0) {
+                raw[i][0] = *reinterpret_cast<const uint2 *>(tile + (size_t) row * D + cc * 8);
+            } else {  // q4_0: byte j of the 32-block = elem j | elem j+16 << 4
+                const int blk = cc * 8 / PKV_QK, e0 = cc * 8 % PKV_QK;
+                raw[i][0] = *reinterpret_cast<const uint2 *>(tile + (size_t) row * (D / 2) + blk * 16 + (e0 & 15));
             }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = tid + i * NT, r = c / CPR, cc = c % CPR;
+        uint4 v;
+        if constexpr (KT == PKV_TYPE_F16) {
+            v = make_uint4(raw[i][0].x, raw[i][0].y, raw[i][1].x, raw[i][1].y);
+        } else {
+            const uint32_t ww[2] = {raw[i][0].x, raw[i][0].y};
+            _Float16 o[8];
+            if constexpr (KT == PKV_TYPE_Q8_0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) (int) (signed char) (ww[j >> 2] >> (8 * (j & 3))) * dsc[i]);
+            } else {
+                const int sh = (cc * 8 % PKV_QK) < 16 ? 0 : 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) ((int) ((ww[j >> 2] >> (8 * (j & 3) + sh)) & 0xF) - 8) * dsc[i]);
+            }
+            v = *reinterpret_cast<const uint4 *>(o);
         }
         *reinterpret_cast<uint4 *>(lds + (size_t) r * D * 2 + ((cc ^ (r & 15)) & (CPR - 1)) * 16) = v;
     }
 }
 
-// stage one 64-token V tile into LDS as [32 token pairs][D] dwords (half2 = tokens 2p, 2p+1 of one d)
+// stage one 64-token V tile into LDS as [32 token pairs][D] dwords (half2 = tokens 2p, 2p+1 of one d).
+// Unconditional clamped loads; cells past the end of the sequence are zeroed by a select (0 * stale NaN must not happen).
 template <int VT, int D, int NT>
 __device__ __forceinline__ void stage_v(char * lds, const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
-    constexpr int CPP = D / 4;  // 16-byte chunks per pair row (D dwords)
-    for (int c = tid; c < (KVT / 2) * CPP; c += NT) {
-        const int p = c / CPP, cc = c % CPP;  // pair inside the tile, chunk = 4 consecutive d
-        const int t0 = 2 * p;                 // first token of the pair inside the tile
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t0 < n_rows_valid) {
-            const int row = row0 + t0;
-            if constexpr (VT == PKV_TYPE_F16) {
-                v = *reinterpret_cast<const uint4 *>(tile + ((size_t) (row / 2) * D + cc * 4) * 4);
-            } else {
-                constexpr int TL = VT == PKV_TYPE_Q8_0 ? 4 : 8;
-                const int grp = row / TL, tl = row % TL;  // tokens tl, tl+1 of the group (row is even)
-                const uint4 w = *reinterpret_cast<const uint4 *>(tile + ((size_t) grp * D + cc * 4) * 4);
-                const _Float16 * sp = reinterpret_cast<const _Float16 *>(
-                    tile + tile_quant_bytes(VT, block_size, D) + ((size_t) grp * (D / PKV_QK) + cc * 4 / PKV_QK) * TL * 2);
-                const float d0 = (float) sp[tl], d1 = (float) sp[tl + 1];
-                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-                uint32_t o[4];
+    constexpr int CPP = D / 4;                    // 16-byte chunks per pair row (D dwords)
+    constexpr int NI  = (KVT / 2) * CPP / NT;     // chunks per thread
+    static_assert((KVT / 2) * CPP % NT == 0, "tile must divide evenly over the workgroup");
+    constexpr int TL = VT == PKV_TYPE_F16 ? 2 : (VT == PKV_TYPE_Q8_0 ? 4 : 8);
+    uint4 raw[NI];
+    float d0[NI], d1[NI];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a, b;
-                    if constexpr (VT == PKV_TYPE_Q8_0) {
-                        a = (float) (int) (signed char) (ww[j] >> (8 * tl)) * d0;
-                        b = (float) (int) (signed char) (ww[j] >> (8 * (tl + 1))) * d1;
-                    } else {
-                        a = (float) ((int) ((ww[j] >> (4 * tl)) & 0xF) - 8) * d0;
-                        b = (float) ((int) ((ww[j] >> (4 * (tl + 1))) & 0xF) - 8) * d1;
-                    }
-                    const _Float16 ha = (_Float16) a, hb = (_Float16) b;
-                    o[j] = (uint32_t) *reinterpret_cast<const uint16_t *>(&ha) | ((uint32_t) *reinterpret_cast<const uint16_t *>(&hb) << 16);
-                }
-                v = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-            if (t0 + 1 >= n_rows_valid) {  // the pair's second token is past the end of the sequence
-                v.x &= 0xFFFFu; v.y &= 0xFFFFu; v.z &= 0xFFFFu; v.w &= 0xFFFFu;
-            }
+    for (int i = 0; i < NI; ++i) {
+        const int c = tid + i * NT, p = c / CPP, cc = c % CPP;
+        const int row = row0 + min(2 * p, (n_rows_valid - 1) & ~1);   // even row of a pair that exists
+        const int grp = row / TL, tl = row % TL;
+        raw[i] = *reinterpret_cast<const uint4 *>(tile + ((size_t) grp * D + cc * 4) * 4);
+        d0[i] = d1[i] = 0.0f;
+        if constexpr (VT != PKV_TYPE_F16) {
+            const _Float16 * sp = reinterpret_cast<const _Float16 *>(
+                tile + tile_quant_bytes(VT, block_size, D) + ((size_t) grp * (D / PKV_QK) + cc * 4 / PKV_QK) * TL * 2);
+            d0[i] = (float) sp[tl];
+            d1[i] = (float) sp[tl + 1];
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = tid + i * NT, p = c / CPP, cc = c % CPP;
+        const int t0 = 2 * p;
+        uint4 v = raw[i];
+        if constexpr (VT != PKV_TYPE_F16) {
+            const int tl = (row0 + min(t0, (n_rows_valid - 1) & ~1)) % TL;
+            const uint32_t ww[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a, b;
+                if constexpr (VT == PKV_TYPE_Q8_0) {
+                    a = (float) (int) (signed char) (ww[j] >> (8 * tl)) * d0[i];
+                    b = (float) (int) (signed char) (ww[j] >> (8 * (tl + 1))) * d1[i];
+                } else {
+                    a = (float) ((int) ((ww[j] >> (4 * tl)) & 0xF) - 8) * d0[i];
+                    b = (float) ((int) ((ww[j] >> (4 * (tl + 1))) & 0xF) - 8) * d1[i];
+                }
+                const _Float16 ha = (_Float16) a, hb = (_Float16) b;
+                o[j] = (uint32_t) *reinterpret_cast<const uint16_t *>(&ha) | ((uint32_t) *reinterpret_cast<const uint16_t *>(&hb) << 16);
+            }
+            v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        const uint32_t keep = t0 >= n_rows_valid ? 0u : (t0 + 1 >= n_rows_valid ? 0xFFFFu : 0xFFFFFFFFu);
+        v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
         *reinterpret_cast<uint4 *>(lds + ((size_t) p * D + cc * 4) * 4) = v;
     }
 }
 
-template <int KT, int VT, int D, int G>
+template <int KT, int VT, int D, int G, bool SOFTCAP>
 __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs a) {
     constexpr int NT = 64 * G, KS = D / 16, DT = D / 32;  // k-steps of QK^T, 32-row d tiles of O^T
     __shared__ __attribute__((aligned(16))) char sK[KVT * D * 2];
@@ -145,11 +172,9 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
         const float * qp = a.q + (size_t) (tok0 + (q_ok ? jr : 0)) * a.q_stride_tok + (size_t) head * a.q_stride_head;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            float4 x0 = make_float4(0, 0, 0, 0), x1 = x0;
-            if (q_ok) {
-                x0 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8);
-                x1 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8 + 4);
-            }
+            // rows past the end of the tile read query 0 of the sequence (in bounds) and are never written back
+            const float4 x0 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8);
+            const float4 x1 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8 + 4);
             qf[ks] = half8_t{(_Float16) x0.x, (_Float16) x0.y, (_Float16) x0.z, (_Float16) x0.w,
                              (_Float16) x1.x, (_Float16) x1.y, (_Float16) x1.z, (_Float16) x1.w};
         }
@@ -192,7 +217,7 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float v = sacc[mt][i] * a.scale;
-                if (a.softcap != 0.0f) v = a.softcap * tanhf(v);
+                if constexpr (SOFTCAP) v = a.softcap * tanhf(v);
                 const int kv = kv0 + mt * 32 + crow(i, h);
                 v = kv <= qpos ? v : -INFINITY;
                 sacc[mt][i] = v;
@@ -202,11 +227,13 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
         const float m_new = fmaxf(m, tmax);
         const float alpha = m_new == -INFINITY ? 1.0f : __expf(m - m_new);
         m = m_new;
-        l *= alpha;
+        if (__any(alpha != 1.0f)) {  // wave-uniform: after the first tiles the running max rarely moves
+            l *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        }
         // ---- O^T += V^T . P^T ------------------------------------------------------------------------------------------
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -245,7 +272,8 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
 
 template <int KT, int VT, int D, int G>
 int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
-    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
+    if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
+    else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
