@@ -43,111 +43,125 @@ struct PrefillArgs {
 
 __device__ __forceinline__ int crow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }  // C/D row of register i
 
-// stage one 64-token K tile into LDS as f16 rows of D halfs, 16-byte chunk c of row r stored at chunk c ^ (r & 15).
-// Loads are unconditional (rows past the end of the sequence are clamped to the last valid row and masked later by
-// the causal test), and all of a thread's loads are issued before its first LDS write.
+// Staging of one 64-token K tile: HBM -> registers (load) now, registers -> LDS (write) one loop iteration later, so the
+// loads of tile t+1 are in flight while tile t is being multiplied (cdna_hip_programming.md T14, async-STAGE split).
+// LDS image: f16 rows of D halfs, 16-byte chunk c of row r stored at chunk c ^ (r & 15) (conflict-free ds_read_b128).
+// Loads are unconditional: rows past the end of the sequence are clamped to the last valid row and removed later by
+// the causal test.
 template <int KT, int D, int NT>
-__device__ __forceinline__ void stage_k(char * lds, const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
-    constexpr int CPR = D / 8;            // 16-byte chunks per f16 row
-    constexpr int NI  = KVT * CPR / NT;   // chunks per thread
+struct KStage {
+    static constexpr int CPR = D / 8;            // 16-byte chunks per f16 row
+    static constexpr int NI  = KVT * CPR / NT;   // chunks per thread
     static_assert(KVT * CPR % NT == 0, "tile must divide evenly over the workgroup");
     uint2 raw[NI][2];
     float dsc[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int c = tid + i * NT, r = c / CPR, cc = c % CPR;
-        const int row = row0 + min(r, n_rows_valid - 1);
-        dsc[i] = 0.0f;
-        if constexpr (KT == PKV_TYPE_F16) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(tile + ((size_t) row * D + cc * 8) * 2);
-            raw[i][0] = make_uint2(v.x, v.y); raw[i][1] = make_uint2(v.z, v.w);
-        } else {
-            dsc[i] = (float) *reinterpret_cast<const _Float16 *>(
-                tile + tile_quant_bytes(KT, block_size, D) + ((size_t) row * (D / PKV_QK) + cc * 8 / PKV_QK) * 2);
-            if constexpr (KT == PKV_TYPE_Q8_0) {
-                raw[i][0] = *reinterpret_cast<const uint2 *>(tile + (size_t) row * D + cc * 8);
-            } else {  // q4_0: byte j of the 32-block = elem j | elem j+16 << 4
-                const int blk = cc * 8 / PKV_QK, e0 = cc * 8 % PKV_QK;
-                raw[i][0] = *reinterpret_cast<const uint2 *>(tile + (size_t) row * (D / 2) + blk * 16 + (e0 & 15));
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int c = tid + i * NT, r = c / CPR, cc = c % CPR;
-        uint4 v;
-        if constexpr (KT == PKV_TYPE_F16) {
-            v = make_uint4(raw[i][0].x, raw[i][0].y, raw[i][1].x, raw[i][1].y);
-        } else {
-            const uint32_t ww[2] = {raw[i][0].x, raw[i][0].y};
-            _Float16 o[8];
-            if constexpr (KT == PKV_TYPE_Q8_0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) (int) (signed char) (ww[j >> 2] >> (8 * (j & 3))) * dsc[i]);
-            } else {
-                const int sh = (cc * 8 % PKV_QK) < 16 ? 0 : 4;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) ((int) ((ww[j >> 2] >> (8 * (j & 3) + sh)) & 0xF) - 8) * dsc[i]);
-            }
-            v = *reinterpret_cast<const uint4 *>(o);
-        }
-        *reinterpret_cast<uint4 *>(lds + (size_t) r * D * 2 + ((cc ^ (r & 15)) & (CPR - 1)) * 16) = v;
-    }
-}
 
-// stage one 64-token V tile into LDS as [32 token pairs][D] dwords (half2 = tokens 2p, 2p+1 of one d).
-// Unconditional clamped loads; cells past the end of the sequence are zeroed by a select (0 * stale NaN must not happen).
+    __device__ __forceinline__ void load(const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * NT, r = c / CPR, cc = c % CPR;
+            const int row = row0 + min(r, n_rows_valid - 1);
+            dsc[i] = 0.0f;
+            if constexpr (KT == PKV_TYPE_F16) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(tile + ((size_t) row * D + cc * 8) * 2);
+                raw[i][0] = make_uint2(v.x, v.y); raw[i][1] = make_uint2(v.z, v.w);
+            } else {
+                dsc[i] = (float) *reinterpret_cast<const _Float16 *>(
+                    tile + tile_quant_bytes(KT, block_size, D) + ((size_t) row * (D / PKV_QK) + cc * 8 / PKV_QK) * 2);
+                if constexpr (KT == PKV_TYPE_Q8_0) {
+                    raw[i][0] = *reinterpret_cast<const uint2 *>(tile + (size_t) row * D + cc * 8);
+                } else {  // q4_0: byte j of the 32-block = elem j | elem j+16 << 4
+                    const int blk = cc * 8 / PKV_QK, e0 = cc * 8 % PKV_QK;
+                    raw[i][0] = *reinterpret_cast<const uint2 *>(tile + (size_t) row * (D / 2) + blk * 16 + (e0 & 15));
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void write(char * lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * NT, r = c / CPR, cc = c % CPR;
+            uint4 v;
+            if constexpr (KT == PKV_TYPE_F16) {
+                v = make_uint4(raw[i][0].x, raw[i][0].y, raw[i][1].x, raw[i][1].y);
+            } else {
+                const uint32_t ww[2] = {raw[i][0].x, raw[i][0].y};
+                _Float16 o[8];
+                if constexpr (KT == PKV_TYPE_Q8_0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) (int) (signed char) (ww[j >> 2] >> (8 * (j & 3))) * dsc[i]);
+                } else {
+                    const int sh = (cc * 8 % PKV_QK) < 16 ? 0 : 4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) ((int) ((ww[j >> 2] >> (8 * (j & 3) + sh)) & 0xF) - 8) * dsc[i]);
+                }
+                v = *reinterpret_cast<const uint4 *>(o);
+            }
+            *reinterpret_cast<uint4 *>(lds + (size_t) r * D * 2 + ((cc ^ (r & 15)) & (CPR - 1)) * 16) = v;
+        }
+    }
+};
+
+// V tile: LDS image [32 token pairs][D] dwords (half2 = tokens 2p, 2p+1 of one d).  Unconditional clamped loads; cells
+// past the end of the sequence are zeroed by a select when written (0 * stale NaN must not happen).
 template <int VT, int D, int NT>
-__device__ __forceinline__ void stage_v(char * lds, const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
-    constexpr int CPP = D / 4;                    // 16-byte chunks per pair row (D dwords)
-    constexpr int NI  = (KVT / 2) * CPP / NT;     // chunks per thread
+struct VStage {
+    static constexpr int CPP = D / 4;                    // 16-byte chunks per pair row (D dwords)
+    static constexpr int NI  = (KVT / 2) * CPP / NT;     // chunks per thread
     static_assert((KVT / 2) * CPP % NT == 0, "tile must divide evenly over the workgroup");
-    constexpr int TL = VT == PKV_TYPE_F16 ? 2 : (VT == PKV_TYPE_Q8_0 ? 4 : 8);
+    static constexpr int TL = VT == PKV_TYPE_F16 ? 2 : (VT == PKV_TYPE_Q8_0 ? 4 : 8);
     uint4 raw[NI];
     float d0[NI], d1[NI];
+    int   row0_, nval_;
+
+    __device__ __forceinline__ void load(const char * tile, int row0, int n_rows_valid, int block_size, int tid) {
+        row0_ = row0; nval_ = n_rows_valid;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int c = tid + i * NT, p = c / CPP, cc = c % CPP;
-        const int row = row0 + min(2 * p, (n_rows_valid - 1) & ~1);   // even row of a pair that exists
-        const int grp = row / TL, tl = row % TL;
-        raw[i] = *reinterpret_cast<const uint4 *>(tile + ((size_t) grp * D + cc * 4) * 4);
-        d0[i] = d1[i] = 0.0f;
-        if constexpr (VT != PKV_TYPE_F16) {
-            const _Float16 * sp = reinterpret_cast<const _Float16 *>(
-                tile + tile_quant_bytes(VT, block_size, D) + ((size_t) grp * (D / PKV_QK) + cc * 4 / PKV_QK) * TL * 2);
-            d0[i] = (float) sp[tl];
-            d1[i] = (float) sp[tl + 1];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int c = tid + i * NT, p = c / CPP, cc = c % CPP;
-        const int t0 = 2 * p;
-        uint4 v = raw[i];
-        if constexpr (VT != PKV_TYPE_F16) {
-            const int tl = (row0 + min(t0, (n_rows_valid - 1) & ~1)) % TL;
-            const uint32_t ww[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
-            uint32_t o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a, b;
-                if constexpr (VT == PKV_TYPE_Q8_0) {
-                    a = (float) (int) (signed char) (ww[j] >> (8 * tl)) * d0[i];
-                    b = (float) (int) (signed char) (ww[j] >> (8 * (tl + 1))) * d1[i];
-                } else {
-                    a = (float) ((int) ((ww[j] >> (4 * tl)) & 0xF) - 8) * d0[i];
-                    b = (float) ((int) ((ww[j] >> (4 * (tl + 1))) & 0xF) - 8) * d1[i];
-                }
-                const _Float16 ha = (_Float16) a, hb = (_Float16) b;
-                o[j] = (uint32_t) *reinterpret_cast<const uint16_t *>(&ha) | ((uint32_t) *reinterpret_cast<const uint16_t *>(&hb) << 16);
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * NT, p = c / CPP, cc = c % CPP;
+            const int row = row0 + min(2 * p, (n_rows_valid - 1) & ~1);   // even row of a pair that exists
+            const int grp = row / TL, tl = row % TL;
+            raw[i] = *reinterpret_cast<const uint4 *>(tile + ((size_t) grp * D + cc * 4) * 4);
+            d0[i] = d1[i] = 0.0f;
+            if constexpr (VT != PKV_TYPE_F16) {
+                const _Float16 * sp = reinterpret_cast<const _Float16 *>(
+                    tile + tile_quant_bytes(VT, block_size, D) + ((size_t) grp * (D / PKV_QK) + cc * 4 / PKV_QK) * TL * 2);
+                d0[i] = (float) sp[tl];
+                d1[i] = (float) sp[tl + 1];
             }
-            v = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        const uint32_t keep = t0 >= n_rows_valid ? 0u : (t0 + 1 >= n_rows_valid ? 0xFFFFu : 0xFFFFFFFFu);
-        v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
-        *reinterpret_cast<uint4 *>(lds + ((size_t) p * D + cc * 4) * 4) = v;
     }
-}
+    __device__ __forceinline__ void write(char * lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * NT, p = c / CPP, cc = c % CPP;
+            const int t0 = 2 * p;
+            uint4 v = raw[i];
+            if constexpr (VT != PKV_TYPE_F16) {
+                const int tl = (row0_ + min(t0, (nval_ - 1) & ~1)) % TL;
+                const uint32_t ww[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x, y;
+                    if constexpr (VT == PKV_TYPE_Q8_0) {
+                        x = (float) (int) (signed char) (ww[j] >> (8 * tl)) * d0[i];
+                        y = (float) (int) (signed char) (ww[j] >> (8 * (tl + 1))) * d1[i];
+                    } else {
+                        x = (float) ((int) ((ww[j] >> (4 * tl)) & 0xF) - 8) * d0[i];
+                        y = (float) ((int) ((ww[j] >> (4 * (tl + 1))) & 0xF) - 8) * d1[i];
+                    }
+                    const _Float16 hx = (_Float16) x, hy = (_Float16) y;
+                    o[j] = (uint32_t) *reinterpret_cast<const uint16_t *>(&hx) | ((uint32_t) *reinterpret_cast<const uint16_t *>(&hy) << 16);
+                }
+                v = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            const uint32_t keep = t0 >= nval_ ? 0u : (t0 + 1 >= nval_ ? 0xFFFFu : 0xFFFFFFFFu);
+            v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+            *reinterpret_cast<uint4 *>(lds + ((size_t) p * D + cc * 4) * 4) = v;
+        }
+    }
+};
 
 template <int KT, int VT, int D, int G, bool SOFTCAP>
 __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs a) {
@@ -188,14 +202,21 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
     float m = -INFINITY, l = 0.0f;
 
     const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
-    for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
+    KStage<KT, D, NT> kst;
+    VStage<VT, D, NT> vst;
+    auto prefetch = [&](int kv0) {
         const int phys = a.block_table[(size_t) s * a.max_blocks + kv0 / a.block_size];
-        const int row0 = kv0 % a.block_size;
-        const int nval = min(KVT, seq_len - kv0);
+        const int row0 = kv0 % a.block_size, nval = min(KVT, seq_len - kv0);
+        kst.load(a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k, row0, nval, a.block_size, tid);
+        vst.load(a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v, row0, nval, a.block_size, tid);
+    };
+    prefetch(0);
+    for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
         __syncthreads();  // previous tile fully consumed
-        stage_k<KT, D, NT>(sK, a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k, row0, nval, a.block_size, tid);
-        stage_v<VT, D, NT>(sV, a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v, row0, nval, a.block_size, tid);
+        kst.write(sK, tid);
+        vst.write(sV, tid);
         __syncthreads();
+        if (kv0 + KVT < kv_end) prefetch(kv0 + KVT);  // in flight while this tile is multiplied
 
         // ---- S^T = K . Q^T : two 32-row kv tiles ---------------------------------------------------------------
         floatx16 sacc[2];
