@@ -218,18 +218,39 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
         __syncthreads();
         if (kv0 + KVT < kv_end) prefetch(kv0 + KVT);  // in flight while this tile is multiplied
 
+        // ---- every MFMA operand of this tile is read from LDS up front (one wave per SIMD has 512 registers to spend):
+        //      the MFMA chains below then run without waiting on a ds_read each -------------------------------------
+        half8_t kfr[2][KS];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = mt * 32 + r;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kfr[mt][ks] = *reinterpret_cast<const half8_t *>(sK + (size_t) row * D * 2 + (((2 * ks + h) ^ (row & 15)) & (D / 8 - 1)) * 16);
+        }
+        uint32_t vfr[2][2][DT][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int p0 = mt * 16 + 8 * s2 + 2 * h;  // token pairs p0, p0+1, p0+4, p0+5 = this half's k order
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const uint32_t * vb = reinterpret_cast<const uint32_t *>(sV) + dt * 32 + r;
+                    vfr[mt][s2][dt][0] = vb[(size_t) p0 * D];
+                    vfr[mt][s2][dt][1] = vb[(size_t) (p0 + 1) * D];
+                    vfr[mt][s2][dt][2] = vb[(size_t) (p0 + 4) * D];
+                    vfr[mt][s2][dt][3] = vb[(size_t) (p0 + 5) * D];
+                }
+            }
         // ---- S^T = K . Q^T : two 32-row kv tiles ---------------------------------------------------------------
         floatx16 sacc[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[mt][i] = 0.0f;
-            const int row = mt * 32 + r;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const half8_t kf = *reinterpret_cast<const half8_t *>(sK + (size_t) row * D * 2 + (((2 * ks + h) ^ (row & 15)) & (D / 8 - 1)) * 16);
-                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mt], 0, 0, 0);
-            }
+            for (int ks = 0; ks < KS; ++ks) sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[mt][ks], qf[ks], sacc[mt], 0, 0, 0);
         }
         // ---- scale, causal mask, online softmax (query on the lane) ------------------------------------------------
         float tmax = -INFINITY;
@@ -267,13 +288,9 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
                     pf[j] = (_Float16) p;
                     l += (float) pf[j];   // the weight PV really applies
                 }
-                const int p0 = mt * 16 + 8 * s2 + 2 * h;  // token pairs p0, p0+1, p0+4, p0+5 = this half's k order
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const uint32_t * vb = reinterpret_cast<const uint32_t *>(sV) + dt * 32 + r;
-                    uint32_t w[4] = {vb[(size_t) p0 * D], vb[(size_t) (p0 + 1) * D], vb[(size_t) (p0 + 4) * D], vb[(size_t) (p0 + 5) * D]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(w), pf, o[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < DT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(vfr[mt][s2][dt]), pf, o[dt], 0, 0, 0);
             }
     }
     // ---- normalise and write out[tok][head][d] -----------------------------------------------------------------------------
