@@ -23,6 +23,7 @@ namespace pkv {
 namespace {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int QT  = 32;  // query rows per workgroup tile (one MFMA N dimension)
@@ -194,12 +195,16 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
         }
     }
 
-    floatx16 o[DT];
+    floatx16 o[DT + 1];   // o[DT] = row sums (every row of that tile holds l of the lane's query)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt <= DT; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
-    float m = -INFINITY, l = 0.0f;
+    float m = -INFINITY;
+    const half8_t ones = {(_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f,
+                          (_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f};
+    const float cexp = (SOFTCAP ? 1.0f : a.scale) * 1.44269504088896340736f;   // exp(x * scale) = exp2(x * cexp)
+    const int qpos_min = seq_len - n_q + tile * QT;                               // smallest query position of the tile
 
     const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
     KStage<KT, D, NT> kst;
@@ -218,85 +223,75 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
         __syncthreads();
         if (kv0 + KVT < kv_end) prefetch(kv0 + KVT);  // in flight while this tile is multiplied
 
-        // ---- every MFMA operand of this tile is read from LDS up front (one wave per SIMD has 512 registers to spend):
-        //      the MFMA chains below then run without waiting on a ds_read each -------------------------------------
-        half8_t kfr[2][KS];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = mt * 32 + r;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                kfr[mt][ks] = *reinterpret_cast<const half8_t *>(sK + (size_t) row * D * 2 + (((2 * ks + h) ^ (row & 15)) & (D / 8 - 1)) * 16);
-        }
-        uint32_t vfr[2][2][DT][4];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int p0 = mt * 16 + 8 * s2 + 2 * h;  // token pairs p0, p0+1, p0+4, p0+5 = this half's k order
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const uint32_t * vb = reinterpret_cast<const uint32_t *>(sV) + dt * 32 + r;
-                    vfr[mt][s2][dt][0] = vb[(size_t) p0 * D];
-                    vfr[mt][s2][dt][1] = vb[(size_t) (p0 + 1) * D];
-                    vfr[mt][s2][dt][2] = vb[(size_t) (p0 + 4) * D];
-                    vfr[mt][s2][dt][3] = vb[(size_t) (p0 + 5) * D];
-                }
-            }
         // ---- S^T = K . Q^T : two 32-row kv tiles ---------------------------------------------------------------
         floatx16 sacc[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[mt][i] = 0.0f;
+            const int row = mt * 32 + r;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[mt][ks], qf[ks], sacc[mt], 0, 0, 0);
-        }
-        // ---- scale, causal mask, online softmax (query on the lane) ------------------------------------------------
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = sacc[mt][i] * a.scale;
-                if constexpr (SOFTCAP) v = a.softcap * tanhf(v);
-                const int kv = kv0 + mt * 32 + crow(i, h);
-                v = kv <= qpos ? v : -INFINITY;
-                sacc[mt][i] = v;
-                tmax = fmaxf(tmax, v);
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8_t kf = *reinterpret_cast<const half8_t *>(sK + (size_t) row * D * 2 + (((2 * ks + h) ^ (row & 15)) & (D / 8 - 1)) * 16);
+                sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mt], 0, 0, 0);
             }
+        }
+        // ---- causal mask (only tiles that reach the diagonal), running max; VALU kept to ~1 op per logit:
+        //      the softmax scale rides in the exponent, p = exp2(c*s - c*m) = one v_fma + one v_exp -----------------------
+        if constexpr (SOFTCAP) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[mt][i] = a.softcap * tanhf(sacc[mt][i] * a.scale);
+        }
+        if (kv0 + KVT - 1 > qpos_min) {  // workgroup-uniform
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    sacc[mt][i] = kv0 + mt * 32 + crow(i, h) <= qpos ? sacc[mt][i] : -INFINITY;
+        }
+        float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, fmaxf(sacc[0][i], sacc[1][i]));   // v_max3_f32
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = m_new == -INFINITY ? 1.0f : __expf(m - m_new);
+        const float m_new = fmaxf(m, tmax);                       // in units of the raw (or soft-capped) logit
+        const float alpha = m_new == -INFINITY ? 1.0f : exp2f((m - m_new) * cexp);
         m = m_new;
         if (__any(alpha != 1.0f)) {  // wave-uniform: after the first tiles the running max rarely moves
-            l *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt <= DT; ++dt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
         }
-        // ---- O^T += V^T . P^T ------------------------------------------------------------------------------------------
+        const float mc = m == -INFINITY ? 0.0f : m * cexp;
+        // ---- O^T += V^T . P^T ; the row sums l come from one extra MFMA against an all-ones A fragment, i.e. from the
+        //      same f16-rounded weights PV applies -------------------------------------------------------------------
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                half8_t pf;
+                half2_t pp[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float p = m == -INFINITY ? 0.0f : __expf(sacc[mt][8 * s2 + j] - m);
-                    pf[j] = (_Float16) p;
-                    l += (float) pf[j];   // the weight PV really applies
+                for (int j = 0; j < 4; ++j) {
+                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[mt][8 * s2 + 2 * j], cexp, -mc));
+                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[mt][8 * s2 + 2 * j + 1], cexp, -mc));
+                    pp[j] = __builtin_amdgcn_cvt_pkrtz(p0, p1);
                 }
+                const half8_t pf = *reinterpret_cast<const half8_t *>(pp);
+                const int p0 = mt * 16 + 8 * s2 + 2 * h;  // token pairs p0, p0+1, p0+4, p0+5 = this half's k order
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(vfr[mt][s2][dt]), pf, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < DT; ++dt) {
+                    const uint32_t * vb = reinterpret_cast<const uint32_t *>(sV) + dt * 32 + r;
+                    const uint32_t w[4] = {vb[(size_t) p0 * D], vb[(size_t) (p0 + 1) * D], vb[(size_t) (p0 + 4) * D], vb[(size_t) (p0 + 5) * D]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(w), pf, o[dt], 0, 0, 0);
+                }
+                o[DT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, o[DT], 0, 0, 0);
             }
     }
     // ---- normalise and write out[tok][head][d] -----------------------------------------------------------------------------
-    l += __shfl_xor(l, 32);
     if (q_ok) {
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / o[DT][0];
         float * op = a.out + ((size_t) (tok0 + jr) * a.n_head + head) * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
