@@ -20,6 +20,7 @@
 #include "pkv_common.h"
 
 namespace pkv {
+extern void * g_prefill_stamps;
 namespace {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -40,6 +41,7 @@ struct PrefillArgs {
     const int32_t * q_start;
     int   n_head, n_head_kv, block_size, max_blocks;
     float scale, softcap;
+    unsigned long long * stamps;  // diagnostic build only (PKV_PREFILL_STAMP): per-workgroup phase timestamps
 };
 
 __device__ __forceinline__ int crow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }  // C/D row of register i
@@ -164,11 +166,14 @@ struct VStage {
     }
 };
 
-template <int KT, int VT, int D, int G, bool SOFTCAP>
-__global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs a) {
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool STAMP = false>
+__global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillArgs a) {
+    unsigned long long t_begin = 0, t_q = 0, t_loop = 0, t_stage = 0, t_qk = 0, t_sm = 0, t_pv = 0, tt = 0;
+    if constexpr (STAMP) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int NT = 64 * G, KS = D / 16, DT = D / 32;  // k-steps of QK^T, 32-row d tiles of O^T
-    __shared__ __attribute__((aligned(16))) char sK[KVT * D * 2];
-    __shared__ __attribute__((aligned(16))) char sV[KVT * D * 2];
+    // two LDS images per operand: tile t+1 is written while slower waves still multiply tile t -> ONE barrier per tile
+    __shared__ __attribute__((aligned(16))) char sKb[2][KVT * D * 2];
+    __shared__ __attribute__((aligned(16))) char sVb[2][KVT * D * 2];
 
     const int tile = blockIdx.x, hk = blockIdx.y, s = blockIdx.z;
     const int tok0 = a.q_start[s], n_q = a.q_start[s + 1] - tok0;
@@ -195,6 +200,7 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
         }
     }
 
+    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_q = __builtin_amdgcn_s_memtime(); }
     floatx16 o[DT + 1];   // o[DT] = row sums (every row of that tile holds l of the lane's query)
 #pragma unroll
     for (int dt = 0; dt <= DT; ++dt)
@@ -216,12 +222,16 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
         vst.load(a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v, row0, nval, a.block_size, tid);
     };
     prefetch(0);
-    for (int kv0 = 0; kv0 < kv_end; kv0 += KVT) {
-        __syncthreads();  // previous tile fully consumed
-        kst.write(sK, tid);
-        vst.write(sV, tid);
-        __syncthreads();
-        if (kv0 + KVT < kv_end) prefetch(kv0 + KVT);  // in flight while this tile is multiplied
+    kst.write(sKb[0], tid);
+    vst.write(sVb[0], tid);
+    for (int kv0 = 0, it = 0; kv0 < kv_end; kv0 += KVT, ++it) {
+        if constexpr (STAMP) tt = __builtin_amdgcn_s_memtime();
+        const char * sK = sKb[it & 1];
+        const char * sV = sVb[it & 1];
+        const bool more = kv0 + KVT < kv_end;
+        __syncthreads();                       // tile `it` is complete in LDS; everyone is done with tile it-1
+        if (more) prefetch(kv0 + KVT);         // HBM -> registers, in flight while this tile is multiplied
+        if constexpr (STAMP) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_stage += t2 - tt; tt = t2; }
 
         // ---- S^T = K . Q^T : two 32-row kv tiles ---------------------------------------------------------------
         floatx16 sacc[2];
@@ -236,6 +246,7 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
                 sacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[mt], 0, 0, 0);
             }
         }
+        if constexpr (STAMP) { asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory"); const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_qk += t2 - tt; tt = t2; }
         // ---- causal mask (only tiles that reach the diagonal), running max; VALU kept to ~1 op per logit:
         //      the softmax scale rides in the exponent, p = exp2(c*s - c*m) = one v_fma + one v_exp -----------------------
         if constexpr (SOFTCAP) {
@@ -265,6 +276,7 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
                 for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
         }
         const float mc = m == -INFINITY ? 0.0f : m * cexp;
+        if constexpr (STAMP) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_sm += t2 - tt; tt = t2; }
         // ---- O^T += V^T . P^T ; the row sums l come from one extra MFMA against an all-ones A fragment, i.e. from the
         //      same f16-rounded weights PV applies -------------------------------------------------------------------
 #pragma unroll
@@ -288,7 +300,13 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
                 }
                 o[DT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, o[DT], 0, 0, 0);
             }
+        if (more) {                            // registers -> the other LDS image (last read two barriers ago)
+            kst.write(sKb[(it + 1) & 1], tid);
+            vst.write(sVb[(it + 1) & 1], tid);
+        }
+        if constexpr (STAMP) { asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory"); const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_pv += t2 - tt; tt = t2; }
     }
+    if constexpr (STAMP) t_loop = __builtin_amdgcn_s_memtime();
     // ---- normalise and write out[tok][head][d] -----------------------------------------------------------------------------
     if (q_ok) {
         const float inv = 1.0f / o[DT][0];
@@ -301,10 +319,25 @@ __global__ void __launch_bounds__(64 * G) attn_prefill_kernel(const PrefillArgs 
                 *reinterpret_cast<float4 *>(op + d) = make_float4(o[dt][i] * inv, o[dt][i + 1] * inv, o[dt][i + 2] * inv, o[dt][i + 3] * inv);
             }
     }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long * o8 = a.stamps + ((size_t) (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+            o8[0] = t_q - t_begin; o8[1] = t_loop - t_q; o8[2] = t_end - t_loop; o8[3] = t_stage; o8[4] = t_qk; o8[5] = t_sm; o8[6] = t_pv; o8[7] = t_begin;
+        }
+    }
 }
 
 template <int KT, int VT, int D, int G>
 int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
+    if constexpr (KT == PKV_TYPE_F16 && VT == PKV_TYPE_F16 && D == 128 && G == 4) {
+        if (pa.stamps) {
+            hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, true>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
+            PKV_HIP(hipGetLastError());
+            return PKV_OK;
+        }
+    }
     if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
     else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
     PKV_HIP(hipGetLastError());
@@ -342,6 +375,8 @@ int launch_v(const PrefillArgs & pa, int VT, int D, int G, int n_tiles, int n_se
 
 }  // namespace
 
+void * g_prefill_stamps = nullptr;  // set by pkv_debug_set_prefill_stamps (diagnostic)
+void set_prefill_stamps(void * p) { g_prefill_stamps = p; }
 size_t prefill_workspace_bytes(int, int, int) { return 0; }
 
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
@@ -360,6 +395,7 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
     pa.block_table = a.block_table; pa.seq_lens = a.seq_lens; pa.q_start = a.q_start;
     pa.n_head = a.n_head; pa.n_head_kv = a.n_head_kv; pa.block_size = a.block_size; pa.max_blocks = a.max_blocks;
     pa.softcap = a.logit_softcap;
+    pa.stamps = (unsigned long long *) g_prefill_stamps;
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
     const int n_tiles = (a.max_q_per_seq + QT - 1) / QT, G = a.n_head / a.n_head_kv;
     switch (a.type_k) {

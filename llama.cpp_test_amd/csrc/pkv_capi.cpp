@@ -148,6 +148,8 @@ int  pkv_event_elapsed_ms(void * start, void * stop, float * ms) {
     return PKV_OK;
 }
 
+void pkv_debug_set_prefill_stamps(void * dev_u64) { pkv::set_prefill_stamps(dev_u64); }
+
 int pkv_attn_prefill(const pkv_attn_args * args, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(args != nullptr, "pkv_attn_prefill: null args");

@@ -60,6 +60,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st);
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);
+void set_prefill_stamps(void * dev_u64);  // diagnostic
 int launch_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,
                    const int32_t * cell_delta, int n_cells, int n_head_kv, int D, int block_size, const RopeDev & r,
                    hipStream_t st);
