@@ -127,6 +127,10 @@ typedef struct pkv_attn_args {
     float   logit_softcap;        /* op_params[2]; 0 = off.  max_bias (ALiBi) != 0 is PKV_ERR_UNSUPPORTED       */
     int32_t max_seq_len;          /* upper bound of seq_lens[] known on the host (sizes the split-KV grid)      */
     int32_t flags;                /* PKV_ATTN_* bits                                                            */
+    const void * mask;            /* pkv_attn_prefill only: optional additive mask, device f16 [n_tok][mask_stride] (row =  */
+    int64_t mask_stride;          /* token, column = logical KV cell): the general KQ_mask of ggml_flash_attn_ext            */
+    float   max_bias;             /* (/ref/ggml/include/ggml.h:1794-1807); max_bias > 0 = ALiBi slopes, needs a mask.      */
+                                  /* NULL = the causal-by-position structure of llama (no mask tensor at all)              */
     void *  ev_start;             /* optional hipEvent_t pair bound to the split-KV decode launch itself          */
     void *  ev_stop;              /* (hipExtLaunchKernel): elapsed = the dispatch's own GPU duration, as rocprofv3 */
                                   /* --kernel-trace reports it.  NULL = plain launch.                              */
@@ -139,6 +143,8 @@ typedef struct pkv_attn_args {
  * it; arrival tickets live at the end of `workspace`).  Contract: `workspace` was zeroed once by
  * pkv_attn_workspace_init() and is used by one launch at a time.  Ignored (two-launch path) with softcap / slot_pos. */
 #define PKV_ATTN_FUSED_COMBINE 2
+/* pkv_attn_prefill: every query sees all seq_lens[s] cells (no causal structure); masking, if any, comes from `mask` */
+#define PKV_ATTN_NONCAUSAL 4
 
 size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq_len, int block_size);
 /* zero a fresh workspace (asynchronously, on `stream`); required once before PKV_ATTN_FUSED_COMBINE is used with it */

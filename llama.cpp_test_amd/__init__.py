@@ -32,6 +32,7 @@ TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0}
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SPACE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 ATTN_NO_COMBINE = 1
 ATTN_FUSED_COMBINE = 2
+ATTN_NONCAUSAL = 4
 
 
 class PkvError(RuntimeError):
@@ -57,6 +58,7 @@ class AttnArgs(C.Structure):
                 ("n_head_kv", C.c_int32), ("head_dim", C.c_int32), ("block_size", C.c_int32), ("max_blocks", C.c_int32),
                 ("type_k", C.c_int32), ("type_v", C.c_int32), ("scale", C.c_float), ("logit_softcap", C.c_float),
                 ("max_seq_len", C.c_int32), ("flags", C.c_int32),
+                ("mask", C.c_void_p), ("mask_stride", C.c_int64), ("max_bias", C.c_float),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
@@ -181,7 +183,7 @@ def attn_workspace_bytes(n_tok: int, n_head: int, head_dim: int, max_seq_len: in
 
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
-          stream=None, flags=0, events=None):
+          stream=None, flags=0, events=None, mask=None, max_bias=0.0):
     import torch
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
@@ -192,7 +194,8 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
     a = AttnArgs(_ptr(q), q.stride(0), q.stride(1), _ptr(out), _ptr(k_pool), _ptr(v_pool), _ptr(block_table),
                  _ptr(seq_lens), _ptr(q_start), _ptr(slot_pos), _ptr(q_pos), _ptr(workspace), workspace.numel(),
                  n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
-                 scale, logit_softcap, max_seq_len, flags, events[0] if events else None, events[1] if events else None)
+                 scale, logit_softcap, max_seq_len, flags, _ptr(mask), mask.stride(0) if mask is not None else 0, max_bias,
+                 events[0] if events else None, events[1] if events else None)
     check(fn(C.byref(a), C.c_void_p(_stream(stream))))
     return out
 

@@ -605,6 +605,10 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.max_seq_len > 0 && a.max_seq_len <= a.max_blocks * a.block_size, "pkv_attn_decode: max_seq_len out of range");
     PKV_REQUIRE((a.q_stride_head % 4) == 0 && (a.q_stride_tok % 4) == 0 && ((uintptr_t) a.q % 16) == 0, "pkv_attn_decode: q must be 16-byte aligned");
     PKV_REQUIRE(a.slot_pos == nullptr || a.q_pos != nullptr, "pkv_attn_decode: slot_pos needs q_pos");
+    if (a.mask || a.max_bias != 0.0f || (a.flags & PKV_ATTN_NONCAUSAL)) {
+        set_error("pkv_attn_decode: explicit masks / ALiBi go through pkv_attn_prefill (decode is causal by length)");
+        return PKV_ERR_UNSUPPORTED;
+    }
     const size_t need = decode_workspace_bytes(a.n_tok, a.n_head, a.head_dim, a.max_seq_len);
     PKV_REQUIRE(a.workspace && a.workspace_bytes >= need, "pkv_attn_decode: workspace too small (%zu < %zu)", a.workspace_bytes, need);
 

@@ -41,6 +41,10 @@ struct PrefillArgs {
     const int32_t * q_start;
     int   n_head, n_head_kv, block_size, max_blocks;
     float scale, softcap;
+    const _Float16 * mask;        // optional additive mask f16 [>= n_tok rows][mask_stride], row = token index, col = kv cell
+    int64_t mask_stride;
+    float   max_bias;             // ALiBi: slope(head) * mask (/ref/ggml/src/ggml-cpu/ggml-cpu.c:12294-12316)
+    int     causal;               // 0: every query sees all seq_len cells (test-backend-ops style), 1: llama causal
     unsigned long long * stamps;  // diagnostic build only (PKV_PREFILL_STAMP): per-workgroup phase timestamps
 };
 
@@ -166,7 +170,7 @@ struct VStage {
     }
 };
 
-template <int KT, int VT, int D, int G, bool SOFTCAP, bool STAMP = false>
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool STAMP = false, bool MASKED = false>
 __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillArgs a) {
     unsigned long long t_begin = 0, t_q = 0, t_loop = 0, t_stage = 0, t_qk = 0, t_sm = 0, t_pv = 0, tt = 0;
     if constexpr (STAMP) t_begin = __builtin_amdgcn_s_memtime();
@@ -183,8 +187,9 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     const int head = hk * G + g;
     const int jr = tile * QT + r;            // this lane's query inside the sequence's new tokens
     const bool q_ok = jr < n_q;
-    const int qpos = seq_len - n_q + jr;     // position = index of the last KV cell it sees
-    const int kv_end = min(seq_len, seq_len - n_q + tile * QT + QT);  // workgroup-uniform bound
+    // index of the last KV cell this query sees, and the workgroup-uniform bound of the KV loop
+    const int qpos   = a.causal ? seq_len - n_q + jr : seq_len - 1;
+    const int kv_end = a.causal ? min(seq_len, seq_len - n_q + tile * QT + QT) : seq_len;
 
     // ---- Q^T fragments, rounded to f16 (GGML_FP32_TO_FP16 of the reference's q_to_vec_dot for f16 K) ---------------
     half8_t qf[KS];
@@ -209,8 +214,17 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     float m = -INFINITY;
     const half8_t ones = {(_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f,
                           (_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f, (_Float16) 1.0f};
-    const float cexp = (SOFTCAP ? 1.0f : a.scale) * 1.44269504088896340736f;   // exp(x * scale) = exp2(x * cexp)
-    const int qpos_min = seq_len - n_q + tile * QT;                               // smallest query position of the tile
+    const float cexp = ((SOFTCAP || MASKED) ? 1.0f : a.scale) * 1.44269504088896340736f;   // exp(x * scale) = exp2(x * cexp)
+    const int qpos_min = a.causal ? seq_len - n_q + tile * QT : seq_len - 1;                  // smallest last-visible cell in the tile
+    float slope = 1.0f;
+    if constexpr (MASKED) {
+        if (a.max_bias > 0.0f) {
+            const uint32_t n_head_log2 = 1u << (31 - __clz(a.n_head));
+            const float m0 = exp2f(-a.max_bias / n_head_log2), m1 = exp2f(-(a.max_bias / 2.0f) / n_head_log2);
+            slope = (uint32_t) head < n_head_log2 ? powf(m0, head + 1) : powf(m1, 2 * (head - n_head_log2) + 1);
+        }
+    }
+    const _Float16 * mrow = MASKED ? a.mask + (size_t) (tok0 + (q_ok ? jr : 0)) * a.mask_stride : nullptr;
 
     const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
     KStage<KT, D, NT> kst;
@@ -254,6 +268,20 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sacc[mt][i] = a.softcap * tanhf(sacc[mt][i] * a.scale);
+        } else if constexpr (MASKED) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[mt][i] *= a.scale;
+        }
+        if constexpr (MASKED) {  // s += slope * mask (:12349-12365); -inf entries skip the cell
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kv = min(kv0 + mt * 32 + crow(i, h), seq_len - 1);
+                    sacc[mt][i] += slope * (float) mrow[kv];
+                }
         }
         if (kv0 + KVT - 1 > qpos_min) {  // workgroup-uniform
 #pragma unroll
@@ -338,8 +366,14 @@ int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
             return PKV_OK;
         }
     }
-    if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
-    else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
+    const dim3 grid(n_tiles, pa.n_head_kv, n_seq), block(64 * G);
+    if (pa.mask) {
+        if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true, false, true>), grid, block, 0, st, pa);
+        else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, false, true>), grid, block, 0, st, pa);
+    } else {
+        if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true>), grid, block, 0, st, pa);
+        else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false>), grid, block, 0, st, pa);
+    }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
@@ -396,6 +430,9 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
     pa.n_head = a.n_head; pa.n_head_kv = a.n_head_kv; pa.block_size = a.block_size; pa.max_blocks = a.max_blocks;
     pa.softcap = a.logit_softcap;
     pa.stamps = (unsigned long long *) g_prefill_stamps;
+    pa.mask = (const _Float16 *) a.mask; pa.mask_stride = a.mask_stride; pa.max_bias = a.max_bias;
+    pa.causal = (a.flags & PKV_ATTN_NONCAUSAL) ? 0 : 1;
+    PKV_REQUIRE(a.max_bias == 0.0f || a.mask, "pkv_attn_prefill: max_bias (ALiBi) needs a mask");
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
     const int n_tiles = (a.max_q_per_seq + QT - 1) / QT, G = a.n_head / a.n_head_kv;
     switch (a.type_k) {

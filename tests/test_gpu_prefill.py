@@ -120,3 +120,27 @@ def test_prefill_pp512_properties(pkv, O):
         mask[0, j + 1:] = -np.inf
         ref = O.flash_attn_ext(q[j][:, None, :], kc, vc, mask, type_k=1, type_v=1, scale=D ** -0.5)[0]
         assert np.abs(base[j] - ref).max() <= 1e-3
+
+
+@pytest.mark.parametrize("tk", [1, 8, 2])
+@pytest.mark.parametrize("max_bias,softcap", [(0.0, 0.0), (8.0, 0.0), (0.0, 10.0)])
+def test_prefill_general_mask_noncausal(pkv, O, tk, max_bias, softcap):
+    """the ggml_flash_attn_ext contract as tests/test-backend-ops.cpp:3197-3272 exercises it: every query sees every cell,
+    an additive f16 mask with arbitrary values (and -inf holes), ALiBi slopes (max_bias), logit soft-cap"""
+    rng = np.random.default_rng(int(tk * 100 + max_bias + softcap))
+    D, nh, nkv, n_kv = 128, 8, 2, 512
+    for n_q in (1, 3, 35):
+        kp, vp, bt, sl = make_paged_case(O, rng, lens=[n_kv], D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
+        q = rng.uniform(-1, 1, (n_q, nh, D)).astype(np.float32)
+        mask = rng.uniform(-1, 1, (n_q, n_kv)).astype(np.float16)
+        mask[:, rng.integers(0, n_kv, 20)] = -np.inf
+        out = pkv.attn_prefill(dev(q), dev(kp), dev(vp), dev(bt), dev(sl), dev(np.array([0, n_q], np.int32)), n_head_kv=nkv,
+                               type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5, max_seq_len=n_kv, max_q_per_seq=n_q,
+                               logit_softcap=softcap, mask=dev(mask), max_bias=max_bias, flags=pkv.ATTN_NONCAUSAL)
+        torch.cuda.synchronize()
+        kc = O.pool_gather(kp, tk, 0, bt[0], n_kv, D=D, block_size=128)
+        vc = O.pool_gather(vp, tk, 1, bt[0], n_kv, D=D, block_size=128)
+        ref = O.flash_attn_ext(q.transpose(1, 0, 2), kc, vc, mask, type_k=tk, type_v=tk, scale=D ** -0.5, max_bias=max_bias,
+                               softcap=softcap)
+        assert nmse(out.cpu().numpy(), ref) <= 5e-4, (n_q,)
+        assert np.abs(out.cpu().numpy() - ref).max() <= 3e-3
