@@ -84,6 +84,14 @@ typedef struct pkv_rope_params {
 int pkv_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, int n_head, int head_dim,
                  const pkv_rope_params * rope, int inverse, void * stream);
 
+/* same with explicit input strides (in floats) for non-contiguous views of x (ggml views/permutes); out stays contiguous */
+int pkv_rope_f32_strided(const float * x, int64_t x_stride_tok, int64_t x_stride_head, const int32_t * pos, float * out,
+                         int n_tok, int n_head, int head_dim, const pkv_rope_params * rope, int inverse, void * stream);
+
+/* GGML_OP_CPY f32 -> f16/q8_0/q4_0 into a CONTIGUOUS typed tensor in the reference's own byte format
+ * (ggml_compute_forward_dup_f32, /ref/ggml/src/ggml-cpu/ggml-cpu.c:3742): x f32 [n_rows][ne0], ne0 % 64 == 0. */
+int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, void * stream);
+
 /* KV store: replaces ggml_cpy(k_cur -> k_cache_view) / (v_cur -> v_cache_view) in build_attn
  * (/ref/src/llama-graph.cpp:1367-1398), CPU kernel ggml_compute_forward_dup_f32 + from_float
  * (/ref/ggml/src/ggml-cpu/ggml-cpu.c:3742, ggml-cpu-quants.c:738).
@@ -178,6 +186,11 @@ int pkv_copy_blocks(void * pool, int type, const int32_t * src, const int32_t * 
 int pkv_pool_scatter_rows(void * pool, int type, int is_v, const void * rows, const int32_t * slot_block,
                           const int32_t * slot_off, int n_tok, int n_head_kv, int head_dim, int block_size,
                           void * stream);
+/* scatter with explicit byte strides between tokens / heads of `rows` (any ggml view of a K/V tensor);
+ * slot_block == NULL = identity placement (token t -> block t / block_size, offset t % block_size) */
+int pkv_pool_scatter_rows_strided(void * pool, int type, int is_v, const void * rows, int64_t row_stride_tok,
+                                  int64_t row_stride_head, const int32_t * slot_block, const int32_t * slot_off,
+                                  int n_tok, int n_head_kv, int head_dim, int block_size, void * stream);
 int pkv_pool_gather_rows(const void * pool, int type, int is_v, void * rows, const int32_t * slot_block,
                          const int32_t * slot_off, int n_tok, int n_head_kv, int head_dim, int block_size,
                          void * stream);

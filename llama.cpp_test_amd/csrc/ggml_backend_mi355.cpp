@@ -1,0 +1,313 @@
+// ggml_backend_mi355.cpp — ggml-backend plugin (GGML_BACKEND_API_VERSION 1) over the C ABI of libmi355_paged_kv.so.
+//
+// Boundary (b1) of SURVEY.md §8: exports `ggml_backend_init` / `ggml_backend_score`
+// (/ref/ggml/src/ggml-backend-impl.h:215-251) so that the reference's registry loads it through GGML_BACKEND_PATH
+// (/ref/ggml/src/ggml-backend-reg.cpp:581-585) and its own `test-backend-ops` harness can drive our kernels against
+// the reference's CPU backend (/ref/tests/test-backend-ops.cpp:4574-4592, ggml_backend_compare_graph_backend).
+// The object graph (reg -> device -> buffer type -> buffer / backend) is static and owned by the plugin.
+//
+// Compiled ONLY where the reference's headers exist (dev container): -I/root/reference/ggml/{include,src}; nothing
+// of the reference is copied.  Tensors in our buffers hold the reference's own bytes (plain f32 / f16 / block_q8_0 /
+// block_q4_0), exactly what ggml_backend_tensor_set/get move; ops convert to the private paged pool layout on the fly:
+//   GGML_OP_FLASH_ATTN_EXT  K/V views -> pkv_pool_scatter_rows_strided (identity block table) -> pkv_attn_decode
+//                           (1 query, no mask) or pkv_attn_prefill (general mask / ALiBi / softcap, non-causal)
+//   GGML_OP_ROPE(_BACK)     pkv_rope_f32_strided      (f32, NORM / NEOX)
+//   GGML_OP_CPY             pkv_convert_f32           (f32 -> f16 / q8_0 / q4_0, contiguous)
+//   view ops                no-ops
+// Everything else is reported unsupported, so the scheduler keeps it on another backend.
+#include "ggml-backend-impl.h"
+#include "ggml-backend.h"
+#include "ggml.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mi355_paged_kv.h"
+
+#define MI355_LOG(...) fprintf(stderr, "ggml-mi355: " __VA_ARGS__)
+
+namespace {
+
+constexpr int BLOCK = 128;
+
+struct buffer_ctx { void * base; };
+struct backend_ctx {
+    hipStream_t stream = nullptr;
+    void *      scratch = nullptr;
+    size_t      scratch_size = 0;
+    void * arena(size_t bytes) {  // grow-only device scratch for the per-op pools / tables / workspace
+        if (bytes > scratch_size) {
+            (void) hipStreamSynchronize(stream);
+            if (scratch) (void) hipFree(scratch);
+            scratch = nullptr;
+            scratch_size = 0;
+            if (hipMalloc(&scratch, bytes + (bytes >> 2)) != hipSuccess) return nullptr;
+            scratch_size = bytes + (bytes >> 2);
+        }
+        return scratch;
+    }
+};
+
+bool kv_type(ggml_type t) { return t == GGML_TYPE_F16 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0; }
+
+// ---- buffer ------------------------------------------------------------------------------------------------------------
+void buf_free(ggml_backend_buffer_t b) {
+    auto * c = (buffer_ctx *) b->context;
+    (void) hipFree(c->base);
+    delete c;
+}
+void * buf_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->context)->base; }
+void buf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t n) {
+    (void) hipMemset((char *) t->data + off, v, n);
+}
+void buf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t n) {
+    (void) hipMemcpy((char *) t->data + off, d, n, hipMemcpyHostToDevice);
+}
+void buf_get(ggml_backend_buffer_t, const ggml_tensor * t, void * d, size_t off, size_t n) {
+    (void) hipDeviceSynchronize();
+    (void) hipMemcpy(d, (const char *) t->data + off, n, hipMemcpyDeviceToHost);
+}
+void buf_clear(ggml_backend_buffer_t b, uint8_t v) { (void) hipMemset(((buffer_ctx *) b->context)->base, v, b->size); }
+
+const ggml_backend_buffer_i BUFFER_IFACE = {
+    /* free_buffer   */ buf_free,
+    /* get_base      */ buf_base,
+    /* init_tensor   */ nullptr,
+    /* memset_tensor */ buf_memset,
+    /* set_tensor    */ buf_set,
+    /* get_tensor    */ buf_get,
+    /* cpy_tensor    */ nullptr,
+    /* clear         */ buf_clear,
+    /* reset         */ nullptr,
+};
+
+// ---- buffer type ---------------------------------------------------------------------------------------------------------
+const char * buft_name(ggml_backend_buffer_type_t) { return "MI355"; }
+ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
+    void * p = nullptr;
+    if (hipMalloc(&p, size ? size : 1) != hipSuccess) { MI355_LOG("hipMalloc(%zu) failed\n", size); return nullptr; }
+    (void) hipMemset(p, 0, size ? size : 1);
+    return ggml_backend_buffer_init(buft, BUFFER_IFACE, new buffer_ctx{p}, size);
+}
+size_t buft_align(ggml_backend_buffer_type_t) { return 256; }
+
+// ---- ops -------------------------------------------------------------------------------------------------------------------
+bool supports_flash_attn(const ggml_tensor * op) {
+    const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * m = op->src[3];
+    if (!q || !k || !v || q->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+    if (!kv_type(k->type) || !kv_type(v->type)) return false;
+    const int64_t D = q->ne[0];
+    if ((D != 64 && D != 128) || k->ne[0] != D || v->ne[0] != D) return false;
+    if (q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return false;
+    if (k->ne[2] <= 0 || q->ne[2] % k->ne[2] != 0 || v->ne[2] != k->ne[2] || v->ne[1] != k->ne[1]) return false;
+    const int64_t g = q->ne[2] / k->ne[2];
+    if (g != 1 && g != 2 && g != 4 && g != 8) return false;
+    if (q->nb[0] != sizeof(float) || q->nb[1] % 16 || q->nb[2] % 16) return false;
+    if (k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type)) return false;
+    if (!ggml_is_contiguous(op)) return false;
+    if (m && (m->type != GGML_TYPE_F16 || !ggml_is_contiguous(m) || m->ne[0] != k->ne[1] || m->ne[1] < q->ne[1])) return false;
+    float max_bias;
+    memcpy(&max_bias, (const float *) op->op_params + 1, sizeof(float));
+    if (max_bias > 0.0f && !m) return false;
+    return true;
+}
+
+ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
+    const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * m = op->src[3];
+    float scale, max_bias, softcap;
+    memcpy(&scale, (const float *) op->op_params + 0, sizeof(float));
+    memcpy(&max_bias, (const float *) op->op_params + 1, sizeof(float));
+    memcpy(&softcap, (const float *) op->op_params + 2, sizeof(float));
+    const int D = (int) q->ne[0], n_q = (int) q->ne[1], n_head = (int) q->ne[2], n_kv = (int) k->ne[1], n_head_kv = (int) k->ne[2];
+    const int n_blocks = (n_kv + BLOCK - 1) / BLOCK;
+    const size_t kb = pkv_pool_bytes(k->type, n_blocks, n_head_kv, BLOCK, D), vb = pkv_pool_bytes(v->type, n_blocks, n_head_kv, BLOCK, D);
+    const size_t wsb = pkv_attn_workspace_bytes(n_q, n_head, D, n_kv, BLOCK);
+    const size_t meta = ((size_t) n_blocks + 4) * sizeof(int32_t);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+    char * base = (char *) bc->arena(up(kb) + up(vb) + up(wsb) + up(meta));
+    if (!base) return GGML_STATUS_ALLOC_FAILED;
+    char * kp = base, * vp = kp + up(kb), * ws = vp + up(vb);
+    int32_t * tab = (int32_t *) (ws + up(wsb));
+    std::vector<int32_t> h(n_blocks + 3);
+    for (int i = 0; i < n_blocks; ++i) h[i] = i;            // identity block table
+    h[n_blocks] = n_kv; h[n_blocks + 1] = 0; h[n_blocks + 2] = n_q;  // seq_lens[1], q_start[2]
+    if (hipMemcpyAsync(tab, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, bc->stream) != hipSuccess) return GGML_STATUS_FAILED;
+    (void) hipStreamSynchronize(bc->stream);               // h is a stack-frame object
+    // the pools are private scratch: clear them so that the tail of the last block is finite
+    (void) hipMemsetAsync(kp, 0, up(kb) + up(vb), bc->stream);
+    int rc = pkv_pool_scatter_rows_strided(kp, k->type, 0, k->data, (int64_t) k->nb[1], (int64_t) k->nb[2], nullptr, nullptr, n_kv,
+                                           n_head_kv, D, BLOCK, bc->stream);
+    if (!rc) rc = pkv_pool_scatter_rows_strided(vp, v->type, 1, v->data, (int64_t) v->nb[1], (int64_t) v->nb[2], nullptr, nullptr,
+                                                n_kv, n_head_kv, D, BLOCK, bc->stream);
+    pkv_attn_args a = {};
+    a.q = (const float *) q->data; a.q_stride_tok = (int64_t) (q->nb[1] / sizeof(float)); a.q_stride_head = (int64_t) (q->nb[2] / sizeof(float));
+    a.out = (float *) op->data; a.k_pool = kp; a.v_pool = vp; a.block_table = tab; a.seq_lens = tab + n_blocks;
+    a.workspace = ws; a.workspace_bytes = wsb;
+    a.n_seq = 1; a.n_tok = n_q; a.max_q_per_seq = n_q; a.n_head = n_head; a.n_head_kv = n_head_kv; a.head_dim = D;
+    a.block_size = BLOCK; a.max_blocks = n_blocks; a.type_k = k->type; a.type_v = v->type;
+    a.scale = scale; a.logit_softcap = softcap; a.max_seq_len = n_kv;
+    if (!rc) {
+        if (n_q == 1 && !m) {
+            rc = pkv_attn_decode(&a, bc->stream);          // the split-KV decode kernel (causal by length == all cells)
+        } else {
+            a.q_start = tab + n_blocks + 1;
+            a.flags = PKV_ATTN_NONCAUSAL;
+            a.mask = m ? m->data : nullptr; a.mask_stride = m ? (int64_t) m->ne[0] : 0; a.max_bias = max_bias;
+            rc = pkv_attn_prefill(&a, bc->stream);
+        }
+    }
+    if (rc) { MI355_LOG("flash_attn_ext failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+    return GGML_STATUS_SUCCESS;
+}
+
+bool rope_params(const ggml_tensor * op, pkv_rope_params * rp) {
+    const int32_t * p = (const int32_t *) op->op_params;
+    rp->n_dims = p[1]; rp->mode = p[2]; rp->n_ctx_orig = p[4];
+    memcpy(&rp->freq_base, p + 5, 4);  memcpy(&rp->freq_scale, p + 6, 4);  memcpy(&rp->ext_factor, p + 7, 4);
+    memcpy(&rp->attn_factor, p + 8, 4); memcpy(&rp->beta_fast, p + 9, 4); memcpy(&rp->beta_slow, p + 10, 4);
+    rp->freq_factors = op->src[2] ? (const float *) op->src[2]->data : nullptr;
+    return rp->mode == 0 || rp->mode == GGML_ROPE_TYPE_NEOX;
+}
+bool supports_rope(const ggml_tensor * op) {
+    const ggml_tensor * x = op->src[0];
+    pkv_rope_params rp;
+    if (!x || x->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !rope_params(op, &rp)) return false;
+    if (x->ne[3] != 1 || x->nb[0] != sizeof(float) || !ggml_is_contiguous(op) || x->ne[0] % 2) return false;
+    if (op->src[2] && (op->src[2]->type != GGML_TYPE_F32 || op->src[2]->ne[0] < rp.n_dims / 2)) return false;
+    return rp.n_dims > 0 && rp.n_dims % 2 == 0 && rp.n_dims <= x->ne[0];
+}
+ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
+    const ggml_tensor * x = op->src[0];
+    pkv_rope_params rp;
+    rope_params(op, &rp);
+    const int rc = pkv_rope_f32_strided((const float *) x->data, (int64_t) (x->nb[2] / 4), (int64_t) (x->nb[1] / 4),
+                                        (const int32_t *) op->src[1]->data, (float *) op->data, (int) x->ne[2], (int) x->ne[1],
+                                        (int) x->ne[0], &rp, back ? 1 : 0, bc->stream);
+    if (rc) { MI355_LOG("rope failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+    return GGML_STATUS_SUCCESS;
+}
+
+bool supports_cpy(const ggml_tensor * op) {
+    const ggml_tensor * s = op->src[0], * d = op->src[1];
+    return s && d && s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) &&
+           ggml_nelements(s) == ggml_nelements(d) && s->ne[0] == d->ne[0] && s->ne[0] % 64 == 0;
+}
+ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
+    const ggml_tensor * s = op->src[0];
+    ggml_tensor * d = op->src[1];
+    const int rc = pkv_convert_f32((const float *) s->data, d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
+    if (rc) { MI355_LOG("cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+    return GGML_STATUS_SUCCESS;
+}
+
+// ---- backend -----------------------------------------------------------------------------------------------------------------
+const char * be_name(ggml_backend_t) { return "MI355"; }
+void be_free(ggml_backend_t b) {
+    auto * c = (backend_ctx *) b->context;
+    if (c->scratch) (void) hipFree(c->scratch);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+    delete b;
+}
+void be_sync(ggml_backend_t b) { (void) hipStreamSynchronize(((backend_ctx *) b->context)->stream); }
+ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
+    auto * bc = (backend_ctx *) b->context;
+    (void) hipDeviceSynchronize();  // set_tensor uses the null stream
+    for (int i = 0; i < ggml_graph_n_nodes(g); ++i) {
+        ggml_tensor * n = ggml_graph_node(g, i);
+        ggml_status st = GGML_STATUS_SUCCESS;
+        switch (n->op) {
+            case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
+            case GGML_OP_FLASH_ATTN_EXT: st = run_flash_attn(bc, n); break;
+            case GGML_OP_ROPE:           st = run_rope(bc, n, false); break;
+            case GGML_OP_ROPE_BACK:      st = run_rope(bc, n, true); break;
+            case GGML_OP_CPY:            st = run_cpy(bc, n); break;
+            default: MI355_LOG("op %s reached graph_compute but is not supported\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
+        }
+        if (st != GGML_STATUS_SUCCESS) return st;
+    }
+    (void) hipStreamSynchronize(bc->stream);
+    return GGML_STATUS_SUCCESS;
+}
+const ggml_backend_i BACKEND_IFACE = {
+    /* get_name           */ be_name,
+    /* free               */ be_free,
+    /* set_tensor_async   */ nullptr,
+    /* get_tensor_async   */ nullptr,
+    /* cpy_tensor_async   */ nullptr,
+    /* synchronize        */ be_sync,
+    /* graph_plan_create  */ nullptr,
+    /* graph_plan_free    */ nullptr,
+    /* graph_plan_update  */ nullptr,
+    /* graph_plan_compute */ nullptr,
+    /* graph_compute      */ be_graph_compute,
+    /* event_record       */ nullptr,
+    /* event_wait         */ nullptr,
+};
+ggml_guid_t be_guid() {
+    static ggml_guid guid = {0x6d, 0x69, 0x33, 0x35, 0x35, 0x78, 0x2d, 0x70, 0x61, 0x67, 0x65, 0x64, 0x2d, 0x6b, 0x76, 0x01};
+    return &guid;
+}
+
+// ---- device / registry -----------------------------------------------------------------------------------------------------
+ggml_backend_buffer_type BUFT;   // filled in by reg()
+ggml_backend_device      DEVICE;
+ggml_backend_reg         REG;
+
+const char * dev_name(ggml_backend_dev_t) { return "MI355"; }
+const char * dev_desc(ggml_backend_dev_t) { return "AMD Instinct MI355X (gfx950) paged-KV attention path"; }
+void dev_memory(ggml_backend_dev_t, size_t * free, size_t * total) {
+    if (hipMemGetInfo(free, total) != hipSuccess) { *free = 0; *total = 0; }
+}
+enum ggml_backend_dev_type dev_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+void dev_props(ggml_backend_dev_t dev, ggml_backend_dev_props * p) {
+    p->name = dev_name(dev); p->description = dev_desc(dev); p->type = dev_type(dev);
+    dev_memory(dev, &p->memory_free, &p->memory_total);
+    p->caps = {/* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false};
+}
+ggml_backend_t dev_init(ggml_backend_dev_t dev, const char *) {
+    auto * bc = new backend_ctx;
+    if (hipStreamCreate(&bc->stream) != hipSuccess) { delete bc; return nullptr; }
+    return new ggml_backend{be_guid(), BACKEND_IFACE, dev, bc};
+}
+ggml_backend_buffer_type_t dev_buft(ggml_backend_dev_t) { return &BUFT; }
+bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return true;
+        case GGML_OP_FLASH_ATTN_EXT: return supports_flash_attn(op);
+        case GGML_OP_ROPE: case GGML_OP_ROPE_BACK: return supports_rope(op);
+        case GGML_OP_CPY: return supports_cpy(op);
+        default: return false;
+    }
+}
+bool dev_supports_buft(ggml_backend_dev_t, ggml_backend_buffer_type_t buft) { return buft == &BUFT; }
+
+const char * reg_name(ggml_backend_reg_t) { return "MI355"; }
+size_t reg_count(ggml_backend_reg_t) { return pkv_device_count() > 0 ? 1 : 0; }
+ggml_backend_dev_t reg_dev(ggml_backend_reg_t, size_t i) { return i == 0 ? &DEVICE : nullptr; }
+void * reg_proc(ggml_backend_reg_t, const char *) { return nullptr; }
+
+ggml_backend_reg_t reg() {
+    static bool once = false;
+    if (!once) {
+        once = true;
+        BUFT   = {{buft_name, buft_alloc, buft_align, /* get_max_size */ nullptr, /* get_alloc_size */ nullptr, /* is_host */ nullptr}, &DEVICE, nullptr};
+        DEVICE = {{dev_name, dev_desc, dev_memory, dev_type, dev_props, dev_init, dev_buft, /* host buft */ nullptr,
+                   /* buffer_from_host_ptr */ nullptr, dev_supports_op, dev_supports_buft, /* offload_op */ nullptr,
+                   /* event_new */ nullptr, /* event_free */ nullptr, /* event_synchronize */ nullptr},
+                  &REG, nullptr};
+        REG    = {GGML_BACKEND_API_VERSION, {reg_name, reg_count, reg_dev, reg_proc}, nullptr};
+    }
+    return &REG;
+}
+
+}  // namespace
+
+extern "C" {
+__attribute__((visibility("default"))) ggml_backend_reg_t ggml_backend_init(void) { return reg(); }
+__attribute__((visibility("default"))) int ggml_backend_score(void) { return pkv_device_count() > 0 ? 100 : 0; }
+}

@@ -85,6 +85,22 @@ int pkv_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, i
     return launch_rope_f32(x, pos, out, n_tok, n_head, head_dim, r, inverse, (hipStream_t) stream);
 }
 
+int pkv_rope_f32_strided(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, float * out, int n_tok,
+                         int n_head, int head_dim, const pkv_rope_params * rope, int inverse, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && pos && out && n_tok >= 0 && n_head > 0 && head_dim > 0 && head_dim % 2 == 0 && xs_tok > 0 && xs_head > 0,
+                "pkv_rope_f32_strided: bad arguments");
+    RopeDev r;
+    if (int rc = make_rope(rope, head_dim, &r)) return rc;
+    return launch_rope_f32(x, pos, out, n_tok, n_head, head_dim, r, inverse, (hipStream_t) stream, xs_tok, xs_head);
+}
+
+int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && dst && n_rows >= 0 && ne0 > 0 && kv_type_ok(type), "pkv_convert_f32: bad arguments");
+    return launch_convert_rows(x, dst, type, n_rows, ne0, (hipStream_t) stream);
+}
+
 int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
                  const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
                  const pkv_rope_params * rope, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {
@@ -181,6 +197,15 @@ int pkv_pool_scatter_rows(void * pool, int type, int is_v, const void * rows, co
     PKV_REQUIRE(pool && rows && slot_block && slot_off && n_tok >= 0 && kv_type_ok(type), "pkv_pool_scatter_rows: bad arguments");
     return launch_rows_io(pool, type, is_v, const_cast<void *>(rows), slot_block, slot_off, n_tok, n_head_kv, head_dim, block_size,
                           true, (hipStream_t) stream);
+}
+int pkv_pool_scatter_rows_strided(void * pool, int type, int is_v, const void * rows, int64_t rs_tok, int64_t rs_head,
+                                  const int32_t * slot_block, const int32_t * slot_off, int n_tok, int n_head_kv,
+                                  int head_dim, int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(pool && rows && n_tok >= 0 && kv_type_ok(type) && rs_tok > 0 && rs_head > 0 && (!slot_block || slot_off),
+                "pkv_pool_scatter_rows_strided: bad arguments");
+    return launch_rows_io(pool, type, is_v, const_cast<void *>(rows), slot_block, slot_off, n_tok, n_head_kv, head_dim, block_size,
+                          true, (hipStream_t) stream, rs_tok, rs_head);
 }
 int pkv_pool_gather_rows(const void * pool, int type, int is_v, void * rows, const int32_t * slot_block,
                          const int32_t * slot_off, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {

@@ -52,7 +52,7 @@ struct RopeDev {  // pkv_rope_params resolved on the host (corr dims = ggml_rope
 int make_rope(const pkv_rope_params * p, int head_dim, RopeDev * out);
 
 int launch_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, int n_head, int D,
-                    const RopeDev & r, int inverse, hipStream_t st);
+                    const RopeDev & r, int inverse, hipStream_t st, int64_t xs_tok = 0, int64_t xs_head = 0);
 int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * v_cur, void * k_pool, void * v_pool,
                     int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
                     const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st);
@@ -68,6 +68,7 @@ int launch_copy_blocks(void * pool, size_t block_bytes, const int32_t * src, con
 int launch_copy_cells(void * pool, int type, int is_v, const int32_t * sb, const int32_t * so, const int32_t * db,
                       const int32_t * dof, int n, int n_head_kv, int D, int block_size, hipStream_t st);
 int launch_rows_io(void * pool, int type, int is_v, void * rows, const int32_t * slot_block, const int32_t * slot_off, int n_tok,
-                   int n_head_kv, int D, int block_size, bool scatter, hipStream_t st);
+                   int n_head_kv, int D, int block_size, bool scatter, hipStream_t st, int64_t rs_tok = 0, int64_t rs_head = 0);
+int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);
 
 }  // namespace pkv

@@ -72,9 +72,9 @@ __device__ __forceinline__ float2 rope_row(float2 x, int lane, int pos, const Ro
 }
 
 __global__ void __launch_bounds__(64) rope_f32_kernel(const float * x, const int32_t * pos, float * out, int n_head,
-                                                      int D, const RopeDev r, float sin_sign) {
+                                                      int D, const RopeDev r, float sin_sign, int64_t xs_tok, int64_t xs_head) {
     const int t = blockIdx.y, h = blockIdx.x;
-    const float * src = x + ((size_t) t * n_head + h) * D;
+    const float * src = x + (size_t) t * xs_tok + (size_t) h * xs_head;
     float *       dst = out + ((size_t) t * n_head + h) * D;
     const int p = pos[t];
     const bool neox = r.mode & 2;
@@ -331,13 +331,16 @@ __global__ void __launch_bounds__(64) k_shift_kernel(char * k_pool, const int32_
 // grid (n_head_kv, n_tok): reference-format rows <-> tiles
 template <int T, bool IS_V, bool SCATTER, int D>
 __global__ void __launch_bounds__(64) rows_io_kernel(char * pool, char * rows, const int32_t * slot_block,
-                                                     const int32_t * slot_off, int n_head_kv, int block_size) {
+                                                     const int32_t * slot_off, int n_head_kv, int block_size,
+                                                     int64_t rs_tok, int64_t rs_head) {
     const int h = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
-    if (slot_block[t] < 0) return;
-    char * tile = pool + ((size_t) slot_block[t] * n_head_kv + h) * tile_bytes(T, block_size, D);
-    char * row  = rows + ((size_t) t * n_head_kv + h) * row_size(T, D);
-    if (SCATTER) tile_write<T, IS_V>(tile, slot_off[t], lane, ref_read<T>(row, lane, D), block_size, D);
-    else         ref_write<T>(row, lane, tile_read<T, IS_V>(tile, slot_off[t], lane, block_size, D), D);
+    // slot_block == NULL: identity mapping, token t lives in block t / block_size at offset t % block_size
+    const int blk = slot_block ? slot_block[t] : t / block_size, off = slot_block ? slot_off[t] : t % block_size;
+    if (blk < 0) return;
+    char * tile = pool + ((size_t) blk * n_head_kv + h) * tile_bytes(T, block_size, D);
+    char * row  = rows + (size_t) t * rs_tok + (size_t) h * rs_head;
+    if (SCATTER) tile_write<T, IS_V>(tile, off, lane, ref_read<T>(row, lane, D), block_size, D);
+    else         ref_write<T>(row, lane, tile_read<T, IS_V>(tile, off, lane, block_size, D), D);
 }
 
 // grid (n_head_kv, n_cells): move single cells between blocks (seq_cp of unaligned ranges, defrag)
@@ -384,9 +387,10 @@ int make_rope(const pkv_rope_params * p, int head_dim, RopeDev * out) {
 }
 
 int launch_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, int n_head, int D, const RopeDev & r,
-                    int inverse, hipStream_t st) {
+                    int inverse, hipStream_t st, int64_t xs_tok, int64_t xs_head) {
     if (n_tok == 0) return PKV_OK;
-    hipLaunchKernelGGL(rope_f32_kernel, dim3(n_head, n_tok), dim3(64), 0, st, x, pos, out, n_head, D, r, inverse ? -1.0f : 1.0f);
+    if (xs_tok == 0) { xs_tok = (int64_t) n_head * D; xs_head = D; }
+    hipLaunchKernelGGL(rope_f32_kernel, dim3(n_head, n_tok), dim3(64), 0, st, x, pos, out, n_head, D, r, inverse ? -1.0f : 1.0f, xs_tok, xs_head);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
@@ -490,32 +494,62 @@ int launch_copy_cells(void * pool, int type, int is_v, const int32_t * sb, const
 
 template <int T, bool IS_V, bool SC>
 static int rows_d(void * pool, void * rows, const int32_t * sb, const int32_t * so, int n_tok, int n_head_kv, int D,
-                  int block_size, hipStream_t st) {
+                  int block_size, hipStream_t st, int64_t rs_tok, int64_t rs_head) {
     dim3 grid(n_head_kv, n_tok);
-    if (D == 128)     hipLaunchKernelGGL((rows_io_kernel<T, IS_V, SC, 128>), grid, dim3(64), 0, st, (char *) pool, (char *) rows, sb, so, n_head_kv, block_size);
-    else if (D == 64) hipLaunchKernelGGL((rows_io_kernel<T, IS_V, SC, 64>), grid, dim3(64), 0, st, (char *) pool, (char *) rows, sb, so, n_head_kv, block_size);
+    if (rs_tok == 0) { rs_head = (int64_t) row_size(T, D); rs_tok = rs_head * n_head_kv; }
+    if (D == 128)     hipLaunchKernelGGL((rows_io_kernel<T, IS_V, SC, 128>), grid, dim3(64), 0, st, (char *) pool, (char *) rows, sb, so, n_head_kv, block_size, rs_tok, rs_head);
+    else if (D == 64) hipLaunchKernelGGL((rows_io_kernel<T, IS_V, SC, 64>), grid, dim3(64), 0, st, (char *) pool, (char *) rows, sb, so, n_head_kv, block_size, rs_tok, rs_head);
     else { set_error("row I/O: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
 template <int T>
 static int rows_t(void * pool, void * rows, const int32_t * sb, const int32_t * so, int n_tok, int n_head_kv, int D,
-                  int block_size, bool is_v, bool scatter, hipStream_t st) {
-    if (is_v) return scatter ? rows_d<T, true, true>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st)
-                             : rows_d<T, true, false>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st);
-    return scatter ? rows_d<T, false, true>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st)
-                   : rows_d<T, false, false>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st);
+                  int block_size, bool is_v, bool scatter, hipStream_t st, int64_t rs_tok, int64_t rs_head) {
+    if (is_v) return scatter ? rows_d<T, true, true>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st, rs_tok, rs_head)
+                             : rows_d<T, true, false>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st, rs_tok, rs_head);
+    return scatter ? rows_d<T, false, true>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st, rs_tok, rs_head)
+                   : rows_d<T, false, false>(pool, rows, sb, so, n_tok, n_head_kv, D, block_size, st, rs_tok, rs_head);
 }
 
 int launch_rows_io(void * pool, int type, int is_v, void * rows, const int32_t * slot_block, const int32_t * slot_off,
-                   int n_tok, int n_head_kv, int D, int block_size, bool scatter, hipStream_t st) {
+                   int n_tok, int n_head_kv, int D, int block_size, bool scatter, hipStream_t st, int64_t rs_tok, int64_t rs_head) {
     if (n_tok == 0) return PKV_OK;
     switch (type) {
-        case PKV_TYPE_F16:  return rows_t<PKV_TYPE_F16>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st);
-        case PKV_TYPE_Q8_0: return rows_t<PKV_TYPE_Q8_0>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st);
-        case PKV_TYPE_Q4_0: return rows_t<PKV_TYPE_Q4_0>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st);
+        case PKV_TYPE_F16:  return rows_t<PKV_TYPE_F16>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st, rs_tok, rs_head);
+        case PKV_TYPE_Q8_0: return rows_t<PKV_TYPE_Q8_0>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st, rs_tok, rs_head);
+        case PKV_TYPE_Q4_0: return rows_t<PKV_TYPE_Q4_0>(pool, rows, slot_block, slot_off, n_tok, n_head_kv, D, block_size, is_v, scatter, st, rs_tok, rs_head);
     }
     return PKV_ERR_UNSUPPORTED;
+}
+
+// f32 rows -> reference-format bytes (what GGML_OP_CPY f32 -> f16/q8_0/q4_0 stores, /ref/ggml/src/ggml-cpu/ggml-cpu.c:3742):
+// grid (ne0 / CH, n_rows), one wave per CH-element chunk of a row
+template <int T, int CH>
+__global__ void __launch_bounds__(64) convert_rows_kernel(const float * x, char * dst, int64_t ne0) {
+    const int64_t row = blockIdx.y;
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (2 * lane < CH) v = *reinterpret_cast<const float2 *>(x + row * ne0 + (int64_t) ch * CH + 2 * lane);
+    ref_write<T>(dst + row * (int64_t) row_size(T, ne0) + (int64_t) ch * row_size(T, CH), lane, quantize<T>(v, lane), CH);
+}
+
+int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st) {
+    if (n_rows == 0) return PKV_OK;
+    const int CH = ne0 % 128 == 0 ? 128 : 64;
+    if (ne0 % 64 != 0) { set_error("convert: row length %lld is not a multiple of 64", (long long) ne0); return PKV_ERR_UNSUPPORTED; }
+    dim3 grid((unsigned) (ne0 / CH), (unsigned) n_rows);
+#define PKV_CVT(T) do { if (CH == 128) hipLaunchKernelGGL((convert_rows_kernel<T, 128>), grid, dim3(64), 0, st, x, (char *) dst, ne0); \
+                        else           hipLaunchKernelGGL((convert_rows_kernel<T, 64>), grid, dim3(64), 0, st, x, (char *) dst, ne0); } while (0)
+    switch (type) {
+        case PKV_TYPE_F16:  PKV_CVT(PKV_TYPE_F16); break;
+        case PKV_TYPE_Q8_0: PKV_CVT(PKV_TYPE_Q8_0); break;
+        case PKV_TYPE_Q4_0: PKV_CVT(PKV_TYPE_Q4_0); break;
+        default: return PKV_ERR_UNSUPPORTED;
+    }
+#undef PKV_CVT
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
 }
 
 }  // namespace pkv
