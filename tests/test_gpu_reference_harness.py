@@ -1,0 +1,28 @@
+"""-m gpu: the REFERENCE's own parity harness (tests/test-backend-ops.cpp, compiled in place into oracle/_ref by
+`make -C oracle ref`) driving our kernels through the ggml-backend plugin (llama.cpp_test_amd/libggml-mi355.so, loaded
+via GGML_BACKEND_PATH exactly as ggml_backend_load_all does, /root/reference/ggml/src/ggml-backend-reg.cpp:581-585).
+Every case our device reports as supported must pass the harness's own criterion (NMSE vs the reference CPU backend:
+5e-4 for FLASH_ATTN_EXT, 1e-7 for ROPE, 1e-6 for CPY).  Skipped where the prebuilt binaries did not travel."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TBO = os.path.join(ROOT, "oracle", "_ref", "test-backend-ops")
+PLUGIN = os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so")
+
+
+@pytest.mark.skipif(not (os.path.exists(TBO) and os.path.exists(PLUGIN)), reason="oracle/_ref/test-backend-ops or the plugin not built")
+@pytest.mark.parametrize("op,min_ok", [("FLASH_ATTN_EXT", 300), ("ROPE", 60), ("ROPE_BACK", 60), ("CPY", 3)])
+def test_reference_harness(op, min_ok):
+    env = dict(os.environ, GGML_BACKEND_PATH=PLUGIN)
+    r = subprocess.run([TBO, "test", "-o", op], env=env, capture_output=True, text=True, timeout=900)
+    out = re.sub(r"\x1b\[[0-9;]*m", "", r.stdout + r.stderr)
+    assert "Backend MI355: OK" in out, out[-2000:]
+    ok = len(re.findall(rf"{op}\(.*\): OK", out))
+    assert "FAIL" not in out
+    assert ok >= min_ok, (ok, out[-1000:])
+    assert r.returncode == 0
