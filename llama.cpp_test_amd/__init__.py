@@ -295,7 +295,10 @@ class PagedKVCache:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().pkv_cache_free(C.c_void_p(self._h))
+            try:
+                lib().pkv_cache_free(C.c_void_p(self._h))
+            except TypeError:          # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     __del__ = close

@@ -79,59 +79,87 @@ struct DecodeArgs {
     float scale, softcap;
 };
 
-// Q fragment for one lane: f16 path = E halfs per head; quantized path = E int8 per head + f16-rounded block scale
+// Q operand of QK^T.  It is converted ONCE per workgroup into LDS (f16 for f16 K — GGML_FP32_TO_FP16 of the reference's
+// q_to_vec_dot; q8_0 for quantized K — quantize_row_q8_0 as the reference's CPU backend runs it for Q, AVX2 branch,
+// /ref/ggml/src/ggml-cpu/ggml-cpu-quants.c:808-862: d = amax/127 stored as f16, id = 127/amax, round-half-even), one
+// element per thread, and every lane then reads the fragment that matches its 16-byte K chunk.
+template <int KT, int D, int G> struct QShared;
+template <int D, int G> struct QShared<PKV_TYPE_F16, D, G> { _Float16 h[G][D]; };
+template <int KT, int D, int G> struct QSharedQ { signed char qs[G][D]; float d[G][D / PKV_QK]; int qsum[G][D / PKV_QK]; };
+template <int D, int G> struct QShared<PKV_TYPE_Q8_0, D, G> : QSharedQ<PKV_TYPE_Q8_0, D, G> {};
+template <int D, int G> struct QShared<PKV_TYPE_Q4_0, D, G> : QSharedQ<PKV_TYPE_Q4_0, D, G> {};
+
+template <int D, int G, int NT> struct QRaw { float x[(G * D + NT - 1) / NT]; };
+
+// the global load of Q is issued BEFORE the KV stream (vmcnt retires in order: a Q load queued behind sixteen tile loads
+// would only return after all of them), its conversion and the LDS hand-off then run while the KV loads are in flight
+template <int D, int G, int NT>
+__device__ __forceinline__ void q_load(QRaw<D, G, NT> & r, const float * q, int64_t stride_head, int tid) {
+#pragma unroll
+    for (int i = 0; i < (G * D + NT - 1) / NT; ++i) {
+        const int e = (G * D) % NT == 0 ? i * NT + tid : min(i * NT + tid, G * D - 1);   // unconditional, in-bounds load
+        r.x[i] = q[(e / D) * stride_head + e % D];
+    }
+}
+template <int KT, int D, int G, int NT>
+__device__ __forceinline__ void q_to_lds(QShared<KT, D, G> & sq, const QRaw<D, G, NT> & r, int tid) {
+    static_assert(D % 32 == 0 && NT % 32 == 0, "a 32-element block must map onto 32 consecutive lanes");
+#pragma unroll
+    for (int i = 0; i < (G * D + NT - 1) / NT; ++i) {
+        const int e = i * NT + tid;
+        const bool live = e < G * D;
+        const int g = live ? e / D : 0, d = live ? e % D : 0;
+        const float x = r.x[i];
+        if constexpr (KT == PKV_TYPE_F16) {
+            if (live) sq.h[g][d] = (_Float16) x;
+        } else {
+            float amax = fabsf(x);
+            amax = fmaxf(amax, dpp_mov<0xB1>(amax)); amax = fmaxf(amax, dpp_mov<0x4E>(amax));
+            amax = fmaxf(amax, dpp_mov<0x141>(amax)); amax = fmaxf(amax, dpp_mov<0x140>(amax));
+            amax = fmaxf(amax, __shfl_xor(amax, 16));                         // 32 lanes = one 32-element block
+            const float dd = amax / 127.0f;
+            const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+            const int   v  = (int) __builtin_rintf(x * id);
+            int sum = v;
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+            sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
+            if (live) {
+                sq.qs[g][d] = (signed char) v;
+                if ((d & 31) == 0) { sq.d[g][d / PKV_QK] = (float) (_Float16) dd; sq.qsum[g][d / PKV_QK] = sum; }
+            }
+        }
+    }
+}
+
+// per-lane fragment: f16 path = 8 halfs per head; quantized path = E int8 per head + f16-rounded block scale (+ block sum)
 template <int KT, int D, int G> struct QFrag;
 template <int D, int G> struct QFrag<PKV_TYPE_F16, D, G> {
     half2_t h[G][4];
-    __device__ __forceinline__ void load(const float * q, int64_t stride_head, int kc) {
+    __device__ __forceinline__ void load(const QShared<PKV_TYPE_F16, D, G> & sq, int kc) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const float4 a = *reinterpret_cast<const float4 *>(q + g * stride_head + kc * 8);
-            const float4 b = *reinterpret_cast<const float4 *>(q + g * stride_head + kc * 8 + 4);
-            h[g][0] = half2_t{(_Float16) a.x, (_Float16) a.y};  // RN-even == GGML_FP32_TO_FP16
-            h[g][1] = half2_t{(_Float16) a.z, (_Float16) a.w};
-            h[g][2] = half2_t{(_Float16) b.x, (_Float16) b.y};
-            h[g][3] = half2_t{(_Float16) b.z, (_Float16) b.w};
+            const uint4 v = *reinterpret_cast<const uint4 *>(&sq.h[g][kc * 8]);
+            h[g][0] = *reinterpret_cast<const half2_t *>(&v.x); h[g][1] = *reinterpret_cast<const half2_t *>(&v.y);
+            h[g][2] = *reinterpret_cast<const half2_t *>(&v.z); h[g][3] = *reinterpret_cast<const half2_t *>(&v.w);
         }
     }
 };
-// quantize_row_q8_0 as the reference's CPU backend does it for Q (AVX2 branch,
-// /ref/ggml/src/ggml-cpu/ggml-cpu-quants.c:808-862): d = amax/127 (stored as f16), id = 127/amax, round-half-even.
 template <int KT, int D, int G> struct QFragQ {
     static constexpr int E  = KTr<KT, D>::E;   // 16 (q8_0 K) or 32 (q4_0 K) elements per lane
     static constexpr int NW = E / 4;
     int   qs[G][NW];
     float d[G];
     int   qsum[G];  // sum of the block's int8 (q4_0 K needs it for the -8 offset)
-    __device__ __forceinline__ void load(const float * q, int64_t stride_head, int kc) {
+    __device__ __forceinline__ void load(const QShared<KT, D, G> & sq, int kc) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float x[E];
 #pragma unroll
-            for (int j = 0; j < E / 4; ++j) {
-                const float4 a = *reinterpret_cast<const float4 *>(q + g * stride_head + kc * E + j * 4);
-                x[j * 4 + 0] = a.x; x[j * 4 + 1] = a.y; x[j * 4 + 2] = a.z; x[j * 4 + 3] = a.w;
+            for (int w = 0; w < NW; w += 4) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&sq.qs[g][kc * E + w * 4]);
+                qs[g][w] = (int) v.x; qs[g][w + 1] = (int) v.y; qs[g][w + 2] = (int) v.z; qs[g][w + 3] = (int) v.w;
             }
-            float amax = 0.0f;
-#pragma unroll
-            for (int j = 0; j < E; ++j) amax = fmaxf(amax, fabsf(x[j]));
-            if (E == 16) amax = fmaxf(amax, dpp_mov<0xB1>(amax));  // the 32-block spans two lanes
-            const float dd = amax / 127.0f;
-            const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
-            d[g] = (float) (_Float16) dd;
-            int sum = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                int pk = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int v = (int) __builtin_rintf(x[w * 4 + b] * id);
-                    sum += v;
-                    pk |= (v & 0xFF) << (8 * b);
-                }
-                qs[g][w] = pk;
-            }
-            qsum[g] = sum;  // only read by the q4_0-K dot, where the lane holds the whole 32-block
+            d[g]    = sq.d[g][kc * E / PKV_QK];
+            qsum[g] = sq.qsum[g][kc * E / PKV_QK];
         }
     }
 };
@@ -268,6 +296,10 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(VT, a.block_size, D);
     const int n_valid = min(WG_TOK, seq_len - base);  // >= 1
 
+    QRaw<D, G, NT> qraw;
+    q_load<D, G, NT>(qraw, a.q + (size_t) s * a.q_stride_tok + (size_t) hk * G * a.q_stride_head, a.q_stride_head, tid);
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- every K and V load of the lane is issued up front, unconditionally: rows past the end of the sequence are
     //      clamped to the last valid row (in bounds, finite) and removed later by the mask / p = 0 ------------------
     const int kr = lane / K_LPR, kc = lane % K_LPR;
@@ -303,9 +335,12 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
 
     __builtin_amdgcn_sched_barrier(0);  // keep the KV stream ahead of everything else in program order
 
-    // ---- Q fragment (L2-resident, 16 KiB for the whole launch) ----------------------------------------------------
+    // ---- Q: converted once per workgroup into LDS (while the KV stream is in flight), then one fragment per lane ----
+    __shared__ __attribute__((aligned(16))) QShared<KT, D, G> sQ;
+    q_to_lds<KT, D, G, NT>(sQ, qraw, tid);
+    __syncthreads();
     QFrag<KT, D, G> qf;
-    qf.load(a.q + (size_t) s * a.q_stride_tok + (size_t) hk * G * a.q_stride_head, a.q_stride_head, kc);
+    qf.load(sQ, kc);
 
     // ---- QK^T: per-lane partial dots, then a DPP reduce-scatter: every lane ends with NVF finished logits ---------
     float x[NV];
@@ -472,11 +507,12 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
 }
 
 // merge the per-block partials: out = sum_j O_j e^{m_j - M} / sum_j l_j e^{m_j - M}.
-// One workgroup per (sequence, query head); the split weights are computed once (thread j <-> split j) and shared
-// through LDS so that the D threads then stream their column with independent loads.
+// One workgroup per (sequence, query head), thread d owns output column d.  The kernel is pure latency (a few KB per
+// workgroup), so every load it will ever need — this thread's column of up to CH partials AND the (m, l) pairs — is
+// issued before the first dependent instruction: one memory round trip instead of two.
 template <int D>
 __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
-    constexpr int CH = D;  // splits handled per pass (ctx 16384 -> 128 splits = one pass at D = 128)
+    constexpr int CH = 32;  // splits per pass (ctx 4096 = one pass)
     __shared__ float sW[CH];
     __shared__ float sRed[2][D / 64];
     const int h = blockIdx.x, s = blockIdx.y, d = threadIdx.x, wave = d >> 6, lane = d & 63;
@@ -486,7 +522,10 @@ __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
     if (ns <= 0) { o[d] = 0.0f; return; }
     const float * ml = a.part_ml + ((size_t) s * a.n_head + h) * a.n_splits * 2;
     const float * po = a.part_o + ((size_t) s * a.n_head + h) * a.n_splits * D;
-    // global max over all splits
+    // first pass of columns + every (m, l): all in flight together
+    float pv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) pv[u] = po[(size_t) min(u, ns - 1) * D + d];
     float m = -INFINITY;
     for (int j = d; j < ns; j += D) m = fmaxf(m, ml[j * 2]);
     m = wave_max(m);
@@ -497,27 +536,22 @@ __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
     for (int w = 1; w < D / 64; ++w) M = fmaxf(M, sRed[0][w]);
     float L = 0.0f, acc = 0.0f;
     for (int j0 = 0; j0 < ns; j0 += CH) {
-        const int j = j0 + d;
-        float w = 0.0f, lw = 0.0f;
-        if (j < ns) {
-            const float2 v = *reinterpret_cast<const float2 *>(ml + j * 2);
-            w  = v.x == -INFINITY ? 0.0f : __expf(v.x - M);
-            lw = v.y * w;
+        const int n = min(CH, ns - j0);
+        if (j0 > 0) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) pv[u] = po[(size_t) (j0 + min(u, n - 1)) * D + d];
+        }
+        float w = 0.0f;
+        if (d < n) {
+            const float2 v = *reinterpret_cast<const float2 *>(ml + (size_t) (j0 + d) * 2);
+            w = v.x == -INFINITY ? 0.0f : __expf(v.x - M);
+            L = fmaf(v.y, w, L);
         }
         __syncthreads();  // previous pass finished reading sW
-        sW[d] = w;
-        L += lw;
+        if (d < CH) sW[d] = w;
         __syncthreads();
-        const int n = min(CH, ns - j0);
-        int jj = 0;
-        for (; jj + 8 <= n; jj += 8) {  // 8 independent loads in flight per thread
-            float pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = po[(size_t) (j0 + jj + u) * D + d];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(pv[u], sW[jj + u], acc);
-        }
-        for (; jj < n; ++jj) acc = fmaf(po[(size_t) (j0 + jj) * D + d], sW[jj], acc);
+        for (int u = 0; u < CH; ++u) acc = u < n ? fmaf(pv[u], sW[u], acc) : acc;
     }
     L = wave_sum(L);
     if (lane == 0) sRed[1][wave] = L;
