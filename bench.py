@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 
 METRIC = "decode tok/s + KV-gather HBM GB/s (% of peak), Llama-3-8B Q4_K ctx=4096"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-GEOM = dict(n_layer=32, n_head=32, n_head_kv=8, head_dim=128, block_size=128)
+GEOM = dict(n_layer=32, n_head=32, n_head_kv=8, head_dim=128, block_size=128)          # Llama-3-8B (the headline config)
+GEOM_70B = dict(n_layer=80, n_head=64, n_head_kv=8, head_dim=128, block_size=128)     # Llama-3-70B (BASELINE config 5)
 
 
 def algorithmic_bytes(n_kv: int, type_k: int, type_v: int, pkv, g=GEOM) -> int:
@@ -170,6 +171,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=4096)
     ap.add_argument("--n-seq", type=int, default=1, help="sequences per GPU (1 = BASELINE config 2)")
     ap.add_argument("--kv-type", default="f16", choices=["f16", "q8_0", "q4_0"])
+    ap.add_argument("--model", default="8b", choices=["8b", "70b"], help="geometry: 8b = headline config, 70b = BASELINE config 5 (use --ctx 16384)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-merge", action="store_true",
@@ -195,7 +197,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     t = pkv.TYPE_BY_NAME[args.kv_type]
-    w = Workload(pkv, torch, ctx=args.ctx, n_seq=args.n_seq, type_k=t, type_v=t, seed=1234 + rank)
+    g = GEOM if args.model == "8b" else GEOM_70B
+    w = Workload(pkv, torch, ctx=args.ctx, n_seq=args.n_seq, type_k=t, type_v=t, seed=1234 + rank, g=g)
     w.step_flags = pkv.ATTN_FUSED_COMBINE if args.fused_merge else 0
 
     # one decode step = 32 layers x (fused RoPE(Q)+RoPE(K)+KV store, split-KV attention, merge); captured once, replayed per step
@@ -233,20 +236,20 @@ def main():
 
     traffic = None
     try:   # PMC traffic cannot be collected from inside the run: taken from the committed rocprofv3 passes, if this workload has one
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{args.kv_type}_ctx{args.ctx}_nseq{args.n_seq}")
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{args.kv_type}_ctx{args.ctx}_nseq{args.n_seq}") if args.model == "8b" else None
     except Exception:
         pass
     tok_s = world * args.n_seq * args.steps / dt
-    bytes_launch = args.n_seq * algorithmic_bytes(args.ctx, t, t, pkv)
+    bytes_launch = args.n_seq * algorithmic_bytes(args.ctx, t, t, pkv, g)
     achieved = bytes_launch / k_mean / 1e9
     line = {
         "metric": METRIC, "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.kv_type if args.kv_type != "f16" else "f16",
         "data": "synthetic",
-        "config": {"workload": f"Llama-3-8B geometry, {args.n_seq} seq/GPU, ctx {args.ctx} paged decode "
-                               f"(block_size 128, {args.kv_type} KV), attention path of all 32 layers per token",
-                   "n_layer": 32, "n_head": 32, "n_head_kv": 8, "head_dim": 128, "block_size": 128, "ctx": args.ctx,
+        "config": {"workload": f"Llama-3-{args.model.upper()} geometry, {args.n_seq} seq/GPU, ctx {args.ctx} paged decode "
+                               f"(block_size 128, {args.kv_type} KV), attention path of all {g['n_layer']} layers per token",
+                   "n_layer": g["n_layer"], "n_head": g["n_head"], "n_head_kv": g["n_head_kv"], "head_dim": 128, "block_size": 128, "ctx": args.ctx,
                    "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "eager" if graph is None else "hipGraph", "merge": "in-kernel (last-arriving workgroup)" if args.fused_merge else "second launch",
                    "parallelism": f"replicas x{world} (no collective on the data path)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
