@@ -190,11 +190,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU (the paged-KV path has no CPU fallback)")
+    shared = world > n_dev                      # rehearsal only: more ranks than GPUs on this box -> ranks share a device
+    torch.cuda.set_device(local % n_dev)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PKV_BENCH_FORCE_DIST"):
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # one process per GPU; RCCL ("nccl") carries only the barrier and the max-time reduction — the data path has no
+        # collective.  Ranks that share a device (rehearsal) cannot form an RCCL communicator: gloo then.
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % n_dev))
 
     t = pkv.TYPE_BY_NAME[args.kv_type]
     g = GEOM if args.model == "8b" else GEOM_70B
@@ -228,7 +237,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
 
