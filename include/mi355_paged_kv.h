@@ -274,6 +274,24 @@ void pkv_toy_kvm_free  (pkv_toy_kv_manager * m);
 int  pkv_toy_kvm_insert(pkv_toy_kv_manager * m, int * physical_block, int * slot); /* VirtualBlockEntry */
 int  pkv_toy_kvm_release(pkv_toy_kv_manager * m, int physical_block, int slot);
 
+/* BlockKVCache + block_kv_attention toys (/ref/tests/test_block_kv_cache.cpp, test_block_kv_attention.cpp,
+ * test_paged_attention.cpp): host float storage, block element count be = block_size*num_kv_heads*head_size */
+typedef struct pkv_toy_block_kv_cache pkv_toy_block_kv_cache;
+pkv_toy_block_kv_cache * pkv_toy_bkc_create(int num_blocks, int block_size, int num_kv_heads, int head_size);
+void pkv_toy_bkc_free(pkv_toy_block_kv_cache * c);
+void pkv_toy_bkc_init_cache(pkv_toy_block_kv_cache * c);
+void pkv_toy_bkc_write_to_cache(pkv_toy_block_kv_cache * c, const float * k, const float * v, const int * slot_mapping, int n);
+void pkv_toy_bkc_swap_blocks(pkv_toy_block_kv_cache * c, pkv_toy_block_kv_cache * other, const int * mapping, int n);
+void pkv_toy_bkc_copy_blocks(pkv_toy_block_kv_cache * c, const pkv_toy_block_kv_cache * src, const int * mapping, int n);
+int  pkv_toy_bkc_insert_kv_block(pkv_toy_block_kv_cache * c, const float * k, const float * v, int * physical_block, int * slot);
+int  pkv_toy_bkc_free_kv_block(pkv_toy_block_kv_cache * c, int physical_block, int slot);
+int  pkv_toy_bkc_get(const pkv_toy_block_kv_cache * c, int which_v, float * out, int cap);   /* getKeyCache / getValueCache */
+void pkv_toy_attention_fwd(const float * q, int n, pkv_toy_block_kv_cache * c, const float * k, const float * v,
+                           const int * slot_mapping, int n_map, float * out);               /* blockKVAttentionFwd      */
+void pkv_toy_attention_paged_fwd(const float * q, int n, pkv_toy_block_kv_cache * c, const float * k, const float * v,
+                                 float * out, int page_size);                               /* blockKVAttentionPagedFwd */
+void pkv_toy_attention_real_fwd(const float * q, int n, const float * k, const float * v, float * out); /* ...RealFwd   */
+
 #ifdef __cplusplus
 }
 #endif

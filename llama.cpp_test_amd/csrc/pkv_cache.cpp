@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <set>
 
 namespace pkv {
@@ -45,6 +46,72 @@ bool ToyKvManager::release(int block, int slot) {
     if (block < 0 || (size_t) block >= blocks_.size() || slot < 0 || slot >= cap_) return false;
     blocks_[block][slot] = false;
     return true;
+}
+
+ToyBlockKVCache::ToyBlockKVCache(size_t num_blocks, size_t block_size, size_t num_kv_heads, size_t head_size)
+    : num_blocks_(num_blocks), be_(block_size * num_kv_heads * head_size), mgr_((int) num_blocks) {}
+void ToyBlockKVCache::initCache() {
+    key_.assign(num_blocks_ * be_, 0.0f);
+    value_.assign(num_blocks_ * be_, 0.0f);
+}
+void ToyBlockKVCache::writeToCache(const float * k, const float * v, const std::vector<int> & map) {
+    for (size_t i = 0; i < map.size(); ++i) {
+        const int slot = map[i];
+        if (slot < 0 || (size_t) slot >= num_blocks_ || ((size_t) slot + 1) * be_ > key_.size()) continue;
+        std::copy(k + i * be_, k + (i + 1) * be_, key_.begin() + (size_t) slot * be_);
+        std::copy(v + i * be_, v + (i + 1) * be_, value_.begin() + (size_t) slot * be_);
+    }
+}
+void ToyBlockKVCache::swapBlocks(ToyBlockKVCache & o, const std::vector<int> & map) {
+    for (size_t i = 0; i < map.size(); ++i) {
+        const int j = map[i];
+        if (i >= num_blocks_ || j < 0 || (size_t) j >= o.num_blocks_) continue;
+        std::swap_ranges(key_.begin() + i * be_, key_.begin() + (i + 1) * be_, o.key_.begin() + (size_t) j * be_);
+        std::swap_ranges(value_.begin() + i * be_, value_.begin() + (i + 1) * be_, o.value_.begin() + (size_t) j * be_);
+    }
+}
+void ToyBlockKVCache::copyBlocks(const ToyBlockKVCache & src, const std::vector<int> & map) {
+    for (int idx : map) {
+        if (idx < 0 || (size_t) idx >= num_blocks_ || (size_t) idx >= src.num_blocks_) continue;
+        std::copy(src.key_.begin() + (size_t) idx * be_, src.key_.begin() + ((size_t) idx + 1) * be_, key_.begin() + (size_t) idx * be_);
+        std::copy(src.value_.begin() + (size_t) idx * be_, src.value_.begin() + ((size_t) idx + 1) * be_, value_.begin() + (size_t) idx * be_);
+    }
+}
+void ToyBlockKVCache::splitKVCache(const std::vector<float> & kv, std::vector<float> & k, std::vector<float> & v) {
+    const size_t h = kv.size() / 2;
+    k.assign(kv.begin(), kv.begin() + h);
+    v.assign(kv.begin() + h, kv.begin() + 2 * h);
+}
+bool ToyBlockKVCache::insertKVBlock(const float * k, const float * v, int * pb, int * slot) {
+    // the prototype sizes storage BEFORE KVCacheManager::insert() may append a block and then writes out of bounds on the
+    // insert that grows it (test_kv_cache.cpp:44); here storage follows the manager, the indices are the same
+    if (!mgr_.insert(pb, slot)) return false;
+    const size_t need = (size_t) mgr_.n_blocks() * num_blocks_ * be_;  // slot capacity == num_blocks
+    if (key_.size() < need) { key_.resize(need, 0.0f); value_.resize(need, 0.0f); }
+    const size_t at = ((size_t) *pb * num_blocks_ + (size_t) *slot) * be_;
+    std::copy(k, k + be_, key_.begin() + at);
+    std::copy(v, v + be_, value_.begin() + at);
+    return true;
+}
+bool ToyBlockKVCache::freeKVBlock(int pb, int slot) { return mgr_.release(pb, slot); }
+
+void toyBlockKVAttentionFwd(const float * q, size_t n, ToyBlockKVCache & c, const float * k, const float * v,
+                            const std::vector<int> & map, float * out) {
+    c.writeToCache(k, v, map);
+    std::copy(q, q + n, out);
+}
+void toyBlockKVAttentionPagedFwd(const float * q, size_t n, ToyBlockKVCache & c, const float * k, const float * v, float * out,
+                                 size_t page) {
+    for (size_t s = 0; s < n; s += page) toyBlockKVAttentionFwd(q + s, std::min(page, n - s), c, k, v, {0}, out + s);
+}
+void toyBlockKVAttentionRealFwd(const float * q, size_t n, const float * k, const float * v, float * out) {
+    for (size_t i = 0; i < n; ++i) {
+        float sc[4], m = -3.0e38f, sum = 0.0f;
+        for (int j = 0; j < 4; ++j) { sc[j] = q[i] * k[j]; m = std::max(m, sc[j]); }
+        for (int j = 0; j < 4; ++j) { sc[j] = std::exp(sc[j] - m); sum += sc[j]; }
+        out[i] = 0.0f;
+        for (int j = 0; j < 4; ++j) out[i] += sc[j] / sum * v[j];
+    }
 }
 
 // ---- paged cache ---------------------------------------------------------------------------------------------------

@@ -36,6 +36,34 @@ class ToyKvManager {
     std::vector<std::vector<bool>> blocks_;
 };
 
+// ---- fork prototype: BlockKVCache (test_kv_cache.cpp, test_block_kv_cache.cpp) + the block_kv_attention toys -----
+// float-only host storage, exactly the prototype's semantics; be = block_size*heads*head_size
+class ToyBlockKVCache {
+  public:
+    ToyBlockKVCache(size_t num_blocks, size_t block_size, size_t num_kv_heads, size_t head_size);
+    void initCache();                                                          // zero-fill num_blocks * be
+    void writeToCache(const float * k, const float * v, const std::vector<int> & slot_mapping);  // block i of input -> slot map[i]
+    void swapBlocks(ToyBlockKVCache & other, const std::vector<int> & mapping);    // this block i <-> other block map[i]
+    void copyBlocks(const ToyBlockKVCache & src, const std::vector<int> & mapping); // same-index copy src[idx] -> this[idx]
+    static void splitKVCache(const std::vector<float> & kv, std::vector<float> & k, std::vector<float> & v);
+    bool insertKVBlock(const float * k, const float * v, int * physical_block, int * slot);
+    bool freeKVBlock(int physical_block, int slot);
+    const std::vector<float> & getKeyCache() const { return key_; }
+    const std::vector<float> & getValueCache() const { return value_; }
+    size_t blockElems() const { return be_; }
+  private:
+    size_t num_blocks_, be_;
+    std::vector<float> key_, value_;
+    ToyKvManager mgr_;
+};
+// blockKVAttentionFwd: writeToCache + copy(query -> output); PagedFwd: page by page with mapping {0};
+// RealFwd: per query scalar q_i, scores q_i*k[j] (j < 4), max-subtracted softmax, out_i = sum p_j v[j]
+void toyBlockKVAttentionFwd(const float * q, size_t n, ToyBlockKVCache & c, const float * k, const float * v,
+                            const std::vector<int> & slot_mapping, float * out);
+void toyBlockKVAttentionPagedFwd(const float * q, size_t n, ToyBlockKVCache & c, const float * k, const float * v, float * out,
+                                 size_t page_size);
+void toyBlockKVAttentionRealFwd(const float * q, size_t n, const float * k, const float * v, float * out);
+
 // ---- the paged cache ------------------------------------------------------------------------------------------
 // device work queued by host edits, executed IN ORDER by pkv_cache_update: whole-block copies (copy-on-write)
 // and single-cell copies (seq_cp of unaligned ranges, defrag)

@@ -50,6 +50,7 @@ struct pkv_cache {
 };
 struct pkv_toy_block_manager { ToyBlockManager bm; explicit pkv_toy_block_manager(int n) : bm(n) {} };
 struct pkv_toy_kv_manager    { ToyKvManager m;     explicit pkv_toy_kv_manager(int c) : m(c) {} };
+struct pkv_toy_block_kv_cache { ToyBlockKVCache c; pkv_toy_block_kv_cache(int nb, int bs, int h, int d) : c(nb, bs, h, d) {} };
 
 extern "C" {
 
@@ -398,5 +399,39 @@ pkv_toy_kv_manager * pkv_toy_kvm_create(int cap) { return new pkv_toy_kv_manager
 void pkv_toy_kvm_free(pkv_toy_kv_manager * m) { delete m; }
 int  pkv_toy_kvm_insert(pkv_toy_kv_manager * m, int * b, int * s) { return m && m->m.insert(b, s) ? 0 : -1; }
 int  pkv_toy_kvm_release(pkv_toy_kv_manager * m, int b, int s) { return m && m->m.release(b, s) ? 0 : -1; }
+
+pkv_toy_block_kv_cache * pkv_toy_bkc_create(int nb, int bs, int h, int d) { return nb > 0 && bs > 0 && h > 0 && d > 0 ? new pkv_toy_block_kv_cache(nb, bs, h, d) : nullptr; }
+void pkv_toy_bkc_free(pkv_toy_block_kv_cache * c) { delete c; }
+void pkv_toy_bkc_init_cache(pkv_toy_block_kv_cache * c) { if (c) c->c.initCache(); }
+void pkv_toy_bkc_write_to_cache(pkv_toy_block_kv_cache * c, const float * k, const float * v, const int * m, int n) {
+    if (c) c->c.writeToCache(k, v, std::vector<int>(m, m + n));
+}
+void pkv_toy_bkc_swap_blocks(pkv_toy_block_kv_cache * c, pkv_toy_block_kv_cache * o, const int * m, int n) {
+    if (c && o) c->c.swapBlocks(o->c, std::vector<int>(m, m + n));
+}
+void pkv_toy_bkc_copy_blocks(pkv_toy_block_kv_cache * c, const pkv_toy_block_kv_cache * src, const int * m, int n) {
+    if (c && src) c->c.copyBlocks(src->c, std::vector<int>(m, m + n));
+}
+int pkv_toy_bkc_insert_kv_block(pkv_toy_block_kv_cache * c, const float * k, const float * v, int * pb, int * slot) {
+    return c && c->c.insertKVBlock(k, v, pb, slot) ? 0 : -1;
+}
+int pkv_toy_bkc_free_kv_block(pkv_toy_block_kv_cache * c, int pb, int slot) { return c && c->c.freeKVBlock(pb, slot) ? 0 : -1; }
+int pkv_toy_bkc_get(const pkv_toy_block_kv_cache * c, int which_v, float * out, int cap) {
+    if (!c) return 0;
+    const auto & x = which_v ? c->c.getValueCache() : c->c.getKeyCache();
+    for (int i = 0; i < (int) x.size() && i < cap; ++i) out[i] = x[i];
+    return (int) x.size();
+}
+void pkv_toy_attention_fwd(const float * q, int n, pkv_toy_block_kv_cache * c, const float * k, const float * v, const int * m,
+                           int nm, float * out) {
+    if (c) toyBlockKVAttentionFwd(q, (size_t) n, c->c, k, v, std::vector<int>(m, m + nm), out);
+}
+void pkv_toy_attention_paged_fwd(const float * q, int n, pkv_toy_block_kv_cache * c, const float * k, const float * v, float * out,
+                                 int page) {
+    if (c && page > 0) toyBlockKVAttentionPagedFwd(q, (size_t) n, c->c, k, v, out, (size_t) page);
+}
+void pkv_toy_attention_real_fwd(const float * q, int n, const float * k, const float * v, float * out) {
+    toyBlockKVAttentionRealFwd(q, (size_t) n, k, v, out);
+}
 
 }  // extern "C"

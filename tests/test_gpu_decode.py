@@ -186,3 +186,30 @@ def test_decode_fused_merge_matches_two_launch(pkv, O, tk):
                            max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
     torch.cuda.synchronize()
     assert np.abs(out2.cpu().numpy() - base2).max() <= 2e-6
+
+
+def test_decode_matches_non_flash_attention_path(pkv, O):
+    """`-fa 0` graphs (/root/reference/src/llama-graph.cpp:1201-1239): kq = mul_mat(k, q) -> soft_max_ext(kq, mask, scale) ->
+    mul_mat(v, kq).  Same attention, different op sequence; the reference's own soft_max kernel (oracle/_ref) supplies the
+    probabilities where it was shipped, numpy otherwise."""
+    rng = np.random.default_rng(77)
+    D, nh, nkv, n = 128, 8, 2, 700
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=[n], D=D, n_head=nh, n_head_kv=nkv, type_k=1, type_v=1)
+    q = rng.uniform(-1, 1, (1, nh, D)).astype(np.float32)
+    got = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=nkv, tk=1, tv=1)[0]
+    K = O.to_float(1, O.pool_gather(kp, 1, 0, bt[0], n, D=D, block_size=128), D)        # [nkv][n][D]
+    V = O.to_float(1, O.pool_gather(vp, 1, 1, bt[0], n, D=D, block_size=128), D)
+    qh = q[0].astype(np.float16).astype(np.float32)                                      # mul_mat converts the f32 operand to f16
+    kq = np.einsum("hnd,hd->hn", np.repeat(K, nh // nkv, 0), qh).astype(np.float32)
+    if O.ref_available():
+        lib = O.ref()
+        probs = np.empty_like(kq)
+        import ctypes as C
+        rc = lib.ref_soft_max_ext(kq.ctypes.data_as(C.c_void_p), None, probs.ctypes.data_as(C.c_void_p), n, nh, 0,
+                                  C.c_float(D ** -0.5), C.c_float(0.0), 1)
+        assert rc == 0
+    else:
+        z = kq * np.float32(D ** -0.5)
+        probs = np.exp(z - z.max(1, keepdims=True)); probs /= probs.sum(1, keepdims=True)
+    ref = np.einsum("hn,hnd->hd", probs.astype(np.float16).astype(np.float32), np.repeat(V, nh // nkv, 0))
+    assert np.abs(got - ref).max() <= 1e-3 and nmse(got, ref) <= 5e-4
