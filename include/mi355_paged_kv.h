@@ -88,6 +88,11 @@ int pkv_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok, i
 int pkv_rope_f32_strided(const float * x, int64_t x_stride_tok, int64_t x_stride_head, const int32_t * pos, float * out,
                          int n_tok, int n_head, int head_dim, const pkv_rope_params * rope, int inverse, void * stream);
 
+/* RoPE on an f16 tensor (strides in halfs): f16 in, f32 math, f16 out = ggml_compute_forward_rope_f16
+ * (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10855), the op build_rope_shift applies to an f16 K cache (/ref/src/llama-context.cpp:483-492) */
+int pkv_rope_f16_strided(const void * x, int64_t x_stride_tok, int64_t x_stride_head, const int32_t * pos, void * out,
+                         int n_tok, int n_head, int head_dim, const pkv_rope_params * rope, int inverse, void * stream);
+
 /* GGML_OP_CPY f32 -> f16/q8_0/q4_0 into a CONTIGUOUS typed tensor in the reference's own byte format
  * (ggml_compute_forward_dup_f32, /ref/ggml/src/ggml-cpu/ggml-cpu.c:3742): x f32 [n_rows][ne0], ne0 % 64 == 0. */
 int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, void * stream);

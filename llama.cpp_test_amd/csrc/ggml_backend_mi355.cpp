@@ -11,7 +11,7 @@
 // block_q4_0), exactly what ggml_backend_tensor_set/get move; ops convert to the private paged pool layout on the fly:
 //   GGML_OP_FLASH_ATTN_EXT  K/V views -> pkv_pool_scatter_rows_strided (identity block table) -> pkv_attn_decode
 //                           (1 query, no mask) or pkv_attn_prefill (general mask / ALiBi / softcap, non-causal)
-//   GGML_OP_ROPE(_BACK)     pkv_rope_f32_strided      (f32, NORM / NEOX)
+//   GGML_OP_ROPE(_BACK)     pkv_rope_f32_strided / pkv_rope_f16_strided (NORM / NEOX)
 //   GGML_OP_CPY             pkv_convert_f32           (f32 -> f16 / q8_0 / q4_0, contiguous)
 //   view ops                no-ops
 // Everything else is reported unsupported, so the scheduler keeps it on another backend.
@@ -175,8 +175,8 @@ bool rope_params(const ggml_tensor * op, pkv_rope_params * rp) {
 bool supports_rope(const ggml_tensor * op) {
     const ggml_tensor * x = op->src[0];
     pkv_rope_params rp;
-    if (!x || x->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !rope_params(op, &rp)) return false;
-    if (x->ne[3] != 1 || x->nb[0] != sizeof(float) || !ggml_is_contiguous(op) || x->ne[0] % 2) return false;
+    if (!x || (x->type != GGML_TYPE_F32 && x->type != GGML_TYPE_F16) || op->type != x->type || !rope_params(op, &rp)) return false;
+    if (x->ne[3] != 1 || x->nb[0] != ggml_type_size(x->type) || !ggml_is_contiguous(op) || x->ne[0] % 2) return false;
     if (op->src[2] && (op->src[2]->type != GGML_TYPE_F32 || op->src[2]->ne[0] < rp.n_dims / 2)) return false;
     return rp.n_dims > 0 && rp.n_dims % 2 == 0 && rp.n_dims <= x->ne[0];
 }
@@ -184,9 +184,12 @@ ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
     const ggml_tensor * x = op->src[0];
     pkv_rope_params rp;
     rope_params(op, &rp);
-    const int rc = pkv_rope_f32_strided((const float *) x->data, (int64_t) (x->nb[2] / 4), (int64_t) (x->nb[1] / 4),
-                                        (const int32_t *) op->src[1]->data, (float *) op->data, (int) x->ne[2], (int) x->ne[1],
-                                        (int) x->ne[0], &rp, back ? 1 : 0, bc->stream);
+    const int64_t es = (int64_t) ggml_type_size(x->type);
+    const int rc = x->type == GGML_TYPE_F32
+        ? pkv_rope_f32_strided((const float *) x->data, (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data,
+                               (float *) op->data, (int) x->ne[2], (int) x->ne[1], (int) x->ne[0], &rp, back ? 1 : 0, bc->stream)
+        : pkv_rope_f16_strided(x->data, (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data, op->data,
+                               (int) x->ne[2], (int) x->ne[1], (int) x->ne[0], &rp, back ? 1 : 0, bc->stream);
     if (rc) { MI355_LOG("rope failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
     return GGML_STATUS_SUCCESS;
 }

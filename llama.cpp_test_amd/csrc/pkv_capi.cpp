@@ -96,6 +96,16 @@ int pkv_rope_f32_strided(const float * x, int64_t xs_tok, int64_t xs_head, const
     return launch_rope_f32(x, pos, out, n_tok, n_head, head_dim, r, inverse, (hipStream_t) stream, xs_tok, xs_head);
 }
 
+int pkv_rope_f16_strided(const void * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, void * out, int n_tok,
+                         int n_head, int head_dim, const pkv_rope_params * rope, int inverse, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && pos && out && n_tok >= 0 && n_head > 0 && head_dim > 0 && head_dim % 2 == 0 && xs_tok > 0 && xs_head > 0,
+                "pkv_rope_f16_strided: bad arguments");
+    RopeDev r;
+    if (int rc = make_rope(rope, head_dim, &r)) return rc;
+    return launch_rope_f16(x, pos, out, n_tok, n_head, head_dim, r, inverse, (hipStream_t) stream, xs_tok, xs_head);
+}
+
 int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(x && dst && n_rows >= 0 && ne0 > 0 && kv_type_ok(type), "pkv_convert_f32: bad arguments");

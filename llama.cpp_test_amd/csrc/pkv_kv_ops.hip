@@ -71,20 +71,23 @@ __device__ __forceinline__ float2 rope_row(float2 x, int lane, int pos, const Ro
               : make_float2(rot1(px, x.x, c0.x, c0.y), rot1(py, x.y, c1.x, c1.y));
 }
 
-__global__ void __launch_bounds__(64) rope_f32_kernel(const float * x, const int32_t * pos, float * out, int n_head,
-                                                      int D, const RopeDev r, float sin_sign, int64_t xs_tok, int64_t xs_head) {
+// T = float (ggml_compute_forward_rope_f32) or _Float16 (ggml_compute_forward_rope_f16, :10855: f16 in, f32 math, f16 out —
+// what the reference's K-shift runs on an f16 cache, /ref/src/llama-context.cpp:483-492)
+template <typename T>
+__global__ void __launch_bounds__(64) rope_kernel(const T * x, const int32_t * pos, T * out, int n_head,
+                                                  int D, const RopeDev r, float sin_sign, int64_t xs_tok, int64_t xs_head) {
     const int t = blockIdx.y, h = blockIdx.x;
-    const float * src = x + (size_t) t * xs_tok + (size_t) h * xs_head;
-    float *       dst = out + ((size_t) t * n_head + h) * D;
+    const T * src = x + (size_t) t * xs_tok + (size_t) h * xs_head;
+    T *       dst = out + ((size_t) t * n_head + h) * D;
     const int p = pos[t];
     const bool neox = r.mode & 2;
     for (int ip = threadIdx.x; ip < D / 2; ip += 64) {
         if (2 * ip < r.n_dims) {
             const float2 cs = rope_cs(p, ip, r, sin_sign);
             const int i0 = neox ? ip : 2 * ip, i1 = neox ? ip + r.n_dims / 2 : 2 * ip + 1;
-            const float x0 = src[i0], x1 = src[i1];
-            dst[i0] = rot0(x0, x1, cs.x, cs.y);
-            dst[i1] = rot1(x0, x1, cs.x, cs.y);
+            const float x0 = (float) src[i0], x1 = (float) src[i1];
+            dst[i0] = (T) rot0(x0, x1, cs.x, cs.y);
+            dst[i1] = (T) rot1(x0, x1, cs.x, cs.y);
         } else {  // pass-through channels (:10841-10847)
             dst[2 * ip]     = src[2 * ip];
             dst[2 * ip + 1] = src[2 * ip + 1];
@@ -390,7 +393,17 @@ int launch_rope_f32(const float * x, const int32_t * pos, float * out, int n_tok
                     int inverse, hipStream_t st, int64_t xs_tok, int64_t xs_head) {
     if (n_tok == 0) return PKV_OK;
     if (xs_tok == 0) { xs_tok = (int64_t) n_head * D; xs_head = D; }
-    hipLaunchKernelGGL(rope_f32_kernel, dim3(n_head, n_tok), dim3(64), 0, st, x, pos, out, n_head, D, r, inverse ? -1.0f : 1.0f, xs_tok, xs_head);
+    hipLaunchKernelGGL(rope_kernel<float>, dim3(n_head, n_tok), dim3(64), 0, st, x, pos, out, n_head, D, r, inverse ? -1.0f : 1.0f, xs_tok, xs_head);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+
+int launch_rope_f16(const void * x, const int32_t * pos, void * out, int n_tok, int n_head, int D, const RopeDev & r,
+                    int inverse, hipStream_t st, int64_t xs_tok, int64_t xs_head) {
+    if (n_tok == 0) return PKV_OK;
+    if (xs_tok == 0) { xs_tok = (int64_t) n_head * D; xs_head = D; }
+    hipLaunchKernelGGL(rope_kernel<_Float16>, dim3(n_head, n_tok), dim3(64), 0, st, (const _Float16 *) x, pos, (_Float16 *) out, n_head,
+                       D, r, inverse ? -1.0f : 1.0f, xs_tok, xs_head);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
