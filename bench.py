@@ -73,6 +73,8 @@ class Workload:
         self.ws = pkv.attn_workspace(n_seq, H, D, ctx, BS)
         self.scale = D ** -0.5
         self.step_flags = 0
+        self.rope_cs = pkv.rope_cache(self.pos, self.rope, D)             # refreshed at the start of every step
+        self.fused_step = True     # pkv_attn_decode_step: RoPE(Q) + RoPE(K) + KV store inside the decode launch
 
     def _random_pool(self, t, gen):
         torch, pkv, g = self.torch, self.pkv, self.g
@@ -86,21 +88,29 @@ class Workload:
         scales = (torch.rand((nb, HK, BS * D // 32), generator=gen, device="cuda") * 0.01 + 0.001).to(torch.float16)
         return torch.cat([quants, scales.view(torch.uint8).reshape(nb, HK, -1)], dim=2).contiguous()
 
-    def layer_step(self, l, flags=None):
+    def layer_step(self, l, flags=None, events=None):
         flags = self.step_flags if flags is None else flags
         pkv, g = self.pkv, self.g
+        if self.fused_step:
+            pkv.attn_decode_step(self.q[l], self.k_cur[l], self.v_cur[l], self.pos, self.rope, self.k_pools[l], self.v_pools[l],
+                                 self.block_table, self.seq_lens, n_head_kv=g["n_head_kv"], type_k=self.tk, type_v=self.tv,
+                                 block_size=g["block_size"], scale=self.scale, max_seq_len=self.ctx, out=self.out[l],
+                                 workspace=self.ws, events=events, rope_cache=self.rope_cs)
+            return
         pkv.qkv_prepare(self.q[l], self.k_cur[l], self.v_cur[l], self.k_pools[l], self.v_pools[l], type_k=self.tk,
                         type_v=self.tv, slot_block=self.slot_block, slot_off=self.slot_off, block_size=g["block_size"],
                         pos=self.pos, rope=self.rope)
-        self.attn(l, flags)
+        self.attn(l, flags, events)
 
-    def attn(self, l, flags=0):
+    def attn(self, l, flags=0, events=None):
         pkv, g = self.pkv, self.g
         pkv.attn_decode(self.q[l], self.k_pools[l], self.v_pools[l], self.block_table, self.seq_lens,
                         n_head_kv=g["n_head_kv"], type_k=self.tk, type_v=self.tv, block_size=g["block_size"],
-                        scale=self.scale, max_seq_len=self.ctx, out=self.out[l], workspace=self.ws, flags=flags)
+                        scale=self.scale, max_seq_len=self.ctx, out=self.out[l], workspace=self.ws, flags=flags, events=events)
 
     def step(self):
+        if self.fused_step:   # ggml_rope_cache_init once per step: the (cos, sin) rows are the same for all layers
+            self.pkv.rope_cache(self.pos, self.rope, self.g["head_dim"], out=self.rope_cs)
         for l in range(self.g["n_layer"]):
             self.layer_step(l)
 
@@ -116,9 +126,10 @@ def measure_dominant_kernel(w: Workload, torch, reps: int):
     timer = pkv.KernelTimer(reps * L)
 
     def launch(l, ev=None):
-        pkv.attn_decode(w.q[l], w.k_pools[l], w.v_pools[l], w.block_table, w.seq_lens, n_head_kv=g["n_head_kv"],
-                        type_k=w.tk, type_v=w.tv, block_size=g["block_size"], scale=w.scale, max_seq_len=w.ctx,
-                        out=w.out[l], workspace=w.ws, flags=flags, events=ev)
+        if w.fused_step:
+            w.layer_step(l, events=ev)      # the decode-step kernel (+ its merge launch, which the events do not cover)
+        else:
+            w.attn(l, flags, ev)
     for l in range(L):
         launch(l)
     torch.cuda.synchronize()
@@ -177,6 +188,8 @@ def main():
     ap.add_argument("--fused-merge", action="store_true",
                     help="merge the split-KV partials inside the decode launch (last-arriving workgroup) instead of a second "
                          "launch; measured slower on MI355X (12.1 us vs 6.9 + 4.7 us), kept for comparison")
+    ap.add_argument("--two-call", action="store_true",
+                    help="pkv_qkv_prepare + pkv_attn_decode (three launches per layer) instead of the fused pkv_attn_decode_step")
     ap.add_argument("--kernel-reps", type=int, default=20)
     args = ap.parse_args()
 
@@ -209,6 +222,7 @@ def main():
     g = GEOM if args.model == "8b" else GEOM_70B
     w = Workload(pkv, torch, ctx=args.ctx, n_seq=args.n_seq, type_k=t, type_v=t, seed=1234 + rank, g=g)
     w.step_flags = pkv.ATTN_FUSED_COMBINE if args.fused_merge else 0
+    w.fused_step = not (args.two_call or args.fused_merge)
 
     # one decode step = 32 layers x (fused RoPE(Q)+RoPE(K)+KV store, split-KV attention, merge); captured once, replayed per step
     side = torch.cuda.Stream()
@@ -260,11 +274,12 @@ def main():
                                f"(block_size 128, {args.kv_type} KV), attention path of all {g['n_layer']} layers per token",
                    "n_layer": g["n_layer"], "n_head": g["n_head"], "n_head_kv": g["n_head_kv"], "head_dim": 128, "block_size": 128, "ctx": args.ctx,
                    "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "eager" if graph is None else "hipGraph", "merge": "in-kernel (last-arriving workgroup)" if args.fused_merge else "second launch",
+                   "step": "pkv_attn_decode_step (RoPE + KV store inside the decode launch) + merge" if w.fused_step else "pkv_qkv_prepare + pkv_attn_decode",
                    "parallelism": f"replicas x{world} (no collective on the data path)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
-                     "kernel": "pkv::attn_decode_kernel (split-KV paged decode, one launch per layer)",
+                     "kernel": "pkv::attn_decode_kernel (split-KV paged decode" + (", RoPE(Q,K) + KV store of the new token fused in" if w.fused_step else "") + "; one launch per layer)",
                      "algorithmic_bytes_per_launch": bytes_launch,
                      "kernel_us": {"mean": round(k_mean * 1e6, 3), "median": round(k_med * 1e6, 3), "min": round(k_min * 1e6, 3)},
                      "timing": "hipExtLaunchKernel start/stop events of each launch (GPU timestamps of the dispatch), layers cycled (cold KV)"},

@@ -164,6 +164,27 @@ size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq
 int    pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream);
 /* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks */
 int pkv_attn_decode(const pkv_attn_args * args, void * stream);
+/* One decode step of a layer in ONE launch (+ the merge): pkv_qkv_prepare + pkv_attn_decode fused, i.e. the whole
+ * ggml_rope_ext(Qcur) / ggml_rope_ext(Kcur) / ggml_cpy(Kcur, Vcur -> cache) / ggml_flash_attn_ext run of
+ * llm_build_llama + build_attn (/ref/src/llama-model.cpp:4091-4105, /ref/src/llama-graph.cpp:1367-1432) for a
+ * one-token-per-sequence micro-batch.  The new token of sequence s is cell seq_lens[s]-1 (its block must already be
+ * in block_table: find_slot ran).  Differences from the two calls: args->q is read un-rotated and NOT modified (the
+ * rotated Q goes straight into the QK^T operand), and the results are bit-identical to pkv_qkv_prepare +
+ * pkv_attn_decode, pools included.  PKV_ERR_UNSUPPORTED with softcap, slot_pos or merge flags (use the two calls). */
+typedef struct pkv_step_args {
+    const float *   k_cur;            /* device f32 [n_seq][n_head_kv][head_dim], this step's K rows, un-rotated  */
+    const float *   v_cur;            /* device f32 [n_seq][n_head_kv][head_dim]                                  */
+    const int32_t * pos;              /* device i32 [n_seq]: position of the new token (the RoPE angle); may be   */
+                                      /* NULL when rope_cache is given                                            */
+    const pkv_rope_params * rope;     /* NULL = no RoPE (Q and K are used as given)                               */
+    const float *   rope_cache;       /* optional pkv_rope_cache() rows of these tokens, device f32               */
+                                      /* [n_seq][head_dim/2][2]: computed ONCE per step and shared by all layers; */
+                                      /* NULL = the call builds them itself from (pos, rope) with one more launch */
+} pkv_step_args;
+/* ggml_rope_cache_init (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10595-10609) for a micro-batch: cache[t][i] = (cos, sin) * mscale
+ * of rotation pair i at pos[t] (identity past n_dims/2).  cache: device f32 [n_tok][head_dim/2][2], 16-byte aligned. */
+int pkv_rope_cache(const int32_t * pos, int n_tok, int head_dim, const pkv_rope_params * rope, float * cache, void * stream);
+int pkv_attn_decode_step(const pkv_attn_args * args, const pkv_step_args * step, void * stream);
 /* measurement aid: raw hipEvent_t handles for pkv_attn_args.ev_start / ev_stop */
 void * pkv_event_create(void);
 void   pkv_event_destroy(void * ev);

@@ -49,6 +49,11 @@ class RopeParams(C.Structure):
                 ("freq_factors", C.c_void_p)]
 
 
+class StepArgs(C.Structure):
+    _fields_ = [("k_cur", C.c_void_p), ("v_cur", C.c_void_p), ("pos", C.c_void_p), ("rope", C.POINTER(RopeParams)),
+                ("rope_cache", C.c_void_p)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("q_stride_tok", C.c_int64), ("q_stride_head", C.c_int64), ("out", C.c_void_p),
                 ("k_pool", C.c_void_p), ("v_pool", C.c_void_p), ("block_table", C.c_void_p), ("seq_lens", C.c_void_p),
@@ -183,7 +188,7 @@ def attn_workspace_bytes(n_tok: int, n_head: int, head_dim: int, max_seq_len: in
 
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
-          stream=None, flags=0, events=None, mask=None, max_bias=0.0):
+          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None):
     import torch
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
@@ -196,7 +201,12 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
                  n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
                  scale, logit_softcap, max_seq_len, flags, _ptr(mask), mask.stride(0) if mask is not None else 0, max_bias,
                  events[0] if events else None, events[1] if events else None)
-    check(fn(C.byref(a), C.c_void_p(_stream(stream))))
+    if step is not None:
+        k_cur, v_cur, pos, rope, rope_cache = step
+        st = StepArgs(_ptr(k_cur), _ptr(v_cur), _ptr(pos), C.pointer(rope) if rope is not None else None, _ptr(rope_cache))
+        check(fn(C.byref(a), C.byref(st), C.c_void_p(_stream(stream))))
+    else:
+        check(fn(C.byref(a), C.c_void_p(_stream(stream))))
     return out
 
 
@@ -213,6 +223,26 @@ def attn_decode(q, k_pool, v_pool, block_table, seq_lens, **kw):
     """Paged single-token decode: ggml_flash_attn_ext for one query per sequence
     (/root/reference/src/llama-graph.cpp:1187-1197).  q f32 [n_seq][n_head][D] -> out f32 [n_seq][n_head][D]."""
     return _attn(lib().pkv_attn_decode, q, k_pool, v_pool, block_table, seq_lens, **kw)
+
+
+def rope_cache(pos, rope: RopeParams, head_dim: int, *, out=None, stream=None):
+    """ggml_rope_cache_init for a micro-batch (pkv_rope_cache): f32 [n_tok][head_dim/2][2] (cos, sin) rows, computed once
+    per step and shared by every layer's attn_decode_step."""
+    import torch
+    n_tok = pos.shape[0]
+    out = torch.empty((n_tok, head_dim // 2, 2), dtype=torch.float32, device=pos.device) if out is None else out
+    check(lib().pkv_rope_cache(C.c_void_p(_ptr(pos)), n_tok, head_dim, C.byref(rope), C.c_void_p(_ptr(out)),
+                               C.c_void_p(_stream(stream))))
+    return out
+
+
+def attn_decode_step(q, k_cur, v_cur, pos, rope, k_pool, v_pool, block_table, seq_lens, *, rope_cache=None, **kw):
+    """One decode step of a layer in one launch: RoPE(Q) + RoPE(K) + KV store + paged decode (pkv_attn_decode_step).
+    q f32 [n_seq][n_head][D] un-rotated (left untouched), k_cur/v_cur f32 [n_seq][n_head_kv][D], pos i32 [n_seq];
+    the new token of sequence s is cell seq_lens[s]-1.  rope=None: no RoPE.  rope_cache: rows from rope_cache(pos, rope, D),
+    shared by all layers of the step (None: built per call)."""
+    return _attn(lib().pkv_attn_decode_step, q, k_pool, v_pool, block_table, seq_lens,
+                 step=(k_cur, v_cur, pos, rope, rope_cache), **kw)
 
 
 class KernelTimer:

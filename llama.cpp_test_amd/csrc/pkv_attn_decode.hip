@@ -18,6 +18,7 @@
 //           cross-lane-row and cross-wave sums, then one (m, l, O[G][D]) partial per workgroup.
 //   A second tiny kernel merges the per-block partials (flash-decoding).
 #include "pkv_common.h"
+#include "pkv_rowcodec.h"
 
 #include <hip/hip_ext.h>
 
@@ -77,6 +78,12 @@ struct DecodeArgs {
     unsigned *      counters; // [n_seq][n_head_kv] arrival tickets (fused merge), zero between launches
     int   n_head, n_head_kv, block_size, max_blocks, n_splits, bs_shift;  // block_size = WG_TOK << bs_shift
     float scale, softcap;
+    // fused decode step (PREP): this step's un-rotated K / V rows, the new token's position, RoPE
+    const float *   k_cur;    // [n_seq][n_head_kv][D]
+    const float *   v_cur;
+    const float4 *  rope_cache;  // [n_seq][D/2] (cos, sin): pkv_rope_cache rows of the new tokens, NULL = no RoPE
+    int             has_rope;
+    RopeDev         rope;
 };
 
 // Q operand of QK^T.  It is converted ONCE per workgroup into LDS (f16 for f16 K — GGML_FP32_TO_FP16 of the reference's
@@ -255,6 +262,58 @@ __device__ __forceinline__ float head_reduce(float x) {
     return x;
 }
 
+// ---- fused decode step (PREP): the per-token work that precedes attention runs inside the decode launch ------------
+// A "row job" is one D-element f32 row held by one wave (lane i = elements 2i, 2i+1, the layout of pkv_rowcodec.h):
+// jobs 0..G-1 are this kv head's query rows (RoPE, then the QK^T operand format straight into LDS: the rotated Q never
+// goes back to memory), job G is the new token's K row (RoPE + quantize), job G+1 its V row (quantize).  The workgroup
+// that owns the sequence's last block patches the new token's K / V bits into the registers it loaded from the pool
+// (the pool slot itself is written at the end of the kernel, for the steps to come), so no launch and no memory round
+// trip separates ggml_rope_ext + ggml_cpy from the attention that consumes them (/ref/src/llama-model.cpp:4091-4105).
+template <int KT, int D, int G>
+__device__ __forceinline__ void q_row_to_lds(QShared<KT, D, G> & sq, int g, int lane, float2 x) {
+    if constexpr (KT == PKV_TYPE_F16) {
+        const Q2 v = quantize<PKV_TYPE_F16>(x, lane);
+        if (2 * lane < D) *reinterpret_cast<uint32_t *>(&sq.h[g][2 * lane]) = (uint32_t) (v.q0 & 0xFFFF) | ((uint32_t) v.q1 << 16);
+    } else {
+        const Q2 v = quantize<PKV_TYPE_Q8_0>(x, lane);     // the reference quantizes Q to q8_0 for every quantized K type
+        int sum = v.q0 + v.q1;
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+        if (2 * lane < D) {
+            *reinterpret_cast<uint16_t *>(&sq.qs[g][2 * lane]) = (uint16_t) ((v.q0 & 0xFF) | ((v.q1 & 0xFF) << 8));
+            if ((lane & 15) == 0) { sq.d[g][2 * lane / PKV_QK] = h_val(v.d); sq.qsum[g][2 * lane / PKV_QK] = sum; }
+        }
+    }
+}
+// the new token's K row in the K-tile row format (quants, then one f32 scale per 32-element block)
+template <int KT, int D> struct KCur { __attribute__((aligned(16))) unsigned char q[D * 2]; float d[D / PKV_QK]; };
+template <int KT, int D>
+__device__ __forceinline__ void k_row_to_lds(KCur<KT, D> & sk, int lane, const Q2 & v) {
+    const int e0 = 2 * lane;
+    if constexpr (KT == PKV_TYPE_Q4_0) {   // byte j of a block = elem j | elem (j+16) << 4
+        const int p0 = __shfl_xor(v.q0, 8), p1 = __shfl_xor(v.q1, 8);
+        if (e0 >= D) return;
+        if ((lane & 15) < 8)
+            *reinterpret_cast<uint16_t *>(&sk.q[(e0 / PKV_QK) * 16 + 2 * (lane & 15)]) = (uint16_t) ((v.q0 | (p0 << 4)) | ((v.q1 | (p1 << 4)) << 8));
+    } else {
+        if (e0 >= D) return;
+        if constexpr (KT == PKV_TYPE_F16) *reinterpret_cast<uint32_t *>(&sk.q[e0 * 2]) = (uint32_t) (v.q0 & 0xFFFF) | ((uint32_t) v.q1 << 16);
+        else                              *reinterpret_cast<uint16_t *>(&sk.q[e0]) = (uint16_t) ((v.q0 & 0xFF) | ((v.q1 & 0xFF) << 8));
+    }
+    if (KT != PKV_TYPE_F16 && (lane & 15) == 0) sk.d[e0 / PKV_QK] = h_val(v.d);
+}
+// the new token's V row as V-tile dwords: dword d carries the token's bits at its place `sub` in the token group, zeros elsewhere
+template <int D> struct VCur { __attribute__((aligned(16))) uint32_t w[D]; float d[D / PKV_QK]; };
+template <int VT, int D>
+__device__ __forceinline__ void v_row_to_lds(VCur<D> & sv, int lane, const Q2 & v, int sub) {
+    const int e0 = 2 * lane;
+    if (e0 >= D) return;
+    constexpr int BITS = 32 / VTr<VT>::TL;
+    constexpr uint32_t M = BITS == 32 ? 0xFFFFFFFFu : (1u << BITS) - 1u;
+    sv.w[e0]     = ((uint32_t) v.q0 & M) << (BITS * sub);
+    sv.w[e0 + 1] = ((uint32_t) v.q1 & M) << (BITS * sub);
+    if (VT != PKV_TYPE_F16 && (lane & 15) == 0) sv.d[e0 / PKV_QK] = h_val(v.d);
+}
+
 template <int KT, int VT, int D>
 struct Geo {
     using KT_ = KTr<KT, D>;
@@ -265,7 +324,7 @@ struct Geo {
     static constexpr int K_NL = TPW / K_RPL, V_NL = TPW / V_RPL;
 };
 
-template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED>
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP>
 __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(const DecodeArgs a) {
     using GE = Geo<KT, VT, D>;
     using KT_ = KTr<KT, D>;
@@ -296,8 +355,26 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(VT, a.block_size, D);
     const int n_valid = min(WG_TOK, seq_len - base);  // >= 1
 
+    // PREP: the row jobs of this workgroup (see "fused decode step"); wave w takes jobs w, w + NW, ...
+    constexpr int NJ = G + 2, NJW = (NJ + NW - 1) / NW;
+    const int  wv      = __builtin_amdgcn_readfirstlane(wave);
+    const bool is_last = PREP && base + n_valid == seq_len;     // this workgroup's last valid row is the new token
     QRaw<D, G, NT> qraw;
-    q_load<D, G, NT>(qraw, a.q + (size_t) s * a.q_stride_tok + (size_t) hk * G * a.q_stride_head, a.q_stride_head, tid);
+    float2 jx[NJW];
+    float4 jcs = make_float4(1.0f, 0.0f, 1.0f, 0.0f);           // this lane's (cos, sin) entries of the new token's row
+    if constexpr (PREP) {
+#pragma unroll
+        for (int k = 0; k < NJW; ++k) {                         // unconditional, in-bounds loads (clamped job / element)
+            const int job = min(wv + k * NW, NJ - 1);
+            const float * src = job < G ? a.q + (size_t) s * a.q_stride_tok + (size_t) (hk * G + job) * a.q_stride_head
+                                        : (job == G ? a.k_cur : a.v_cur) + ((size_t) s * a.n_head_kv + hk) * D;
+            jx[k] = *reinterpret_cast<const float2 *>(src + min(2 * lane, D - 2));
+        }
+        if (a.has_rope)
+            jcs = *reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(a.rope_cache) + (size_t) s * (D / 2) + rope_cache_base<D>(lane, a.rope));
+    } else {
+        q_load<D, G, NT>(qraw, a.q + (size_t) s * a.q_stride_tok + (size_t) hk * G * a.q_stride_head, a.q_stride_head, tid);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- every K and V load of the lane is issued up front, unconditionally: rows past the end of the sequence are
@@ -337,10 +414,62 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
 
     // ---- Q: converted once per workgroup into LDS (while the KV stream is in flight), then one fragment per lane ----
     __shared__ __attribute__((aligned(16))) QShared<KT, D, G> sQ;
-    q_to_lds<KT, D, G, NT>(sQ, qraw, tid);
+    __shared__ KCur<KT, D> sKc;
+    __shared__ VCur<D>     sVc;
+    Q2 curq[NJW];
+    if constexpr (PREP) {
+#pragma unroll
+        for (int k = 0; k < NJW; ++k) {
+            const int job = wv + k * NW;                        // wave-uniform
+            curq[k] = Q2{0, 0, 0};
+            if (job < G) {                                      // ggml_rope_ext(Qcur), then q_to_vec_dot
+                float2 x = jx[k];
+                if (a.has_rope) x = rope_row_cached<D>(x, lane, jcs, a.rope);
+                q_row_to_lds<KT, D, G>(sQ, job, lane, x);
+            } else if (job == G && is_last) {                   // ggml_rope_ext(Kcur) + ggml_cpy -> k cache
+                float2 x = jx[k];
+                if (a.has_rope) x = rope_row_cached<D>(x, lane, jcs, a.rope);
+                curq[k] = quantize<KT>(x, lane);
+                k_row_to_lds<KT, D>(sKc, lane, curq[k]);
+            } else if (job == G + 1 && is_last) {               // ggml_cpy(Vcur) -> v cache
+                curq[k] = quantize<VT>(jx[k], lane);
+                v_row_to_lds<VT, D>(sVc, lane, curq[k], (boff + n_valid - 1) % V_TL);
+            }
+        }
+    } else {
+        q_to_lds<KT, D, G, NT>(sQ, qraw, tid);
+    }
     __syncthreads();
     QFrag<KT, D, G> qf;
     qf.load(sQ, kc);
+    if constexpr (PREP) {
+        if (is_last) {   // the new token's bits replace whatever the pool slot held (its store happens at the end of the kernel)
+            const int tl = n_valid - 1;
+#pragma unroll
+            for (int i = 0; i < K_NL; ++i)
+                if (min(wave * TPW + i * K_RPL + kr, tl) == tl) {
+                    kreg[i] = *reinterpret_cast<const uint4 *>(&sKc.q[kc * 16]);
+                    if constexpr (KT != PKV_TYPE_F16) ksc[i] = sKc.d[kc * KT_::E / PKV_QK];
+                }
+            constexpr int BITS = 32 / V_TL;
+            const int      gcur = (boff + tl) / V_TL, sub = (boff + tl) % V_TL;
+            const uint32_t keep = ~((BITS == 32 ? 0xFFFFFFFFu : (1u << BITS) - 1u) << (BITS * sub));
+#pragma unroll
+            for (int i = 0; i < V_NL; ++i) {
+                const int tw = wave * TPW + i * V_RPL + vl * V_TL;
+                if ((boff + min(tw, tl)) / V_TL == gcur) {
+                    const uint4 nv = *reinterpret_cast<const uint4 *>(&sVc.w[vc * 4]);
+                    vreg[i].x = (vreg[i].x & keep) | nv.x; vreg[i].y = (vreg[i].y & keep) | nv.y;
+                    vreg[i].z = (vreg[i].z & keep) | nv.z; vreg[i].w = (vreg[i].w & keep) | nv.w;
+                    if constexpr (VT != PKV_TYPE_F16) {
+#pragma unroll
+                        for (int t = 0; t < V_TL; ++t)
+                            if (t == sub && tw <= tl) vsc[i][t] = sVc.d[vc / 8];
+                    }
+                }
+            }
+        }
+    }
 
     // ---- QK^T: per-lane partial dots, then a DPP reduce-scatter: every lane ends with NVF finished logits ---------
     float x[NV];
@@ -470,6 +599,16 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
             if (d == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = l; }
         }
     }
+    if constexpr (PREP) {
+        if (is_last) {   // the new token's rows reach the pool for the steps to come (nothing in this launch reads them back)
+#pragma unroll
+            for (int k = 0; k < NJW; ++k) {
+                const int job = wv + k * NW;
+                if (job == G)     tile_write<KT, false>(const_cast<char *>(ktile), boff + n_valid - 1, lane, curq[k], a.block_size, D);
+                if (job == G + 1) tile_write<VT, true>(const_cast<char *>(vtile), boff + n_valid - 1, lane, curq[k], a.block_size, D);
+            }
+        }
+    }
     if constexpr (FUSED) {
         __shared__ unsigned sLast;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores ...
@@ -517,17 +656,21 @@ __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
     __shared__ float sRed[2][D / 64];
     const int h = blockIdx.x, s = blockIdx.y, d = threadIdx.x, wave = d >> 6, lane = d & 63;
     const int seq_len = a.seq_lens[s];
+    const float * ml = a.part_ml + ((size_t) s * a.n_head + h) * a.n_splits * 2;
+    const float * po = a.part_o + ((size_t) s * a.n_head + h) * a.n_splits * D;
+    // The first pass of columns and of (m, l) pairs is requested BEFORE seq_len is back: the addresses only need the
+    // host-known split count (slots past the sequence's own count hold stale partials; they are selected away below,
+    // never multiplied), so the sequence length and the data share one memory round trip.
+    const int nsm = a.n_splits - 1;
+    float pv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) pv[u] = po[(size_t) min(u, nsm) * D + d];
+    const float2 ml0 = *reinterpret_cast<const float2 *>(ml + (size_t) min(d, nsm) * 2);
     const int ns = (seq_len + WG_TOK - 1) / WG_TOK;
     float * o = a.out + ((size_t) s * a.n_head + h) * D;
     if (ns <= 0) { o[d] = 0.0f; return; }
-    const float * ml = a.part_ml + ((size_t) s * a.n_head + h) * a.n_splits * 2;
-    const float * po = a.part_o + ((size_t) s * a.n_head + h) * a.n_splits * D;
-    // first pass of columns + every (m, l): all in flight together
-    float pv[CH];
-#pragma unroll
-    for (int u = 0; u < CH; ++u) pv[u] = po[(size_t) min(u, ns - 1) * D + d];
-    float m = -INFINITY;
-    for (int j = d; j < ns; j += D) m = fmaxf(m, ml[j * 2]);
+    float m = d < ns ? ml0.x : -INFINITY;
+    for (int j = d + D; j < ns; j += D) m = fmaxf(m, ml[j * 2]);
     m = wave_max(m);
     if (lane == 0) sRed[0][wave] = m;
     __syncthreads();
@@ -537,13 +680,14 @@ __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
     float L = 0.0f, acc = 0.0f;
     for (int j0 = 0; j0 < ns; j0 += CH) {
         const int n = min(CH, ns - j0);
+        float2 v = ml0;
         if (j0 > 0) {
 #pragma unroll
             for (int u = 0; u < CH; ++u) pv[u] = po[(size_t) (j0 + min(u, n - 1)) * D + d];
+            if (d < n) v = *reinterpret_cast<const float2 *>(ml + (size_t) (j0 + d) * 2);
         }
         float w = 0.0f;
         if (d < n) {
-            const float2 v = *reinterpret_cast<const float2 *>(ml + (size_t) (j0 + d) * 2);
             w = v.x == -INFINITY ? 0.0f : __expf(v.x - M);
             L = fmaf(v.y, w, L);
         }
@@ -577,13 +721,16 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     dim3 grid(da.n_splits, da.n_head_kv, n_seq);
     const dim3 block(64 * Geo<KT, VT, D>::NW);
     const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr;
-    if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
-        launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true>, grid, block, st, da);
+    if (da.k_cur) {      // fused decode step: RoPE(Q), RoPE(K) + KV store and the split-KV attention in one launch
+        launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
+        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
+    } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
+        launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, false>, grid, block, st, da);
     } else {
-        if (!cap && !sp)      launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false>, grid, block, st, da);
-        else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false>, grid, block, st, da);
-        else if (cap && !sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, false, false>, grid, block, st, da);
-        else                  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, true, false>, grid, block, st, da);
+        if (!cap && !sp)      launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false>, grid, block, st, da);
+        else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false, false>, grid, block, st, da);
+        else if (cap && !sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, false, false, false>, grid, block, st, da);
+        else                  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, true, false, false>, grid, block, st, da);
         if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
     }
     PKV_HIP(hipGetLastError());
@@ -624,13 +771,14 @@ int launch_v(const DecodeArgs & da, int VT, int D, int G, int n_seq, hipStream_t
 
 }  // namespace
 
-// [part_o f32 n_tok*n_head*ns*D][part_ml f32 n_tok*n_head*ns*2][tickets u32 n_tok*n_head]
+// [part_o f32 n_tok*n_head*ns*D][part_ml f32 n_tok*n_head*ns*2][tickets u32 n_tok*n_head][rope cache f32 n_tok*D, 16-byte aligned]
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len) {
     const size_t ns = (size_t) (max_seq_len + WG_TOK - 1) / WG_TOK;
-    return (size_t) n_tok * n_head * (ns ? ns : 1) * (D + 2) * sizeof(float) + (size_t) n_tok * n_head * sizeof(unsigned);
+    return (size_t) n_tok * n_head * (ns ? ns : 1) * (D + 2) * sizeof(float) + (size_t) n_tok * n_head * sizeof(unsigned)
+         + 16 + (size_t) n_tok * D * sizeof(float);   // + the step's RoPE cache rows (pkv_attn_decode_step without rope_cache)
 }
 
-int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {
+int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_args * step) {
     PKV_REQUIRE(a.q && (a.out || (a.flags & PKV_ATTN_NO_COMBINE)) && a.k_pool && a.v_pool && a.block_table && a.seq_lens, "pkv_attn_decode: null pointer");
     PKV_REQUIRE(a.q_start == nullptr && a.n_tok == a.n_seq, "pkv_attn_decode: one query token per sequence (use pkv_attn_prefill)");
     PKV_REQUIRE(a.n_seq > 0 && a.n_head > 0 && a.n_head_kv > 0 && a.n_head % a.n_head_kv == 0, "pkv_attn_decode: bad head counts");
@@ -668,6 +816,33 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st) {
         da.counters = reinterpret_cast<unsigned *>(da.part_ml + (size_t) a.n_tok * a.n_head * da.n_splits * 2);
     da.softcap = a.logit_softcap;
     da.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;  // :12290-12292
+    da.k_cur = da.v_cur = nullptr; da.rope_cache = nullptr; da.has_rope = 0; da.rope = RopeDev{};
+    if (step) {
+        PKV_REQUIRE(step->k_cur && step->v_cur, "pkv_attn_decode_step: null pointer");
+        PKV_REQUIRE(((uintptr_t) step->k_cur % 8) == 0 && ((uintptr_t) step->v_cur % 8) == 0 && (a.q_stride_head % 2) == 0, "pkv_attn_decode_step: rows must be 8-byte aligned");
+        if (a.logit_softcap != 0.0f || a.slot_pos || (a.flags & (PKV_ATTN_FUSED_COMBINE | PKV_ATTN_NO_COMBINE))) {
+            set_error("pkv_attn_decode_step: softcap / irregular sequences / merge flags take pkv_qkv_prepare + pkv_attn_decode");
+            return PKV_ERR_UNSUPPORTED;
+        }
+        da.k_cur = step->k_cur; da.v_cur = step->v_cur;
+        if (step->rope) {
+            const int rc = make_rope(step->rope, a.head_dim, &da.rope);
+            if (rc != PKV_OK) return rc;
+            if ((da.rope.mode & 2) && da.rope.n_dims != a.head_dim) { set_error("fused NEOX rope needs n_dims == head_dim"); return PKV_ERR_UNSUPPORTED; }
+            da.has_rope = 1;
+            if (step->rope_cache) {
+                PKV_REQUIRE(((uintptr_t) step->rope_cache % 16) == 0, "pkv_attn_decode_step: rope_cache must be 16-byte aligned");
+                da.rope_cache = reinterpret_cast<const float4 *>(step->rope_cache);
+            } else {   // no row supplied by the caller: build this launch's rows in the workspace tail first
+                PKV_REQUIRE(step->pos != nullptr, "pkv_attn_decode_step: pos or rope_cache is required with rope");
+                char * tail = reinterpret_cast<char *>(da.part_ml + (size_t) a.n_tok * a.n_head * da.n_splits * 2) + (size_t) a.n_tok * a.n_head * sizeof(unsigned);
+                tail = reinterpret_cast<char *>(((uintptr_t) tail + 15) & ~(uintptr_t) 15);
+                const int rc2 = launch_rope_cache(step->pos, reinterpret_cast<float *>(tail), a.n_tok, a.head_dim, da.rope, st);
+                if (rc2 != PKV_OK) return rc2;
+                da.rope_cache = reinterpret_cast<const float4 *>(tail);
+            }
+        }
+    }
     const int G = a.n_head / a.n_head_kv;
     switch (a.type_k) {
         case PKV_TYPE_F16:  return launch_v<PKV_TYPE_F16>(da, a.type_v, a.head_dim, G, a.n_seq, st);

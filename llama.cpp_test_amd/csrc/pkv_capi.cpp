@@ -161,6 +161,21 @@ int pkv_attn_decode(const pkv_attn_args * args, void * stream) {
     return launch_attn_decode(*args, (hipStream_t) stream);
 }
 
+int pkv_rope_cache(const int32_t * pos, int n_tok, int head_dim, const pkv_rope_params * rope, float * cache, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(pos && cache && n_tok >= 0 && head_dim > 0 && head_dim % 2 == 0, "pkv_rope_cache: bad arguments");
+    PKV_REQUIRE(((uintptr_t) cache % 16) == 0, "pkv_rope_cache: cache must be 16-byte aligned");
+    RopeDev r;
+    if (int rc = make_rope(rope, head_dim, &r)) return rc;
+    return launch_rope_cache(pos, cache, n_tok, head_dim, r, (hipStream_t) stream);
+}
+
+int pkv_attn_decode_step(const pkv_attn_args * args, const pkv_step_args * step, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args != nullptr && step != nullptr, "pkv_attn_decode_step: null args");
+    return launch_attn_decode(*args, (hipStream_t) stream, step);
+}
+
 // raw hipEvent_t helpers for callers without a HIP binding (bench.py measures the decode kernel with them)
 void * pkv_event_create(void) {
     hipEvent_t e = nullptr;

@@ -5,7 +5,8 @@
     kv_self->find_slot(ubatch) -> PagedKVCache.find_slot()         (:1301)   + update() for queued copy-on-write copies
     set_inputs(KQ_mask, pos)  -> block_table / seq_lens / q_start (:1330; the dense mask is gone)
     per layer: rope(Q), rope(K), cpy K/V -> cache, flash_attn_ext  (/root/reference/src/llama-model.cpp:4091-4105)
-                              -> qkv_prepare + attn_decode | attn_prefill
+                              -> attn_decode_step (one token per sequence: everything in one launch + merge, the
+                                 (cos, sin) rows built once per ubatch) | qkv_prepare + attn_prefill
 
 Everything model-side (projections, FFN, sampling) is outside this path: the caller supplies the per-layer Q/K/V
 activations as device tensors (benchmarks use random ones, like llama-bench uses random tokens).
@@ -16,8 +17,8 @@ from typing import List, Sequence
 
 import numpy as np
 
-from . import (ATTN_NONCAUSAL, PagedKVCache, PkvError, RopeParams, attn_decode, attn_prefill, attn_workspace,  # noqa: F401
-               qkv_prepare, rope_params)
+from . import (ATTN_NONCAUSAL, PagedKVCache, PkvError, RopeParams, attn_decode, attn_decode_step, attn_prefill,  # noqa: F401
+               attn_workspace, qkv_prepare, rope_cache, rope_params)
 
 
 class AttnPathRunner:
@@ -67,19 +68,25 @@ class AttnPathRunner:
                 raise PkvError(-5, "irregular sequence (holes / shifted cells): call defrag() + update() first")
         bt, sl = self.cache.block_table(seqs)
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-        return dict(n_tok=n_tok, n_seq=len(seqs), max_q=int(n_q.max()), all_decode=bool((n_q == 1).all()),
-                    max_seq_len=int(sl.max()), slot_block=dev(blk), slot_off=dev(off), pos=dev(p), block_table=dev(bt),
-                    seq_lens=dev(sl), q_start=dev(np.asarray(starts, np.int32)))
+        all_decode = bool((n_q == 1).all())
+        dpos = dev(p)
+        return dict(n_tok=n_tok, n_seq=len(seqs), max_q=int(n_q.max()), all_decode=all_decode,
+                    max_seq_len=int(sl.max()), slot_block=dev(blk), slot_off=dev(off), pos=dpos, block_table=dev(bt),
+                    seq_lens=dev(sl), q_start=dev(np.asarray(starts, np.int32)),
+                    # ggml_rope_cache_init once per ubatch, shared by every layer's fused decode step
+                    rope_cache=rope_cache(dpos, self.rope, self.D) if all_decode else None)
 
     def layer(self, il: int, plan, q, k_cur, v_cur, out=None):
-        """device half, one layer: q f32 [n_tok][n_head][D] (rotated in place), k_cur/v_cur f32 [n_tok][n_head_kv][D]"""
+        """device half, one layer: q f32 [n_tok][n_head][D], k_cur/v_cur f32 [n_tok][n_head_kv][D], all un-rotated.
+        Decode ubatches (one token per sequence) leave q untouched; prefill ubatches rotate it in place."""
         c = self.cache
-        qkv_prepare(q, k_cur, v_cur, c.k_pool(il), c.v_pool(il), type_k=self.tk, type_v=self.tv, slot_block=plan["slot_block"],
-                    slot_off=plan["slot_off"], block_size=self.BS, pos=plan["pos"], rope=self.rope)
         kw = dict(n_head_kv=self.HK, type_k=self.tk, type_v=self.tv, block_size=self.BS, scale=self.scale,
                   max_seq_len=plan["max_seq_len"], out=out, workspace=self.ws)
         if plan["all_decode"]:
-            return attn_decode(q, c.k_pool(il), c.v_pool(il), plan["block_table"], plan["seq_lens"], **kw)
+            return attn_decode_step(q, k_cur, v_cur, plan["pos"], self.rope, c.k_pool(il), c.v_pool(il), plan["block_table"],
+                                    plan["seq_lens"], rope_cache=plan["rope_cache"], **kw)
+        qkv_prepare(q, k_cur, v_cur, c.k_pool(il), c.v_pool(il), type_k=self.tk, type_v=self.tv, slot_block=plan["slot_block"],
+                    slot_off=plan["slot_off"], block_size=self.BS, pos=plan["pos"], rope=self.rope)
         return attn_prefill(q, c.k_pool(il), c.v_pool(il), plan["block_table"], plan["seq_lens"], plan["q_start"],
                             max_q_per_seq=plan["max_q"], **kw)
 

@@ -1,0 +1,136 @@
+"""-m gpu: the fused decode step (pkv_attn_decode_step = RoPE(Q) + RoPE(K) + KV store + paged decode in one launch).
+
+Bar: bit-identical to the two-call path (pkv_qkv_prepare + pkv_attn_decode) — outputs AND pool bytes — which is
+itself pinned against the oracle elsewhere; plus a direct check against the oracle (rope -> from_float -> pool_store ->
+attn_paged), attention output max-abs <= 1e-3 / NMSE <= 5e-4 (tests/test-backend-ops.cpp:3216)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, make_paged_case, nmse
+
+pytestmark = pytest.mark.gpu
+TYPES = {"f16": 1, "q8_0": 8, "q4_0": 2}
+
+
+def _case(O, rng, lens, D, nh, nkv, tk, tv):
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tv)
+    n = len(lens)
+    q = rng.uniform(-1, 1, (n, nh, D)).astype(np.float32)
+    kc = rng.uniform(-1, 1, (n, nkv, D)).astype(np.float32)
+    vc = rng.uniform(-1, 1, (n, nkv, D)).astype(np.float32)
+    pos = (sl - 1).astype(np.int32)
+    return kp, vp, bt, sl, q, kc, vc, pos
+
+
+def _two_call(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, *, nkv, tk, tv):
+    dq, dkp, dvp = dev(q), dev(kp), dev(vp)
+    last = sl - 1
+    sb = bt[np.arange(len(sl)), last // 128].astype(np.int32)
+    so = (last % 128).astype(np.int32)
+    if rope is not None:
+        pkv.qkv_prepare(dq, dev(kc), dev(vc), dkp, dvp, type_k=tk, type_v=tv, slot_block=dev(sb), slot_off=dev(so), block_size=128,
+                        pos=dev(pos), rope=rope)
+    else:
+        pkv.kv_store(dev(kc), dev(vc), dkp, dvp, type_k=tk, type_v=tv, slot_block=dev(sb), slot_off=dev(so), block_size=128)
+    D = q.shape[2]
+    out = pkv.attn_decode(dq, dkp, dvp, dev(bt), dev(sl), n_head_kv=nkv, type_k=tk, type_v=tv, block_size=128, scale=D ** -0.5,
+                          max_seq_len=int(sl.max()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), dkp.cpu().numpy(), dvp.cpu().numpy()
+
+
+def _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, *, nkv, tk, tv, shared_cache=False):
+    dq, dkp, dvp = dev(q), dev(kp), dev(vp)
+    D = q.shape[2]
+    # shared_cache: the (cos, sin) rows are built once (pkv_rope_cache) and handed to the step, as a 32-layer loop does
+    cache = pkv.rope_cache(dev(pos), rope, D) if (shared_cache and rope is not None) else None
+    out = pkv.attn_decode_step(dq, dev(kc), dev(vc), None if cache is not None else dev(pos), rope, dkp, dvp, dev(bt), dev(sl),
+                               n_head_kv=nkv, type_k=tk, type_v=tv, block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()),
+                               rope_cache=cache)
+    torch.cuda.synchronize()
+    assert np.array_equal(dq.cpu().numpy(), q), "q must be left un-rotated"
+    return out.cpu().numpy(), dkp.cpu().numpy(), dvp.cpu().numpy()
+
+
+@pytest.mark.parametrize("tk,tv", [("f16", "f16"), ("q8_0", "q8_0"), ("q4_0", "q4_0"), ("q8_0", "f16"), ("f16", "q4_0")])
+@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (128, 8, 1), (128, 4, 4), (64, 32, 4), (128, 4, 2), (64, 8, 8)])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_step_bit_identical_to_two_calls(pkv, O, tk, tv, D, nh, nkv, mode):
+    tk, tv = TYPES[tk], TYPES[tv]
+    rng = np.random.default_rng(D + nh * 3 + tk + tv * 5 + mode)
+    lens = [1, 2, 3, 8, 31, 127, 128, 129, 130, 255, 256, 257, 300, 641]   # new token first / last / middle of a block, of a V group
+    kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, lens, D, nh, nkv, tk, tv)
+    rope = pkv.rope_params(n_dims=D, mode=mode, freq_base=10000.0)
+    a = _two_call(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=tk, tv=tv)
+    b = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=tk, tv=tv, shared_cache=bool((D + nh + mode) % 4 == 0))
+    assert np.isfinite(b[0]).all()
+    assert np.array_equal(a[1], b[1]), "K pool bytes differ"
+    assert np.array_equal(a[2], b[2]), "V pool bytes differ"
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), np.abs(a[0] - b[0]).max()
+
+
+def test_step_without_rope_and_partial_rotation(pkv, O):
+    rng = np.random.default_rng(5)
+    D, nh, nkv = 128, 8, 2
+    kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, [5, 128, 200, 513], D, nh, nkv, 8, 8)
+    for rope in (None, pkv.rope_params(n_dims=64, mode=0, freq_base=500000.0, freq_scale=0.5, ext_factor=1.0, attn_factor=1.1,
+                                       n_ctx_orig=4096)):
+        a = _two_call(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=8, tv=8)
+        for shared in (False, True):
+            b = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=8, tv=8, shared_cache=shared)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+
+
+def test_rope_cache_rows(pkv, O):
+    """pkv_rope_cache == the (cos, sin) the oracle's rope applies: rotating the unit pair (1, 0) reads them back"""
+    D, n = 128, 6
+    pos = np.array([0, 1, 17, 4095, 16383, 100000], np.int32)
+    for kw in (dict(n_dims=128, mode=0, freq_base=500000.0), dict(n_dims=64, mode=0, freq_base=10000.0, freq_scale=0.25, ext_factor=1.0,
+                                                                   attn_factor=1.2, n_ctx_orig=4096)):
+        rp = pkv.rope_params(**kw)
+        got = pkv.rope_cache(dev(pos), rp, D).cpu().numpy()
+        x = np.zeros((n, 1, D), np.float32)
+        x[:, :, 0::2] = 1.0                                        # NORM pairs (1, 0) -> (cos, sin)
+        ref = O.rope(x, pos, **kw)[:, 0]
+        nd = kw["n_dims"]
+        assert np.abs(got[:, :nd // 2, 0] - ref[:, 0:nd:2]).max() <= 2e-6
+        assert np.abs(got[:, :nd // 2, 1] - ref[:, 1:nd:2]).max() <= 2e-6
+        assert np.array_equal(got[:, nd // 2:, 0], np.ones_like(got[:, nd // 2:, 0])) and not got[:, nd // 2:, 1].any()
+
+
+@pytest.mark.parametrize("tk", ["f16", "q8_0", "q4_0"])
+def test_step_matches_oracle(pkv, O, tk):
+    """the oracle's own chain: rope_f32 -> from_float -> pool_store -> flash_attn_ext over the gathered cells"""
+    t = TYPES[tk]
+    rng = np.random.default_rng(77 + t)
+    D, nh, nkv = 128, 32, 8
+    lens = [1, 129, 384, 1000]
+    kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, lens, D, nh, nkv, t, t)
+    rope = pkv.rope_params(n_dims=D, mode=0, freq_base=500000.0)
+    got, gk, gv = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=t, tv=t)
+    okw = dict(n_dims=D, mode=0, freq_base=500000.0)
+    qr = O.rope(q, pos, **okw)
+    kr = O.rope(kc, pos, **okw)
+    last = sl - 1
+    sb, so = bt[np.arange(len(sl)), last // 128].astype(np.int32), (last % 128).astype(np.int32)
+    O.pool_store(kp, t, 0, O.from_float(t, kr), sb, so, D=D, block_size=128)
+    O.pool_store(vp, t, 1, O.from_float(t, vc), sb, so, D=D, block_size=128)
+    ref = O.attn_paged(qr[:, :, None, :], kp, vp, bt, sl, n_q=1, type_k=t, type_v=t, block_size=128, scale=D ** -0.5)[:, 0]
+    assert np.array_equal(gv, vp), "V pool bytes differ from the oracle's store"
+    # K went through RoPE: device cosf/sinf differ from libm by ulps, so the stored rows are compared as values
+    for s_, n in enumerate(lens):
+        a = O.to_float(t, O.pool_gather(gk, t, 0, bt[s_], n, D=D, block_size=128), D)
+        b = O.to_float(t, O.pool_gather(kp, t, 0, bt[s_], n, D=D, block_size=128), D)
+        assert np.abs(a - b).max() <= (2e-3 if t == 1 else 0.2 if t == 2 else 1.2e-2)   # one quantum of the type at |x| <= 1.42
+    assert np.abs(got - ref).max() <= 1e-3
+    assert nmse(got, ref) <= 5e-4
+
+
+def test_step_rejects_unsupported(pkv, O):
+    rng = np.random.default_rng(9)
+    kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, [100], 128, 4, 4, 1, 1)
+    with pytest.raises(pkv.PkvError):
+        pkv.attn_decode_step(dev(q), dev(kc), dev(vc), dev(pos), None, dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=4, type_k=1,
+                             type_v=1, block_size=128, scale=1.0, max_seq_len=100, logit_softcap=30.0)
