@@ -284,6 +284,23 @@ void * pkv_cache_v_pool(pkv_cache * c, int layer);
  * pending K-shift (has_shift) to every layer on `stream`, then clear the deltas. */
 int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream);
 
+/* Session state of the KV cache in the reference's byte format: llama_kv_cache_unified::state_write / state_read
+ * (/ref/src/llama-kv-cache.cpp:848-1221; reached through llama_state_get_data / llama_state_seq_get_data,
+ * /ref/include/llama.h:793-876).  Layout: u32 cell_count | per cell {i32 pos, u32 n_seq_id, i32 seq_id[n_seq_id]} |
+ * u32 v_trans | u32 n_layer | per layer {i32 type_k, u64 k_size_row, K rows} | per layer {i32 type_v, u64 v_size_row,
+ * V rows}; one row = one cell = row_size(type, n_head_kv * head_dim) bytes exactly as the reference stores it.
+ * seq_id >= 0: that sequence's cells (n_seq_id written as 0); seq_id == -1: every occupied cell with its sequence set,
+ * in ascending (block, offset) order.  The rows are gathered through the block table on save and scattered on load
+ * ("gather-on-save"), so files are interchangeable with the reference's flat cell ring.  v_trans is written as 0 (the
+ * flash-attention layout); files with v_trans = 1 (f16 V of `-fa 0` runs) are read and transposed back.
+ * host pointers; a bookkeeping-only cache (n_layer == 0) reads/writes the metadata alone and needs no GPU.
+ * state_size / state_write return the byte count (>= 0) or a negative PKV_ERR_*; pending device work (copies, K-shift)
+ * must have been applied by pkv_cache_update first.  state_read on failure leaves the cache cleared (seq_id == -1) or
+ * the sequence removed, like the reference (:888-896). */
+int64_t pkv_cache_state_size(pkv_cache * c, int32_t seq_id);
+int64_t pkv_cache_state_write(pkv_cache * c, int32_t seq_id, void * dst, size_t capacity, void * stream);
+int     pkv_cache_state_read(pkv_cache * c, int32_t seq_id, const void * src, size_t n_bytes, void * stream);
+
 /* ---- the fork prototype's toy classes (sources absent from /ref; semantics recovered from
  * /ref/tests/test_block_manager.cpp, test_kv_cache.cpp, test_block_kv_cache.cpp and the ELF symbols,
  * SURVEY.md §8(a-toy)) ---------------------------------------------------------------------------- */

@@ -90,6 +90,8 @@ def lib() -> C.CDLL:
             getattr(L, f).restype = C.c_size_t
         L.pkv_row_size.argtypes = [C.c_int, C.c_int64]
         L.pkv_cache_create.restype = C.c_void_p
+        L.pkv_cache_state_size.restype = C.c_int64
+        L.pkv_cache_state_write.restype = C.c_int64
         L.pkv_cache_create.argtypes = [C.POINTER(CacheParams)]
         for f in ("pkv_cache_k_pool", "pkv_cache_v_pool", "pkv_toy_bm_create", "pkv_toy_kvm_create"):
             getattr(L, f).restype = C.c_void_p
@@ -365,7 +367,7 @@ class PagedKVCache:
     def seq_len(self, s) -> int: return lib().pkv_cache_seq_len(self.h, s)
     def seq_is_regular(self, s) -> bool: return bool(lib().pkv_cache_seq_is_regular(self.h, s))
     def n_free_blocks(self) -> int: return lib().pkv_cache_n_free_blocks(self.h)
-    def block_refcount(self, b) -> int: return lib().pkv_cache_block_refcount(self.h, b)
+    def block_refcount(self, b) -> int: return lib().pkv_cache_block_refcount(self.h, int(b))
     def has_shift(self) -> bool: return bool(lib().pkv_cache_has_shift(self.h))
 
     def seq_blocks(self, s) -> np.ndarray:
@@ -399,6 +401,23 @@ class PagedKVCache:
     # device side
     def k_pool(self, layer: int) -> int: return lib().pkv_cache_k_pool(self.h, layer)
     def v_pool(self, layer: int) -> int: return lib().pkv_cache_v_pool(self.h, layer)
+
+    # session state in the reference's byte format (llama_kv_cache_unified::state_write / state_read,
+    # /root/reference/src/llama-kv-cache.cpp:848-1221); seq_id = -1: the whole cache
+    def state_write(self, seq_id: int = -1, stream=None) -> bytes:
+        n = lib().pkv_cache_state_size(self.h, seq_id)
+        if n < 0:
+            check(int(n))
+        buf = C.create_string_buffer(max(int(n), 1))
+        st = C.c_void_p(_stream(stream)) if self.n_layer > 0 else None
+        w = lib().pkv_cache_state_write(self.h, seq_id, buf, C.c_size_t(int(n)), st)
+        if w < 0:
+            check(int(w))
+        return buf.raw[:int(w)]
+
+    def state_read(self, data: bytes, seq_id: int = -1, stream=None) -> None:
+        st = C.c_void_p(_stream(stream)) if self.n_layer > 0 else None
+        check(lib().pkv_cache_state_read(self.h, seq_id, data, C.c_size_t(len(data)), st))
 
     def update(self, rope: Optional[RopeParams] = None, stream=None):
         """kv_self_update (/root/reference/src/llama-context.cpp:719-803): queued copies + pending K-shift."""

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <map>
 #include <set>
 
 namespace pkv {
@@ -384,6 +385,76 @@ void KvCachePaged::defrag() {
         for (int32_t b : s.blocks) unref_block(b);
         s = std::move(d);
     }
+}
+
+int KvCachePaged::state_cells(int32_t seq_id, std::vector<StateCell> & out) const {
+    out.clear();
+    if (has_shift_ || !pending.empty()) return PKV_ERR_INVALID;   // positions / rows not yet consistent on the device
+    const int32_t BS = p_.block_size;
+    if (seq_id >= 0) {
+        if (!valid(seq_id)) return PKV_OK;                        // unknown sequence: no cells (has_seq_id is false everywhere)
+        const Seq & s = seqs_[seq_id];
+        for (size_t c = 0; c < s.pos.size(); ++c)
+            if (s.pos[c] >= 0) out.push_back({s.blocks[c / BS], (int32_t) (c % BS), s.pos[c], {}});
+        return PKV_OK;
+    }
+    std::map<int64_t, StateCell> cells;                           // flat index block * BS + off, ascending
+    for (int32_t sid = 0; sid < (int32_t) seqs_.size(); ++sid) {
+        const Seq & s = seqs_[sid];
+        for (size_t c = 0; c < s.pos.size(); ++c) {
+            if (s.pos[c] < 0) continue;
+            const int32_t b = s.blocks[c / BS], o = (int32_t) (c % BS);
+            StateCell & cell = cells[(int64_t) b * BS + o];
+            cell.block = b; cell.off = o; cell.pos = s.pos[c];
+            cell.seq_ids.push_back(sid);                          // ascending, like std::set<llama_seq_id> iteration
+        }
+    }
+    for (auto & kv : cells) out.push_back(std::move(kv.second));
+    return PKV_OK;
+}
+
+int KvCachePaged::state_restore(int32_t dest, const std::vector<int32_t> & pos, const std::vector<std::vector<int32_t>> & seq_ids,
+                                std::vector<StateTarget> & targets) {
+    targets.clear();
+    const size_t n = pos.size(), BS = (size_t) p_.block_size;
+    if (dest >= 0) {                                              // single sequence (:1004-1042)
+        if (!valid(dest)) return PKV_ERR_INVALID;
+        for (const auto & ids : seq_ids) if (!ids.empty()) return PKV_ERR_INVALID;   // "invalid seq_id-agnostic kv cell"
+        seq_rm(dest, -1, -1);
+        if (n == 0) return PKV_OK;
+        std::vector<int32_t> sid(n, dest), blk(n), off(n);
+        const int rc = find_slot((int) n, sid.data(), pos.data(), blk.data(), off.data());
+        if (rc != PKV_OK) return rc;
+        for (size_t i = 0; i < n; ++i) targets.push_back({(int32_t) i, blk[i], off[i]});
+        return PKV_OK;
+    }
+    // whole cache (:1043-1090)
+    for (const auto & ids : seq_ids)
+        for (int32_t id : ids) if (!valid(id)) return PKV_ERR_INVALID;
+    clear();
+    std::vector<std::vector<int32_t>> list(seqs_.size());         // per sequence: its file cells, in file order
+    for (size_t i = 0; i < n; ++i)
+        for (int32_t id : seq_ids[i]) list[id].push_back((int32_t) i);
+    std::map<std::vector<int32_t>, int32_t> made;                  // file cells of a block -> the physical block that holds them
+    for (size_t sid = 0; sid < seqs_.size(); ++sid) {
+        const auto & L = list[sid];
+        Seq & s = seqs_[sid];
+        for (size_t c0 = 0; c0 < L.size(); c0 += BS) {
+            const std::vector<int32_t> key(L.begin() + c0, L.begin() + std::min(L.size(), c0 + BS));
+            auto it = made.find(key);
+            int32_t b;
+            if (it != made.end()) { b = it->second; ++ref_[b]; }
+            else {
+                b = alloc_block();
+                if (b < 0) { clear(); return PKV_ERR_NO_SPACE; }
+                made.emplace(key, b);
+                for (size_t j = 0; j < key.size(); ++j) targets.push_back({key[j], b, (int32_t) j});
+            }
+            s.blocks.push_back(b);
+        }
+        for (int32_t i : L) { s.pos.push_back(pos[i]); s.delta.push_back(0); }
+    }
+    return PKV_OK;
 }
 
 void KvCachePaged::take_shifts(std::vector<int32_t> & blk, std::vector<int32_t> & off, std::vector<int32_t> & dlt) {

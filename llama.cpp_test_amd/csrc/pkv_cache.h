@@ -100,6 +100,18 @@ class KvCachePaged {
     bool    valid(int32_t s) const { return s >= 0 && s < (int32_t) seqs_.size(); }
     const pkv_cache_params & params() const { return p_; }
 
+    // session state (/ref/src/llama-kv-cache.cpp:848-1103): the cell list a session file carries, and its restore.
+    // state_cells: seq_id >= 0 -> that sequence's cells in logical order (seq_ids left empty, as the reference writes
+    // n_seq_id = 0); seq_id == -1 -> every occupied physical cell once, ascending (block, offset) = the flat cell order
+    // of the reference, each with the set of sequences that hold it.  PKV_ERR_INVALID while device work is pending.
+    struct StateCell   { int32_t block, off, pos; std::vector<int32_t> seq_ids; };
+    struct StateTarget { int32_t cell, block, off; };   // file cell -> pool slot that must receive its K/V rows
+    int state_cells(int32_t seq_id, std::vector<StateCell> & out) const;
+    // state_read_meta (:1003-1103): dest >= 0 replaces that sequence by the file's cells (find_slot); dest == -1 clears
+    // the cache and rebuilds every sequence; blocks that hold the same file cells in the same order are shared again.
+    int state_restore(int32_t dest_seq_id, const std::vector<int32_t> & pos, const std::vector<std::vector<int32_t>> & seq_ids,
+                      std::vector<StateTarget> & targets);
+
     // work queued for the device (consumed by pkv_cache_update)
     std::vector<PendingOp> pending;
     // cells with a pending K-shift: (block, off, delta); clears the per-cell deltas

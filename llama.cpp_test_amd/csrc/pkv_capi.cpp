@@ -3,6 +3,7 @@
 #include "pkv_cache.h"
 #include "pkv_common.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -51,6 +52,26 @@ struct pkv_cache {
 struct pkv_toy_block_manager { ToyBlockManager bm; explicit pkv_toy_block_manager(int n) : bm(n) {} };
 struct pkv_toy_kv_manager    { ToyKvManager m;     explicit pkv_toy_kv_manager(int c) : m(c) {} };
 struct pkv_toy_block_kv_cache { ToyBlockKVCache c; pkv_toy_block_kv_cache(int nb, int bs, int h, int d) : c(nb, bs, h, d) {} };
+
+namespace {
+struct StateLayout { size_t n, meta, k_row, v_row, total; };
+StateLayout state_layout(const pkv_cache_params & p, const std::vector<KvCachePaged::StateCell> & cells) {
+    StateLayout L{};
+    L.n = cells.size();
+    L.meta = 4;
+    for (const auto & c : cells) L.meta += 8 + 4 * c.seq_ids.size();
+    L.k_row = p.n_layer > 0 ? row_size(p.type_k, (int64_t) p.n_head_kv * p.head_dim) : 0;
+    L.v_row = p.n_layer > 0 ? row_size(p.type_v, (int64_t) p.n_head_kv * p.head_dim) : 0;
+    L.total = L.meta + 8 + (size_t) p.n_layer * (12 + L.n * L.k_row) + (size_t) p.n_layer * (12 + L.n * L.v_row);
+    return L;
+}
+template <typename T> void put(char *& w, T v) { memcpy(w, &v, sizeof(T)); w += sizeof(T); }
+template <typename T> bool get(const char *& r, const char * end, T * v) {
+    if ((size_t) (end - r) < sizeof(T)) return false;
+    memcpy(v, r, sizeof(T)); r += sizeof(T);
+    return true;
+}
+}  // namespace
 
 extern "C" {
 
@@ -406,6 +427,153 @@ int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream)
             PKV_HIP(hipStreamSynchronize(st));
         }
     }
+    return PKV_OK;
+}
+
+// ---- session state: llama_kv_cache_unified::state_write / state_read in the reference's byte format ------------------------
+// (/ref/src/llama-kv-cache.cpp:848-1221)   u32 cell_count | per cell: i32 pos, u32 n_seq_id, i32 seq_id[n_seq_id] |
+//   u32 v_trans | u32 n_layer | per layer: i32 type_k, u64 k_size_row, K rows | per layer: i32 type_v, u64 v_size_row, V rows
+// v_trans is written as 0 (the paged path is the flash-attention path, whose V cache is not transposed, :94); a file with
+// v_trans = 1 (f16 V, `-fa 0` reference runs) is accepted and transposed back on the host.
+
+int64_t pkv_cache_state_size(pkv_cache * c, int32_t seq_id) {
+    if (!c) { set_error("pkv_cache_state_size: null cache"); return PKV_ERR_INVALID; }
+    std::vector<KvCachePaged::StateCell> cells;
+    if (c->host.state_cells(seq_id, cells) != PKV_OK) { set_error("pkv_cache_state_size: device work is pending, call pkv_cache_update first"); return PKV_ERR_INVALID; }
+    return (int64_t) state_layout(c->host.params(), cells).total;
+}
+
+int64_t pkv_cache_state_write(pkv_cache * c, int32_t seq_id, void * dst, size_t cap, void * stream) {
+    if (!c || !dst) { set_error("pkv_cache_state_write: null argument"); return PKV_ERR_INVALID; }
+    const pkv_cache_params & p = c->host.params();
+    hipStream_t st = (hipStream_t) stream;
+    std::vector<KvCachePaged::StateCell> cells;
+    if (c->host.state_cells(seq_id, cells) != PKV_OK) { set_error("pkv_cache_state_write: device work is pending, call pkv_cache_update first"); return PKV_ERR_INVALID; }
+    const StateLayout L = state_layout(p, cells);
+    if (cap < L.total) { set_error("pkv_cache_state_write: buffer too small (%zu < %zu)", cap, L.total); return PKV_ERR_INVALID; }
+    char * w = (char *) dst;
+    put<uint32_t>(w, (uint32_t) L.n);
+    for (const auto & cell : cells) {                             // state_write_meta (:904-921)
+        put<int32_t>(w, cell.pos);
+        put<uint32_t>(w, (uint32_t) cell.seq_ids.size());
+        for (int32_t id : cell.seq_ids) put<int32_t>(w, id);
+    }
+    put<uint32_t>(w, 0u);                                         // v_trans
+    put<uint32_t>(w, (uint32_t) p.n_layer);
+    if (p.n_layer > 0) {                                          // state_write_data (:923-1001): gather-on-save through the block table
+        if (int rc = ensure_device()) return rc;
+        std::vector<int32_t> h(2 * L.n + 2);
+        for (size_t i = 0; i < L.n; ++i) { h[i] = cells[i].block; h[L.n + i] = cells[i].off; }
+        if (int rc = upload(c, h, st)) return rc;
+        void * rows = nullptr;
+        const size_t rb = std::max<size_t>(16, L.n * std::max(L.k_row, L.v_row));
+        PKV_HIP(hipMalloc(&rows, rb));
+        int rc = PKV_OK;
+        for (int v = 0; v < 2 && rc == PKV_OK; ++v) {
+            const int type = v ? p.type_v : p.type_k;
+            const size_t row = v ? L.v_row : L.k_row;
+            for (int l = 0; l < p.n_layer && rc == PKV_OK; ++l) {
+                put<int32_t>(w, (int32_t) type);                  // ggml_type ids: F16 1, Q4_0 2, Q8_0 8 == PKV_TYPE_*
+                put<uint64_t>(w, (uint64_t) row);
+                if (L.n == 0) continue;
+                rc = launch_rows_io(v ? c->dev.v[l] : c->dev.k[l], type, v, rows, c->dev.scratch, c->dev.scratch + L.n, (int) L.n,
+                                    p.n_head_kv, p.head_dim, p.block_size, false, st);
+                if (rc == PKV_OK && hipMemcpyAsync(w, rows, L.n * row, hipMemcpyDeviceToHost, st) != hipSuccess) rc = hip_fail(hipGetLastError(), "state D2H");
+                if (rc == PKV_OK && hipStreamSynchronize(st) != hipSuccess) rc = hip_fail(hipGetLastError(), "state sync");
+                w += L.n * row;
+            }
+        }
+        (void) hipFree(rows);
+        if (rc != PKV_OK) return rc;
+    }
+    return (int64_t) (w - (char *) dst);
+}
+
+int pkv_cache_state_read(pkv_cache * c, int32_t seq_id, const void * src, size_t n_bytes, void * stream) {
+    PKV_REQUIRE(c && src, "pkv_cache_state_read: null argument");
+    const pkv_cache_params & p = c->host.params();
+    hipStream_t st = (hipStream_t) stream;
+    const char * r = (const char *) src, * end = r + n_bytes;
+    // failure after the cache was touched leaves it as the reference does (:888-896): cleared / the sequence removed
+    auto fail = [&](int code, const char * what) {
+        if (seq_id == -1) c->host.clear(); else c->host.seq_rm(seq_id, -1, -1);
+        set_error("pkv_cache_state_read: failed to restore kv cache (%s)", what);
+        return code;
+    };
+    uint32_t cell_count = 0;
+    if (!get(r, end, &cell_count)) return fail(PKV_ERR_INVALID, "truncated");
+    if ((uint64_t) cell_count > (uint64_t) p.n_blocks * p.block_size) return fail(PKV_ERR_NO_SPACE, "not enough cells in kv cache");
+    std::vector<int32_t> pos(cell_count);
+    std::vector<std::vector<int32_t>> ids(cell_count);
+    for (uint32_t i = 0; i < cell_count; ++i) {
+        uint32_t n_seq_id = 0;
+        if (!get(r, end, &pos[i]) || !get(r, end, &n_seq_id) || (size_t) (end - r) < (size_t) n_seq_id * 4) return fail(PKV_ERR_INVALID, "truncated");
+        ids[i].resize(n_seq_id);
+        for (uint32_t j = 0; j < n_seq_id; ++j) get(r, end, &ids[i][j]);
+        if (seq_id != -1 && n_seq_id != 0) return fail(PKV_ERR_INVALID, "invalid seq_id-agnostic kv cell");
+    }
+    std::vector<KvCachePaged::StateTarget> tg;
+    const int rc0 = c->host.state_restore(seq_id, pos, ids, tg);
+    if (rc0 == PKV_ERR_NO_SPACE) return fail(rc0, "failed to find available cells in kv cache");
+    if (rc0 != PKV_OK) return fail(rc0, "seq_id out of range");
+    uint32_t v_trans = 0, n_layer = 0;
+    if (!get(r, end, &v_trans) || !get(r, end, &n_layer)) return fail(PKV_ERR_INVALID, "truncated");
+    if ((int32_t) n_layer != p.n_layer) return fail(PKV_ERR_INVALID, "mismatched layer count");
+    if (v_trans > 1) return fail(PKV_ERR_INVALID, "incompatible V transposition");
+    if (n_layer == 0) return PKV_OK;
+    if (int rc = ensure_device()) return fail(rc, "no device");
+    // find_slot may have queued a copy-on-write for a shared tail block: run it before the rows land
+    if (!c->host.pending.empty()) { if (int rc = pkv_cache_update(c, nullptr, stream)) return fail(rc, "pending copies"); }
+    const size_t nt = tg.size();
+    const size_t k_row = row_size(p.type_k, (int64_t) p.n_head_kv * p.head_dim), v_row = row_size(p.type_v, (int64_t) p.n_head_kv * p.head_dim);
+    std::vector<int32_t> h(2 * nt + 2);
+    for (size_t i = 0; i < nt; ++i) { h[i] = tg[i].block; h[nt + i] = tg[i].off; }
+    if (int rc = upload(c, h, st)) return fail(rc, "upload");
+    void * rows = nullptr;
+    if (hipMalloc(&rows, std::max<size_t>(16, nt * std::max(k_row, v_row))) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipMalloc"), "allocation");
+    std::vector<char> stage;
+    int rc = PKV_OK;
+    const char * why = "";
+    for (int v = 0; v < 2 && rc == PKV_OK; ++v) {
+        const int type = v ? p.type_v : p.type_k;
+        const size_t row = v ? v_row : k_row;
+        const bool trans = v && v_trans;
+        for (uint32_t l = 0; l < n_layer && rc == PKV_OK; ++l) {
+            int32_t type_ref = 0;
+            if (!get(r, end, &type_ref)) { rc = PKV_ERR_INVALID; why = "truncated"; break; }
+            if (type_ref != type) { rc = PKV_ERR_INVALID; why = v ? "mismatched value type" : "mismatched key type"; break; }
+            if (!trans) {
+                uint64_t row_ref = 0;
+                if (!get(r, end, &row_ref)) { rc = PKV_ERR_INVALID; why = "truncated"; break; }
+                if (row_ref != row) { rc = PKV_ERR_INVALID; why = v ? "mismatched value row size" : "mismatched key row size"; break; }
+            } else {                                              // transposed V (:1176-1215): element size + n_embd_v_gqa, then [n_embd][cells]
+                uint32_t el = 0, n_embd = 0;
+                if (!get(r, end, &el) || !get(r, end, &n_embd)) { rc = PKV_ERR_INVALID; why = "truncated"; break; }
+                if (type != PKV_TYPE_F16 || el != 2) { rc = PKV_ERR_INVALID; why = "mismatched value element size"; break; }
+                if (n_embd != (uint32_t) (p.n_head_kv * p.head_dim)) { rc = PKV_ERR_INVALID; why = "mismatched GQA embedding size"; break; }
+            }
+            const size_t bytes = (size_t) cell_count * row;
+            if ((size_t) (end - r) < bytes) { rc = PKV_ERR_INVALID; why = "truncated"; break; }
+            if (nt > 0) {
+                stage.resize(nt * row);
+                if (!trans) {
+                    for (size_t i = 0; i < nt; ++i) memcpy(&stage[i * row], r + (size_t) tg[i].cell * row, row);
+                } else {
+                    const uint16_t * tv = (const uint16_t *) r;   // [n_embd][cell_count]
+                    const size_t ne = row / 2;
+                    for (size_t i = 0; i < nt; ++i)
+                        for (size_t j = 0; j < ne; ++j) ((uint16_t *) &stage[i * row])[j] = tv[j * cell_count + (size_t) tg[i].cell];
+                }
+                if (hipMemcpyAsync(rows, stage.data(), nt * row, hipMemcpyHostToDevice, st) != hipSuccess) { rc = hip_fail(hipGetLastError(), "state H2D"); why = "copy"; break; }
+                rc = launch_rows_io(v ? c->dev.v[l] : c->dev.k[l], type, v, rows, c->dev.scratch, c->dev.scratch + nt, (int) nt, p.n_head_kv,
+                                    p.head_dim, p.block_size, true, st);
+                if (rc == PKV_OK && hipStreamSynchronize(st) != hipSuccess) { rc = hip_fail(hipGetLastError(), "state sync"); why = "sync"; }
+            }
+            r += bytes;
+        }
+    }
+    (void) hipFree(rows);
+    if (rc != PKV_OK) return fail(rc, why);
     return PKV_OK;
 }
 

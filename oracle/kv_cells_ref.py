@@ -171,6 +171,114 @@ class UnifiedCells:
         return any(seq_id in c.seq and len(c.seq) > 1 for c in self.cells)
 
 
+# ---- session state: llama_kv_cache_unified::state_write / state_read (:848-1221) over UnifiedCells + flat K/V rows ----
+# k_rows / v_rows: per layer, a numpy uint8 array [size][row bytes] = the flat k_l[il] / v_l[il] tensors (one row per cell).
+# "parity unpinned": libllama cannot be compiled from a few files here, so this restatement is pinned by reading the
+# reference source only (format constants and order cited line by line), not by running it.
+import struct
+
+import numpy as np
+
+
+def state_write(uc: "UnifiedCells", k_rows, v_rows, type_k: int, type_v: int, seq_id: int = -1, v_trans: bool = False) -> bytes:
+    ranges, count, begin = [], 0, uc.size                        # :852-871
+    for i, c in enumerate(uc.cells):
+        if (seq_id == -1 and c.seq) or (seq_id in c.seq):       # !is_empty() || has_seq_id
+            count += 1
+            if begin == uc.size:
+                begin = i
+        elif begin != uc.size:
+            ranges.append((begin, i))
+            begin = uc.size
+    if begin != uc.size:
+        ranges.append((begin, uc.size))
+    out = [struct.pack("<I", count)]                              # :880
+    for a, b in ranges:                                           # state_write_meta :904-921
+        for i in range(a, b):
+            c = uc.cells[i]
+            ids = sorted(c.seq) if seq_id == -1 else []
+            out.append(struct.pack("<iI", c.pos, len(ids)))
+            out += [struct.pack("<i", s) for s in ids]
+    n_layer = len(k_rows)
+    out.append(struct.pack("<II", 1 if v_trans else 0, n_layer))   # :927-928
+    for il in range(n_layer):                                     # keys :934-952
+        out.append(struct.pack("<iQ", type_k, k_rows[il].shape[1]))
+        out += [k_rows[il][a:b].tobytes() for a, b in ranges]
+    for il in range(n_layer):
+        if not v_trans:                                           # :954-973
+            out.append(struct.pack("<iQ", type_v, v_rows[il].shape[1]))
+            out += [v_rows[il][a:b].tobytes() for a, b in ranges]
+        else:                                                     # :974-1000 (f16 V stored [n_embd][kv_size])
+            n_embd = v_rows[il].shape[1] // 2
+            out.append(struct.pack("<iII", type_v, 2, n_embd))
+            vt = v_rows[il].view(np.uint16)                       # [size][n_embd] rows; the transposed tensor is vt.T
+            for j in range(n_embd):
+                out += [vt[a:b, j].tobytes() for a, b in ranges]
+    return b"".join(out)
+
+
+def state_read(uc: "UnifiedCells", k_rows, v_rows, type_k: int, type_v: int, data: bytes, seq_id: int = -1) -> bool:
+    """restores cells and rows in place; returns False where the reference returns false (the caller then clears)"""
+    off = 0
+
+    def rd(fmt):
+        nonlocal off
+        v = struct.unpack_from(fmt, data, off)
+        off += struct.calcsize(fmt)
+        return v
+    (count,) = rd("<I")
+    if seq_id != -1:                                              # :1004-1042
+        uc.seq_rm(seq_id, -1, -1)
+        poss = []
+        for _ in range(count):
+            pos, n = rd("<iI")
+            if n != 0:
+                return False
+            poss.append(pos)
+        if count and not uc.find_slot([seq_id] * count, poss):
+            return False
+    else:                                                         # :1043-1090
+        if count > uc.size:
+            return False
+        uc.clear()
+        for i in range(count):
+            pos, n = rd("<iI")
+            c = uc.cells[i]
+            c.pos = pos
+            for _ in range(n):
+                (s,) = rd("<i")
+                if s < 0:
+                    return False
+                c.seq.add(s)
+        uc.head, uc.used = 0, count
+    v_trans, n_layer = rd("<II")                                  # state_read_data :1105-1221
+    if n_layer != len(k_rows) or count > uc.size:
+        return False
+    h = uc.head
+    for il in range(n_layer):
+        t, row = rd("<iQ")
+        if t != type_k or row != k_rows[il].shape[1]:
+            return False
+        k_rows[il][h:h + count] = np.frombuffer(data, np.uint8, count * row, off).reshape(count, row)
+        off += count * row
+    for il in range(n_layer):
+        if not v_trans:
+            t, row = rd("<iQ")
+            if t != type_v or row != v_rows[il].shape[1]:
+                return False
+            v_rows[il][h:h + count] = np.frombuffer(data, np.uint8, count * row, off).reshape(count, row)
+            off += count * row
+        else:
+            t, el, n_embd = rd("<iII")
+            if t != type_v or el != 2 or n_embd * 2 != v_rows[il].shape[1]:
+                return False
+            vt = v_rows[il].view(np.uint16)
+            for j in range(n_embd):
+                vt[h:h + count, j] = np.frombuffer(data, np.uint16, count, off)
+                off += count * 2
+    return True
+
+
 class ToyBlockManager:
     def __init__(self, n):
         self.used = [False] * n
