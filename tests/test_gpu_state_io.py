@@ -123,6 +123,54 @@ def test_reference_written_file_with_interleaved_cells(pkv, O, v_trans):
     assert c.seq_blocks(0)[0] == c.seq_blocks(1)[0] and c.block_refcount(c.seq_blocks(0)[0]) == 2   # the full prompt block is shared again
 
 
+def test_reference_written_golden_files(pkv, O):
+    """tests/golden/state_io.npz: session files produced by the REFERENCE's own state_write (compiled llama_kv_cache_unified,
+    tests/golden/make_state_golden.py).  The paged cache must restore exactly the rows each sequence had in the ring — all KV
+    types, and the transposed-V (`-fa 0`) file — and what it writes back must read as the same views."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "state_io.npz"))
+    for name in g["names"]:
+        tk, tv, v_trans, n_layer, hk, d, size = (int(x) for x in g[f"{name}__meta"])
+        pos, nseq, seqs = g[f"{name}__cell_pos"], g[f"{name}__cell_nseq"], g[f"{name}__cell_seqs"]
+        ring = {s: [i for i in range(size) if s in seqs[i][:nseq[i]]] for s in (0, 1)}
+        c = pkv.PagedKVCache(n_blocks=4, block_size=BS, n_seq_max=2, n_layer=n_layer, n_head_kv=hk, head_dim=d, type_k=tk, type_v=tv)
+
+        def check(cc, s, idx):
+            n = cc.seq_len(s)
+            assert list(cc.seq_slot_pos(s)) == [int(pos[i]) for i in idx], (name, s)
+            b = cc.seq_blocks(s)
+            i = np.arange(n)
+            blk, off = dev(b[i // BS].astype(np.int32)), dev((i % BS).astype(np.int32))
+            for il in range(n_layer):
+                for is_v, t, key in ((0, tk, "k"), (1, tv, "v")):
+                    exp = g[f"{name}__{key}{il}"][idx]
+                    out = torch.empty(exp.shape, dtype=torch.uint8, device="cuda")
+                    pool = cc.v_pool(il) if is_v else cc.k_pool(il)
+                    pkv.pool_gather_rows(pool, out, type=t, is_v=is_v, slot_block=blk, slot_off=off, n_head_kv=hk, head_dim=d, block_size=BS)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(out.cpu().numpy(), exp), (name, s, il, key)
+
+        c.state_read(g[f"{name}__blob"].tobytes(), -1)
+        for s in (0, 1):
+            check(c, s, ring[s])
+        # the single-sequence file, restored under another id of a fresh cache
+        c1 = pkv.PagedKVCache(n_blocks=4, block_size=BS, n_seq_max=2, n_layer=n_layer, n_head_kv=hk, head_dim=d, type_k=tk, type_v=tv)
+        c1.state_read(g[f"{name}__blob_seq1"].tobytes(), 0)
+        check(c1, 0, ring[1])
+        # what the paged cache writes, the (reference-pinned) ring restatement reads back to the same per-sequence rows
+        # (sharing is per block on the paged side, so the removed range of seq 1 costs private copies: a larger ring)
+        blob2 = c.state_write(-1)
+        uc = UnifiedCells(2 * size)
+        k2 = [np.zeros((2 * size, g[f"{name}__k{il}"].shape[1]), np.uint8) for il in range(n_layer)]
+        v2 = [np.zeros((2 * size, g[f"{name}__v{il}"].shape[1]), np.uint8) for il in range(n_layer)]
+        assert state_read(uc, k2, v2, tk, tv, blob2, -1)
+        for s in (0, 1):
+            idx2 = [i for i, cell in enumerate(uc.cells) if s in cell.seq]
+            assert [uc.cells[i].pos for i in idx2] == [int(pos[i]) for i in ring[s]]
+            for il in range(n_layer):
+                assert np.array_equal(k2[il][idx2], g[f"{name}__k{il}"][ring[s]]) and np.array_equal(v2[il][idx2], g[f"{name}__v{il}"][ring[s]])
+
+
 def test_state_read_rejects_mismatched_geometry(pkv, O):
     a = pkv.PagedKVCache(n_blocks=2, block_size=BS, n_seq_max=1, n_layer=L, n_head_kv=HK, head_dim=D, type_k=1, type_v=1)
     a.find_slot([0] * 3, [0, 1, 2])

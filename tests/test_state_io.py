@@ -2,8 +2,9 @@
 llama_kv_cache_unified::state_write / state_read (/root/reference/src/llama-kv-cache.cpp:848-1221).
 
 CPU part: bookkeeping-only caches (n_layer = 0) against the Python restatement of the reference's cell ring
-(oracle/kv_cells_ref.py; "parity unpinned": pinned by reading the reference source, libllama is not buildable from a few
-files).  What must hold: files written by either side restore on the other side to the same view — for every sequence
+(oracle/kv_cells_ref.py).  The restatement is pinned to the reference twice: tests/test_kv_cells_vs_ref.py drives the
+compiled llama_kv_cache_unified beside it (dev container), and tests/golden/state_io.npz holds session files the
+reference's own state_write produced (checked below, everywhere).  What must hold: files written by either side restore on the other side to the same view — for every sequence
 the same multiset AND order of positions — and the paged side re-shares blocks that hold the same cells."""
 import struct
 
@@ -121,6 +122,35 @@ def test_pending_device_work_blocks_the_save(pkv):
         c.state_write(-1)
     c.update()
     assert struct.unpack_from("<I", c.state_write(-1), 0)[0] == 6
+
+
+def _golden_ring(g, name):
+    tk, tv, v_trans, n_layer, hk, d, size = (int(x) for x in g[f"{name}__meta"])
+    uc = UnifiedCells(size)
+    for i, c in enumerate(uc.cells):
+        c.pos = int(g[f"{name}__cell_pos"][i])
+        c.seq = set(int(x) for x in g[f"{name}__cell_seqs"][i][:g[f"{name}__cell_nseq"][i]])
+    uc.used = sum(1 for c in uc.cells if c.seq)
+    k = [g[f"{name}__k{il}"] for il in range(n_layer)]
+    v = [g[f"{name}__v{il}"] for il in range(n_layer)]
+    return uc, k, v, tk, tv, bool(v_trans), size
+
+
+def test_restatement_reproduces_the_reference_written_files():
+    """tests/golden/state_io.npz: files written by the reference's state_write (tests/golden/make_state_golden.py)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "state_io.npz"))
+    for name in g["names"]:
+        uc, k, v, tk, tv, v_trans, size = _golden_ring(g, name)
+        for sid, key in ((-1, "blob"), (1, "blob_seq1")):
+            blob = g[f"{name}__{key}"].tobytes()
+            assert state_write(uc, k, v, tk, tv, sid, v_trans=v_trans) == blob, (name, sid)
+            uc2 = UnifiedCells(size)
+            k2, v2 = [np.zeros_like(x) for x in k], [np.zeros_like(x) for x in v]
+            assert state_read(uc2, k2, v2, tk, tv, blob, sid)
+            assert _ref_positions(uc2, 1) == _ref_positions(uc, 1)
+            if sid == -1:
+                assert all(np.array_equal(a, b) for a, b in zip(k + v, k2 + v2))
 
 
 def test_restatement_round_trip_with_rows():
