@@ -95,7 +95,7 @@ class Workload:
             pkv.attn_decode_step(self.q[l], self.k_cur[l], self.v_cur[l], self.pos, self.rope, self.k_pools[l], self.v_pools[l],
                                  self.block_table, self.seq_lens, n_head_kv=g["n_head_kv"], type_k=self.tk, type_v=self.tv,
                                  block_size=g["block_size"], scale=self.scale, max_seq_len=self.ctx, out=self.out[l],
-                                 workspace=self.ws, events=events, rope_cache=self.rope_cs)
+                                 workspace=self.ws, events=events, rope_cache=self.rope_cs, flags=flags)
             return
         pkv.qkv_prepare(self.q[l], self.k_cur[l], self.v_cur[l], self.k_pools[l], self.v_pools[l], type_k=self.tk,
                         type_v=self.tv, slot_block=self.slot_block, slot_off=self.slot_off, block_size=g["block_size"],
@@ -222,7 +222,7 @@ def main():
     g = GEOM if args.model == "8b" else GEOM_70B
     w = Workload(pkv, torch, ctx=args.ctx, n_seq=args.n_seq, type_k=t, type_v=t, seed=1234 + rank, g=g)
     w.step_flags = pkv.ATTN_FUSED_COMBINE if args.fused_merge else 0
-    w.fused_step = not (args.two_call or args.fused_merge)
+    w.fused_step = not args.two_call
 
     # one decode step = 32 layers x (fused RoPE(Q)+RoPE(K)+KV store, split-KV attention, merge); captured once, replayed per step
     side = torch.cuda.Stream()

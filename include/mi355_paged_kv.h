@@ -301,6 +301,14 @@ int64_t pkv_cache_state_size(pkv_cache * c, int32_t seq_id);
 int64_t pkv_cache_state_write(pkv_cache * c, int32_t seq_id, void * dst, size_t capacity, void * stream);
 int     pkv_cache_state_read(pkv_cache * c, int32_t seq_id, const void * src, size_t n_bytes, void * stream);
 
+/* Debug view of the cache: llama_kv_cache_view_update (/ref/src/llama-kv-cache.cpp:1364-1433, struct
+ * /ref/include/llama.h:593-630) over the PHYSICAL cells, cell i = (block i / block_size, offset i % block_size).
+ * cell_pos: i32 [n_cells] (pos + pending delta, -1 = empty); cell_seqs: i32 [n_cells][n_seq_max] padded with -1 (ids beyond
+ * n_seq_max are not shown, as in the reference); stats: i32 [5] = {n_cells, token_count, used_cells, max_contiguous,
+ * max_contiguous_idx} with the reference's meaning (longest run of empty cells, -1 when the cache is full).
+ * Returns n_cells (= n_blocks * block_size); arrays may be NULL to query the size only. */
+int32_t pkv_cache_view_update(const pkv_cache * c, int32_t n_seq_max, int32_t * cell_pos, int32_t * cell_seqs, int32_t * stats);
+
 /* ---- the fork prototype's toy classes (sources absent from /ref; semantics recovered from
  * /ref/tests/test_block_manager.cpp, test_kv_cache.cpp, test_block_kv_cache.cpp and the ELF symbols,
  * SURVEY.md §8(a-toy)) ---------------------------------------------------------------------------- */

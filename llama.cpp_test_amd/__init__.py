@@ -195,7 +195,8 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
     out = torch.empty((n_tok, n_head, D), dtype=torch.float32, device=q.device) if out is None else out
-    need = attn_workspace_bytes(n_tok, n_head, D, max_seq_len, block_size)
+    # only the split-KV decode needs scratch (its per-block partials); the prefill kernel keeps everything on chip
+    need = attn_workspace_bytes(n_tok, n_head, D, max_seq_len, block_size) if q_start is None else 0
     if workspace is None:
         workspace = torch.zeros(max(need, 16), dtype=torch.uint8, device=q.device)   # zeroed: valid for ATTN_FUSED_COMBINE
     a = AttnArgs(_ptr(q), q.stride(0), q.stride(1), _ptr(out), _ptr(k_pool), _ptr(v_pool), _ptr(block_table),
@@ -418,6 +419,16 @@ class PagedKVCache:
     def state_read(self, data: bytes, seq_id: int = -1, stream=None) -> None:
         st = C.c_void_p(_stream(stream)) if self.n_layer > 0 else None
         check(lib().pkv_cache_state_read(self.h, seq_id, data, C.c_size_t(len(data)), st))
+
+    def view(self, n_seq_max: int = 4):
+        """llama_kv_cache_view_update (/root/reference/src/llama-kv-cache.cpp:1364-1433) over the physical cells:
+        dict(n_cells, token_count, used_cells, max_contiguous, max_contiguous_idx, cells=pos[n_cells], cells_sequences[n_cells][n_seq_max])"""
+        n = lib().pkv_cache_view_update(self.h, n_seq_max, None, None, None)
+        pos, seqs, st = np.empty(n, np.int32), np.empty((n, n_seq_max), np.int32), np.empty(5, np.int32)
+        lib().pkv_cache_view_update(self.h, n_seq_max, pos.ctypes.data_as(C.c_void_p), seqs.ctypes.data_as(C.c_void_p),
+                                    st.ctypes.data_as(C.c_void_p))
+        return dict(n_cells=int(st[0]), token_count=int(st[1]), used_cells=int(st[2]), max_contiguous=int(st[3]),
+                    max_contiguous_idx=int(st[4]), cells=pos, cells_sequences=seqs)
 
     def update(self, rope: Optional[RopeParams] = None, stream=None):
         """kv_self_update (/root/reference/src/llama-context.cpp:719-803): queued copies + pending K-shift."""

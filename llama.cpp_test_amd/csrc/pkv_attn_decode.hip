@@ -76,6 +76,7 @@ struct DecodeArgs {
     float *         part_ml;  // [n_seq][n_head][n_splits][2]
     float *         out;      // [n_seq][n_head][D]
     unsigned *      counters; // [n_seq][n_head_kv] arrival tickets (fused merge), zero between launches
+    int             part_o_bytes, part_ml_bytes;   // extents of the partial slabs (buffer descriptors of the fused merge)
     int   n_head, n_head_kv, block_size, max_blocks, n_splits, bs_shift;  // block_size = WG_TOK << bs_shift
     float scale, softcap;
     // fused decode step (PREP): this step's un-rotated K / V rows, the new token's position, RoPE
@@ -572,31 +573,59 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     __syncthreads();
 
     // ---- merge the waves (each has its own max) and publish one (m, l, O) partial per workgroup -------------------
-    // FUSED: the partials are handed to the last-arriving workgroup of this (sequence, kv head) inside the launch, so
-    // they leave as agent-scope write-through stores (global_store ... sc1): no release fence, and the reader uses
-    // sc1 loads (cdna_hip_programming.md §5 "In-launch split-K reduction", the sc1 form).
-    for (int e = tid; e < G * D; e += NT) {
-        const int g = e / D, d = e % D;
-        float M = -INFINITY;
+    if constexpr (!FUSED) {
+        for (int e = tid; e < G * D; e += NT) {
+            const int g = e / D, d = e % D;
+            float M = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) M = fmaxf(M, sML[w][g][0]);
-        float o = 0.0f, l = 0.0f;
+            for (int w = 0; w < NW; ++w) M = fmaxf(M, sML[w][g][0]);
+            float o = 0.0f, l = 0.0f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float f = sML[w][g][0] == -INFINITY ? 0.0f : __expf(sML[w][g][0] - M);
-            o = fmaf(sO[w][g][d], f, o);
-            l = fmaf(sML[w][g][1], f, l);
-        }
-        const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
-        if constexpr (FUSED) {
-            __hip_atomic_store(&a.part_o[pi * D + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == 0) {
-                __hip_atomic_store(&a.part_ml[pi * 2], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.part_ml[pi * 2 + 1], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w = 0; w < NW; ++w) {
+                const float f = sML[w][g][0] == -INFINITY ? 0.0f : __expf(sML[w][g][0] - M);
+                o = fmaf(sO[w][g][d], f, o);
+                l = fmaf(sML[w][g][1], f, l);
             }
-        } else {
+            const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
             a.part_o[pi * D + d] = o;
             if (d == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = l; }
+        }
+    }
+    // FUSED: the partials are handed to the last-arriving workgroup of this (sequence, kv head) inside the launch.  The
+    // hand-off is placement-independent (cdna_hip_programming.md §6 Guideline 16, the sc1 form): every payload byte leaves
+    // as a 16-/8-byte write-through store (buffer_store ... sc1), every storing wave drains, the workgroup's barrier, ONE
+    // lane takes an agent-scope ticket; the last arriver reads every payload byte with sc1 loads (no fences at all).
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    constexpr int C4 = G * D / 4;                              // float4 columns of one (m, l, O[G][D]) partial
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_o, rs_ml;
+    [[maybe_unused]] unsigned gb = 0;                          // partial index of (s, hk * G, split 0)
+    if constexpr (FUSED) {
+        static_assert(NT % C4 == 0 && C4 <= NT, "column/part mapping of the in-kernel merge");
+        rs_o  = __builtin_amdgcn_make_buffer_rsrc(a.part_o, 0, a.part_o_bytes, 0x00020000);
+        rs_ml = __builtin_amdgcn_make_buffer_rsrc(a.part_ml, 0, a.part_ml_bytes, 0x00020000);
+        gb = ((unsigned) s * a.n_head + hk * G) * a.n_splits;
+        if (tid < C4) {
+            const int g = tid / (D / 4), d4 = tid % (D / 4);
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) M = fmaxf(M, sML[w][g][0]);
+            float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float l = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float  f = sML[w][g][0] == -INFINITY ? 0.0f : __expf(sML[w][g][0] - M);
+                const float4 v = *reinterpret_cast<const float4 *>(&sO[w][g][d4 * 4]);
+                o.x = fmaf(v.x, f, o.x); o.y = fmaf(v.y, f, o.y); o.z = fmaf(v.z, f, o.z); o.w = fmaf(v.w, f, o.w);
+                l = fmaf(sML[w][g][1], f, l);
+            }
+            const unsigned pi = gb + g * a.n_splits + split;
+            u4_t ov; ov.x = __float_as_uint(o.x); ov.y = __float_as_uint(o.y); ov.z = __float_as_uint(o.z); ov.w = __float_as_uint(o.w);
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rs_o, (int) ((pi * D + d4 * 4) * 4), 0, 16);      // aux 16 = sc1
+            if (d4 == 0) {
+                u2_t mv; mv.x = __float_as_uint(M); mv.y = __float_as_uint(l);
+                __builtin_amdgcn_raw_buffer_store_b64(mv, rs_ml, (int) (pi * 2 * 4), 0, 16);
+            }
         }
     }
     if constexpr (PREP) {
@@ -610,7 +639,9 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         }
     }
     if constexpr (FUSED) {
+        constexpr int P = NT / C4, CH = 32, JP = (CH + P - 1) / P;   // parts that share a column, splits per pass / per part
         __shared__ unsigned sLast;
+        __shared__ float2   sMl2[G][CH];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores ...
         __syncthreads();                                       // ... before ONE lane signals for the workgroup
         const unsigned n_act = (unsigned) (seq_len + WG_TOK - 1) / WG_TOK;   // workgroups that arrive for this (s, hk)
@@ -621,26 +652,57 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         }
         __syncthreads();
         if (!sLast) return;
-        // last arriver: merge the n_act partials of its G query heads (sc1 loads only) and write the output rows
+        // last arriver: online merge of the n_act partials, CH splits per pass; thread = (column c, part)
         const int ns = (int) n_act;
-        for (int e = tid; e < G * D; e += NT) {
-            const int g = e / D, d = e % D;
-            const size_t pb = ((size_t) s * a.n_head + hk * G + g) * a.n_splits;
-            float M = -INFINITY;
-#pragma unroll 8
-            for (int j = 0; j < ns; ++j)
-                M = fmaxf(M, __hip_atomic_load(&a.part_ml[(pb + j) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            float L = 0.0f, acc = 0.0f;
-#pragma unroll 8
-            for (int j = 0; j < ns; ++j) {
-                const float mj = __hip_atomic_load(&a.part_ml[(pb + j) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float lj = __hip_atomic_load(&a.part_ml[(pb + j) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float oj = __hip_atomic_load(&a.part_o[(pb + j) * D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float w  = mj == -INFINITY ? 0.0f : __expf(mj - M);
-                L   = fmaf(lj, w, L);
-                acc = fmaf(oj, w, acc);
+        const int c = tid % C4, part = tid / C4, g = c / (D / 4), d4 = c % (D / 4);
+        float  M = -INFINITY, L = 0.0f;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int j0 = 0; j0 < ns; j0 += CH) {
+            const int n = min(CH, ns - j0);
+            u2_t mlv; mlv.x = 0; mlv.y = 0;
+            if (tid < G * CH)
+                mlv = __builtin_amdgcn_raw_buffer_load_b64(rs_ml, (int) ((gb + (tid / CH) * a.n_splits + j0 + min(tid % CH, n - 1)) * 2 * 4), 0, 16);
+            u4_t ov[JP];
+#pragma unroll
+            for (int k = 0; k < JP; ++k)
+                ov[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, (int) (((gb + g * a.n_splits + j0 + min(part + k * P, n - 1)) * D + d4 * 4) * 4), 0, 16);
+            if (tid < G * CH)
+                sMl2[tid / CH][tid % CH] = tid % CH < n ? make_float2(__uint_as_float(mlv.x), __uint_as_float(mlv.y)) : make_float2(-INFINITY, 0.0f);
+            __syncthreads();
+            float mc = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) mc = fmaxf(mc, sMl2[g][j].x);
+            const float Mn = fmaxf(M, mc);
+            const float sc = M == -INFINITY ? 0.0f : __expf(M - Mn);
+            acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+            L *= sc;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float2 v = sMl2[g][j];
+                L = fmaf(v.y, v.x == -INFINITY ? 0.0f : __expf(v.x - Mn), L);
             }
-            a.out[((size_t) s * a.n_head + hk * G + g) * D + d] = acc / L;
+#pragma unroll
+            for (int k = 0; k < JP; ++k) {
+                const int j = part + k * P;
+                if (j < n) {
+                    const float mj = sMl2[g][j].x;
+                    const float w  = mj == -INFINITY ? 0.0f : __expf(mj - Mn);
+                    acc.x = fmaf(__uint_as_float(ov[k].x), w, acc.x); acc.y = fmaf(__uint_as_float(ov[k].y), w, acc.y);
+                    acc.z = fmaf(__uint_as_float(ov[k].z), w, acc.z); acc.w = fmaf(__uint_as_float(ov[k].w), w, acc.w);
+                }
+            }
+            M = Mn;
+            __syncthreads();                                   // sMl2 is rewritten by the next pass
+        }
+        __shared__ float4 red[NT];
+        red[part * C4 + c] = acc;
+        __syncthreads();
+        if (tid < C4) {
+            float4 r = red[c];
+#pragma unroll
+            for (int q = 1; q < P; ++q) { const float4 v = red[q * C4 + c]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+            const float inv = 1.0f / L;                        // all cells masked -> inf * 0 = NaN, like the reference's 1/S with S == 0
+            *reinterpret_cast<float4 *>(&a.out[((size_t) s * a.n_head + hk * G + g) * D + d4 * 4]) = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
         }
     }
 }
@@ -721,7 +783,9 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     dim3 grid(da.n_splits, da.n_head_kv, n_seq);
     const dim3 block(64 * Geo<KT, VT, D>::NW);
     const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr;
-    if (da.k_cur) {      // fused decode step: RoPE(Q), RoPE(K) + KV store and the split-KV attention in one launch
+    if (da.k_cur && da.counters) {   // the whole decode step of a layer in ONE launch
+        launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, true>, grid, block, st, da);
+    } else if (da.k_cur) {      // fused decode step: RoPE(Q), RoPE(K) + KV store and the split-KV attention in one launch
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
         if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
     } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
@@ -812,7 +876,10 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.part_ml = da.part_o + (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim;
     da.out = (a.flags & PKV_ATTN_NO_COMBINE) ? nullptr : a.out;
     da.counters = nullptr;
-    if ((a.flags & PKV_ATTN_FUSED_COMBINE) && !(a.flags & PKV_ATTN_NO_COMBINE) && a.logit_softcap == 0.0f && !a.slot_pos)
+    const size_t po_bytes = (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim * sizeof(float);
+    da.part_o_bytes = (int) po_bytes; da.part_ml_bytes = (int) (po_bytes / a.head_dim * 2);
+    if ((a.flags & PKV_ATTN_FUSED_COMBINE) && !(a.flags & PKV_ATTN_NO_COMBINE) && a.logit_softcap == 0.0f && !a.slot_pos &&
+        po_bytes < ((size_t) 1 << 31))   // 32-bit buffer offsets; larger slabs take the two-launch path
         da.counters = reinterpret_cast<unsigned *>(da.part_ml + (size_t) a.n_tok * a.n_head * da.n_splits * 2);
     da.softcap = a.logit_softcap;
     da.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;  // :12290-12292
@@ -820,8 +887,8 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     if (step) {
         PKV_REQUIRE(step->k_cur && step->v_cur, "pkv_attn_decode_step: null pointer");
         PKV_REQUIRE(((uintptr_t) step->k_cur % 8) == 0 && ((uintptr_t) step->v_cur % 8) == 0 && (a.q_stride_head % 2) == 0, "pkv_attn_decode_step: rows must be 8-byte aligned");
-        if (a.logit_softcap != 0.0f || a.slot_pos || (a.flags & (PKV_ATTN_FUSED_COMBINE | PKV_ATTN_NO_COMBINE))) {
-            set_error("pkv_attn_decode_step: softcap / irregular sequences / merge flags take pkv_qkv_prepare + pkv_attn_decode");
+        if (a.logit_softcap != 0.0f || a.slot_pos || (a.flags & PKV_ATTN_NO_COMBINE)) {
+            set_error("pkv_attn_decode_step: softcap / irregular sequences / NO_COMBINE take pkv_qkv_prepare + pkv_attn_decode");
             return PKV_ERR_UNSUPPORTED;
         }
         da.k_cur = step->k_cur; da.v_cur = step->v_cur;

@@ -179,7 +179,10 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     __shared__ __attribute__((aligned(16))) char sKb[2][KVT * D * 2];
     __shared__ __attribute__((aligned(16))) char sVb[2][KVT * D * 2];
 
-    const int tile = blockIdx.x, hk = blockIdx.y, s = blockIdx.z;
+    // Causal work grows with the query tile index (tile t visits t/2 + 1 KV tiles): dispatch order = longest first, over
+    // ALL sequences and heads (workgroups are handed out in linear block-id order), so the short tiles fill the tail.
+    const int lin  = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nhs = gridDim.y * gridDim.z;
+    const int tile = gridDim.x - 1 - lin / nhs, hk = (lin % nhs) % gridDim.y, s = (lin % nhs) / gridDim.y;
     const int tok0 = a.q_start[s], n_q = a.q_start[s + 1] - tok0;
     if (tile * QT >= n_q) return;
     const int seq_len = a.seq_lens[s];
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         if (tid == 0) {
-            unsigned long long * o8 = a.stamps + ((size_t) (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+            unsigned long long * o8 = a.stamps + ((size_t) (s * gridDim.y + hk) * gridDim.x + tile) * 8;
             o8[0] = t_q - t_begin; o8[1] = t_loop - t_q; o8[2] = t_end - t_loop; o8[3] = t_stage; o8[4] = t_qk; o8[5] = t_sm; o8[6] = t_pv; o8[7] = t_begin;
         }
     }

@@ -387,6 +387,37 @@ void KvCachePaged::defrag() {
     }
 }
 
+void KvCachePaged::view(int32_t n_seq_max, int32_t * cell_pos, int32_t * cell_seqs, int32_t * stats) const {
+    const int32_t BS = p_.block_size, n_cells = (int32_t) ref_.size() * BS;
+    std::vector<int32_t> pos(n_cells, -1), cnt(n_cells, 0);
+    if (cell_seqs) std::fill(cell_seqs, cell_seqs + (size_t) n_cells * n_seq_max, -1);
+    int32_t token_count = 0;
+    for (int32_t sid = 0; sid < (int32_t) seqs_.size(); ++sid) {   // ascending ids, like std::set iteration
+        const Seq & s = seqs_[sid];
+        for (size_t c = 0; c < s.pos.size(); ++c) {
+            if (s.pos[c] < 0) continue;
+            const int32_t i = s.blocks[c / BS] * BS + (int32_t) (c % BS);
+            pos[i] = s.pos[c] + s.delta[c];
+            if (cell_seqs && cnt[i] < n_seq_max) cell_seqs[(size_t) i * n_seq_max + cnt[i]] = sid;
+            ++cnt[i];
+            ++token_count;
+        }
+    }
+    int32_t used = 0, cur = -1, best = 0, best_idx = -1;
+    for (int32_t i = 0; i < n_cells; ++i) {
+        if (cell_pos) cell_pos[i] = pos[i];
+        if (cnt[i] > 0) {
+            ++used;
+            if (cur >= 0 && i - cur > best) { best = i - cur; best_idx = cur; }
+            cur = -1;
+        } else if (cur < 0) {
+            cur = i;
+        }
+    }
+    if (cur >= 0 && n_cells - cur > best) { best = n_cells - cur; best_idx = cur; }
+    if (stats) { stats[0] = n_cells; stats[1] = token_count; stats[2] = used; stats[3] = best; stats[4] = best_idx; }
+}
+
 int KvCachePaged::state_cells(int32_t seq_id, std::vector<StateCell> & out) const {
     out.clear();
     if (has_shift_ || !pending.empty()) return PKV_ERR_INVALID;   // positions / rows not yet consistent on the device

@@ -112,6 +112,9 @@ class KvCachePaged {
     int state_restore(int32_t dest_seq_id, const std::vector<int32_t> & pos, const std::vector<std::vector<int32_t>> & seq_ids,
                       std::vector<StateTarget> & targets);
 
+    // llama_kv_cache_view_update (:1364-1433) over the physical cells
+    void view(int32_t n_seq_max, int32_t * cell_pos, int32_t * cell_seqs, int32_t * stats) const;
+
     // work queued for the device (consumed by pkv_cache_update)
     std::vector<PendingOp> pending;
     // cells with a pending K-shift: (block, off, delta); clears the per-cell deltas

@@ -577,6 +577,13 @@ int pkv_cache_state_read(pkv_cache * c, int32_t seq_id, const void * src, size_t
     return PKV_OK;
 }
 
+int32_t pkv_cache_view_update(const pkv_cache * c, int32_t n_seq_max, int32_t * cell_pos, int32_t * cell_seqs, int32_t * stats) {
+    if (!c || n_seq_max < 0) return 0;
+    const pkv_cache_params & p = c->host.params();
+    if (cell_pos || cell_seqs || stats) c->host.view(n_seq_max, cell_pos, cell_seqs, stats);
+    return p.n_blocks * p.block_size;
+}
+
 // ---- fork prototype toys ---------------------------------------------------------------------------------------------
 pkv_toy_block_manager * pkv_toy_bm_create(int n) { return new pkv_toy_block_manager(n); }
 void pkv_toy_bm_free(pkv_toy_block_manager * bm) { delete bm; }

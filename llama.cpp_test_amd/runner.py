@@ -34,7 +34,8 @@ class AttnPathRunner:
         self.rope = rope if rope is not None else rope_params(n_dims=head_dim)
         self.scale = head_dim ** -0.5
         self.max_seq_len = max_seq_len or n_blocks * block_size
-        self.ws = attn_workspace(max_batch_tokens, n_head, head_dim, self.max_seq_len, block_size)
+        # scratch of the split-KV decode (one query token per sequence, so at most n_seq_max tokens); prefill needs none
+        self.ws = attn_workspace(n_seq_max, n_head, head_dim, self.max_seq_len, block_size)
         self.max_batch_tokens = max_batch_tokens
 
     # llama_kv_self_* pass-throughs used by drivers

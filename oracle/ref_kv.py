@@ -26,7 +26,7 @@ def lib():
         L.refkv_create.restype = C.c_void_p
         L.refkv_state_write.restype = C.c_int64
         for f in ("refkv_free", "refkv_advance_head", "refkv_clear", "refkv_seq_cp", "refkv_seq_keep", "refkv_seq_add",
-                  "refkv_seq_div", "refkv_cells", "refkv_tensor_set", "refkv_tensor_get"):
+                  "refkv_seq_div", "refkv_cells", "refkv_tensor_set", "refkv_tensor_get", "refkv_view"):
             getattr(L, f).restype = None
         _lib = L
     return _lib
@@ -78,6 +78,12 @@ class RefKvCache:
         seqs = np.zeros((self.size, max_seq), np.int32)
         lib().refkv_cells(self.h, _p(pos), _p(dl), _p(ns), _p(seqs), max_seq)
         return [(int(pos[i]), int(dl[i]), [int(x) for x in seqs[i, :ns[i]]]) for i in range(self.size)]
+
+    def view(self, n_seq_max: int = 4):
+        st, pos, seqs = np.empty(5, np.int32), np.empty(self.size, np.int32), np.empty((self.size, n_seq_max), np.int32)
+        lib().refkv_view(self.h, n_seq_max, _p(st), _p(pos), _p(seqs))
+        return dict(n_cells=int(st[0]), token_count=int(st[1]), used_cells=int(st[2]), max_contiguous=int(st[3]),
+                    max_contiguous_idx=int(st[4]), cells=pos, cells_sequences=seqs)
 
     def tensor_set(self, il: int, is_v: bool, data: np.ndarray, offset: int = 0):
         d = np.ascontiguousarray(data).view(np.uint8).reshape(-1)

@@ -107,6 +107,20 @@ void refkv_cells(void * h, int32_t * pos, int32_t * delta, int32_t * n_seq, int3
         n_seq[i] = (int32_t) kv.cells[i].seq_id.size();
     }
 }
+// llama_kv_cache_view_init + _update (llama-kv-cache.cpp:1338-1433): stats[5] = {n_cells, token_count, used_cells,
+// max_contiguous, max_contiguous_idx}; pos[size]; seqs[size * n_seq_max]
+void refkv_view(void * h, int n_seq_max, int32_t * stats, int32_t * pos, int32_t * seqs) {
+    auto & kv = *((RefKv *) h)->kv;
+    llama_kv_cache_view v = llama_kv_cache_view_init(kv, n_seq_max);
+    llama_kv_cache_view_update(&v, &kv);
+    stats[0] = v.n_cells; stats[1] = v.token_count; stats[2] = v.used_cells; stats[3] = v.max_contiguous; stats[4] = v.max_contiguous_idx;
+    for (int i = 0; i < v.n_cells; ++i) {
+        pos[i] = v.cells[i].pos;
+        for (int j = 0; j < n_seq_max; ++j) seqs[(size_t) i * n_seq_max + j] = v.cells_sequences[(size_t) i * n_seq_max + j];
+    }
+    llama_kv_cache_view_free(&v);
+}
+
 // raw access to the flat per-layer tensors (byte offsets into k_l[il] / v_l[il])
 void refkv_tensor_set(void * h, int il, int is_v, const void * src, size_t offset, size_t size) {
     auto & kv = *((RefKv *) h)->kv;

@@ -26,8 +26,9 @@ for kv_type in (("f16",) if os.environ.get("PKV_PREFILL_ONE") else ("f16", "q8_0
         qs = torch.arange(0, (n_seq + 1) * n_q, n_q, dtype=torch.int32, device="cuda")
         q = torch.rand((n_seq * n_q, H, D), generator=gen, device="cuda") * 2 - 1
         out = torch.empty_like(q)
+        ws = pkv.attn_workspace(n_seq * n_q, H, D, L, BS)       # allocated once: a per-call workspace costs a fill kernel per launch
         run = lambda: pkv.attn_prefill(q, kp, vp, bt, sl, qs, n_head_kv=HK, type_k=t, type_v=t, block_size=BS, scale=D ** -0.5,
-                                       max_seq_len=L, max_q_per_seq=n_q, out=out)
+                                       max_seq_len=L, max_q_per_seq=n_q, out=out, workspace=ws)
         for _ in range(3):
             run()
         torch.cuda.synchronize()

@@ -128,6 +128,28 @@ def test_step_matches_oracle(pkv, O, tk):
     assert nmse(got, ref) <= 5e-4
 
 
+@pytest.mark.parametrize("tk,tv", [("f16", "f16"), ("q8_0", "q8_0"), ("q4_0", "f16")])
+@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (128, 8, 1), (64, 4, 4), (64, 8, 1), (128, 4, 2)])
+def test_step_with_in_kernel_merge(pkv, O, tk, tv, D, nh, nkv):
+    """PKV_ATTN_FUSED_COMBINE on the decode step: RoPE + KV store + attention + merge in ONE launch.  Same pools (bit-exact),
+    outputs equal to the two-launch merge up to the summation order of the partials (<= 2e-6); the workspace's wrapping
+    arrival tickets serve launch after launch, more than 32 splits take several merge passes."""
+    tk, tv = TYPES[tk], TYPES[tv]
+    rng = np.random.default_rng(D + nh + tk * 3 + tv)
+    lens = [1, 127, 128, 129, 640, 4096, 4500, 2000]
+    kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, lens, D, nh, nkv, tk, tv)
+    rope = pkv.rope_params(n_dims=D, mode=0, freq_base=500000.0)
+    base = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=tk, tv=tv)
+    ws = pkv.attn_workspace(len(lens), nh, D, int(sl.max()), 128)
+    for it in range(3):
+        dq, dkp, dvp = dev(q), dev(kp), dev(vp)
+        out = pkv.attn_decode_step(dq, dev(kc), dev(vc), dev(pos), rope, dkp, dvp, dev(bt), dev(sl), n_head_kv=nkv, type_k=tk, type_v=tv,
+                                   block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
+        torch.cuda.synchronize()
+        assert np.array_equal(dkp.cpu().numpy(), base[1]) and np.array_equal(dvp.cpu().numpy(), base[2]), it
+        assert np.abs(out.cpu().numpy() - base[0]).max() <= 2e-6, it
+
+
 def test_step_rejects_unsupported(pkv, O):
     rng = np.random.default_rng(9)
     kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, [100], 128, 4, 4, 1, 1)

@@ -122,3 +122,23 @@ def test_state_files_are_byte_identical_and_cross_readable(tk, tv, fa):
     whole = r.state_write(-1)
     assert not ref_kv.RefKvCache(n_layer=L, n_head_kv=HK, head_dim=D, type_k=tk, type_v=tv, kv_size=size, flash_attn=fa).state_read(whole, 1)
     assert not state_read(UnifiedCells(size), [np.zeros_like(x) for x in k], [np.zeros_like(x) for x in v], tk, tv, whole, 1)
+
+
+def test_debug_view_matches_the_reference(pkv):
+    """llama_kv_cache_view_update (:1364-1433).  A single sequence laid out from block 0 occupies the same cell indices in the
+    paged cache as in the ring, so the whole view — stats, positions (+ pending delta), sequence lists — must coincide."""
+    size, bs = 64, 16
+    r = ref_kv.RefKvCache(n_layer=1, n_head_kv=HK, head_dim=D, type_k=1, type_v=1, kv_size=size)
+    c = pkv.PagedKVCache(n_blocks=size // bs, block_size=bs, n_seq_max=3, n_layer=0)
+    r.find_slot([0] * 40, list(range(40))); r.advance_head(40)
+    c.find_slot([0] * 40, list(range(40)))
+    for x in (r, c):
+        x.seq_rm(0, 5, 9)                                         # a hole (not a whole block: the paged table keeps it)
+        x.seq_add(0, 20, -1, 3)                                   # pending shift shows up as pos + delta
+    a, b = r.view(3), c.view(3)
+    for k in ("n_cells", "token_count", "used_cells", "max_contiguous", "max_contiguous_idx"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    used = a["cells_sequences"][:, 0] >= 0
+    assert np.array_equal(used, b["cells_sequences"][:, 0] >= 0)
+    assert np.array_equal(a["cells"][used], b["cells"][used])
+    assert np.array_equal(a["cells_sequences"], b["cells_sequences"])
