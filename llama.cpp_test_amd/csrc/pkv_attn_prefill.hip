@@ -176,8 +176,10 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     if constexpr (STAMP) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int NT = 64 * G, KS = D / 16, DT = D / 32;  // k-steps of QK^T, 32-row d tiles of O^T
     // two LDS images per operand: tile t+1 is written while slower waves still multiply tile t -> ONE barrier per tile
-    __shared__ __attribute__((aligned(16))) char sKb[2][KVT * D * 2];
-    __shared__ __attribute__((aligned(16))) char sVb[2][KVT * D * 2];
+    constexpr int IMG = KVT * D * 2;                                  // one f16 tile image
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG];       // K0, V0, K1, V1; the epilogue stages O through all of it
+    auto sKb = [&](int i) -> char * { return smem + (size_t) i * 2 * IMG; };
+    auto sVb = [&](int i) -> char * { return smem + (size_t) i * 2 * IMG + IMG; };
 
     // Causal work grows with the query tile index (tile t visits t/2 + 1 KV tiles): dispatch order = longest first, over
     // ALL sequences and heads (workgroups are handed out in linear block-id order), so the short tiles fill the tail.
@@ -194,21 +196,6 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     const int qpos   = a.causal ? seq_len - n_q + jr : seq_len - 1;
     const int kv_end = a.causal ? min(seq_len, seq_len - n_q + tile * QT + QT) : seq_len;
 
-    // ---- Q^T fragments, rounded to f16 (GGML_FP32_TO_FP16 of the reference's q_to_vec_dot for f16 K) ---------------
-    half8_t qf[KS];
-    {
-        const float * qp = a.q + (size_t) (tok0 + (q_ok ? jr : 0)) * a.q_stride_tok + (size_t) head * a.q_stride_head;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            // rows past the end of the tile read query 0 of the sequence (in bounds) and are never written back
-            const float4 x0 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8);
-            const float4 x1 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8 + 4);
-            qf[ks] = half8_t{(_Float16) x0.x, (_Float16) x0.y, (_Float16) x0.z, (_Float16) x0.w,
-                             (_Float16) x1.x, (_Float16) x1.y, (_Float16) x1.z, (_Float16) x1.w};
-        }
-    }
-
-    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_q = __builtin_amdgcn_s_memtime(); }
     floatx16 o[DT + 1];   // o[DT] = row sums (every row of that tile holds l of the lane's query)
 #pragma unroll
     for (int dt = 0; dt <= DT; ++dt)
@@ -238,13 +225,30 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
         kst.load(a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k, row0, nval, a.block_size, tid);
         vst.load(a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v, row0, nval, a.block_size, tid);
     };
+    // the first KV tile's loads go out BEFORE the Q loads: the block-table lookup and the tile's HBM latency overlap the
+    // (row-strided, therefore slow) Q fetch instead of following it
     prefetch(0);
-    kst.write(sKb[0], tid);
-    vst.write(sVb[0], tid);
+    // ---- Q^T fragments, rounded to f16 (GGML_FP32_TO_FP16 of the reference's q_to_vec_dot for f16 K) ---------------
+    half8_t qf[KS];
+    {
+        const float * qp = a.q + (size_t) (tok0 + (q_ok ? jr : 0)) * a.q_stride_tok + (size_t) head * a.q_stride_head;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            // rows past the end of the tile read query 0 of the sequence (in bounds) and are never written back
+            const float4 x0 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8);
+            const float4 x1 = *reinterpret_cast<const float4 *>(qp + ks * 16 + h * 8 + 4);
+            qf[ks] = half8_t{(_Float16) x0.x, (_Float16) x0.y, (_Float16) x0.z, (_Float16) x0.w,
+                             (_Float16) x1.x, (_Float16) x1.y, (_Float16) x1.z, (_Float16) x1.w};
+        }
+    }
+
+    if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_q = __builtin_amdgcn_s_memtime(); }
+    kst.write(sKb(0), tid);
+    vst.write(sVb(0), tid);
     for (int kv0 = 0, it = 0; kv0 < kv_end; kv0 += KVT, ++it) {
         if constexpr (STAMP) tt = __builtin_amdgcn_s_memtime();
-        const char * sK = sKb[it & 1];
-        const char * sV = sVb[it & 1];
+        const char * sK = sKb(it & 1);
+        const char * sV = sVb(it & 1);
         const bool more = kv0 + KVT < kv_end;
         __syncthreads();                       // tile `it` is complete in LDS; everyone is done with tile it-1
         if (more) prefetch(kv0 + KVT);         // HBM -> registers, in flight while this tile is multiplied
@@ -332,23 +336,44 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
                 o[DT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, o[DT], 0, 0, 0);
             }
         if (more) {                            // registers -> the other LDS image (last read two barriers ago)
-            kst.write(sKb[(it + 1) & 1], tid);
-            vst.write(sVb[(it + 1) & 1], tid);
+            kst.write(sKb((it + 1) & 1), tid);
+            vst.write(sVb((it + 1) & 1), tid);
         }
         if constexpr (STAMP) { asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory"); const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_pv += t2 - tt; tt = t2; }
     }
     if constexpr (STAMP) t_loop = __builtin_amdgcn_s_memtime();
     // ---- normalise and write out[tok][head][d] -----------------------------------------------------------------------------
-    if (q_ok) {
+    // O^T sits with the query on the lane: stored directly, every lane would write 16-byte pieces of ITS row (32 rows per
+    // instruction, 32-64 cache lines touched each).  Instead each wave transposes its tile through LDS (the K/V images are
+    // free now) and stores whole rows: 32 lanes x 16 B = one 512-byte head row per half-wave.
+    {
+        constexpr int DH = G <= 4 ? D : D / 2;                 // d columns staged per pass (wave strip = 32 rows x DH f32 <= 4*IMG / G)
+        constexpr int CPRW = DH / 4;                           // 16-byte chunks per staged row
+        static_assert(32 * DH * 4 * G <= 4 * IMG, "per-wave output strips must fit the tile images");
+        float * strip = reinterpret_cast<float *>(smem) + (size_t) g * 32 * DH;
         const float inv = 1.0f / o[DT][0];
-        float * op = a.out + ((size_t) (tok0 + jr) * a.n_head + head) * D;
+        __syncthreads();                                       // every wave is done reading the last K/V tile
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int pass = 0; pass < D / DH; ++pass) {
 #pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                const int d = dt * 32 + crow(i, h);  // registers i..i+3 are 4 consecutive rows (d)
-                *reinterpret_cast<float4 *>(op + d) = make_float4(o[dt][i] * inv, o[dt][i + 1] * inv, o[dt][i + 2] * inv, o[dt][i + 3] * inv);
+            for (int dt = pass * (DH / 32); dt < (pass + 1) * (DH / 32); ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const int c = ((dt * 32 - pass * DH) + crow(i, h)) / 4;   // registers i..i+3 are 4 consecutive d
+                    *reinterpret_cast<float4 *>(strip + (size_t) r * DH + ((c ^ (r & 7)) * 4)) =
+                        make_float4(o[dt][i] * inv, o[dt][i + 1] * inv, o[dt][i + 2] * inv, o[dt][i + 3] * inv);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is private to this wave
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it2 = 0; it2 < 32 * CPRW / 64; ++it2) {
+                const int e = it2 * 64 + lane, row = e / CPRW, c = e % CPRW;
+                const float4 v = *reinterpret_cast<const float4 *>(strip + (size_t) row * DH + ((c ^ (row & 7)) * 4));
+                if (tile * QT + row < n_q)
+                    *reinterpret_cast<float4 *>(a.out + ((size_t) (tok0 + tile * QT + row) * a.n_head + head) * D + pass * DH + c * 4) = v;
             }
+            if (pass + 1 < D / DH) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        }
     }
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
