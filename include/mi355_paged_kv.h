@@ -160,6 +160,9 @@ typedef struct pkv_attn_args {
 #define PKV_ATTN_NONCAUSAL 4
 
 size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq_len, int block_size);
+/* what pkv_attn_prefill alone can use (its split-KV mode for small launches over a long past; 0 above 2048 tokens).  A
+ * smaller or NULL workspace is fine: the call then runs unsplit. */
+size_t pkv_attn_prefill_workspace_bytes(int n_tok, int n_head, int head_dim);
 /* zero a fresh workspace (asynchronously, on `stream`); required once before PKV_ATTN_FUSED_COMBINE is used with it */
 int    pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream);
 /* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks */

@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
             getattr(L, f).restype = C.c_size_t
         L.pkv_row_size.argtypes = [C.c_int, C.c_int64]
         L.pkv_cache_create.restype = C.c_void_p
+        L.pkv_attn_prefill_workspace_bytes.restype = C.c_size_t
         L.pkv_cache_state_size.restype = C.c_int64
         L.pkv_cache_state_write.restype = C.c_int64
         L.pkv_cache_create.argtypes = [C.POINTER(CacheParams)]
@@ -188,6 +189,11 @@ def attn_workspace_bytes(n_tok: int, n_head: int, head_dim: int, max_seq_len: in
     return lib().pkv_attn_workspace_bytes(n_tok, n_head, head_dim, max_seq_len, block_size)
 
 
+def attn_prefill_workspace_bytes(n_tok: int, n_head: int, head_dim: int) -> int:
+    """scratch attn_prefill can use for its split-KV mode (small launches over a long past); 0 above 2048 tokens"""
+    return lib().pkv_attn_prefill_workspace_bytes(n_tok, n_head, head_dim)
+
+
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
           stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None):
@@ -195,8 +201,9 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
     out = torch.empty((n_tok, n_head, D), dtype=torch.float32, device=q.device) if out is None else out
-    # only the split-KV decode needs scratch (its per-block partials); the prefill kernel keeps everything on chip
-    need = attn_workspace_bytes(n_tok, n_head, D, max_seq_len, block_size) if q_start is None else 0
+    # decode: per-block partials of the split-KV kernel; prefill: scratch of its split-KV mode (small launches only)
+    need = (attn_workspace_bytes(n_tok, n_head, D, max_seq_len, block_size) if q_start is None
+            else attn_prefill_workspace_bytes(n_tok, n_head, D))
     if workspace is None:
         workspace = torch.zeros(max(need, 16), dtype=torch.uint8, device=q.device)   # zeroed: valid for ATTN_FUSED_COMBINE
     a = AttnArgs(_ptr(q), q.stride(0), q.stride(1), _ptr(out), _ptr(k_pool), _ptr(v_pool), _ptr(block_table),
@@ -213,10 +220,10 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
     return out
 
 
-def attn_workspace(n_tok: int, n_head: int, head_dim: int, max_seq_len: int, block_size: int, device="cuda"):
+def attn_workspace(n_tok: int, n_head: int, head_dim: int, max_seq_len: int, block_size: int, device="cuda", min_bytes: int = 0):
     """a workspace that is valid for every flag combination (zeroed through pkv_attn_workspace_init)"""
     import torch
-    ws = torch.empty(max(16, attn_workspace_bytes(n_tok, n_head, head_dim, max_seq_len, block_size)), dtype=torch.uint8,
+    ws = torch.empty(max(16, min_bytes, attn_workspace_bytes(n_tok, n_head, head_dim, max_seq_len, block_size)), dtype=torch.uint8,
                      device=device)
     check(lib().pkv_attn_workspace_init(C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), C.c_void_p(_stream())))
     return ws

@@ -19,6 +19,8 @@
 // arithmetic than the reference's q8_0-quantized Q; tolerance in tests/test_gpu_prefill.py).
 #include "pkv_common.h"
 
+#include <algorithm>
+
 namespace pkv {
 extern void * g_prefill_stamps;
 namespace {
@@ -46,6 +48,11 @@ struct PrefillArgs {
     float   max_bias;             // ALiBi: slope(head) * mask (/ref/ggml/src/ggml-cpu/ggml-cpu.c:12294-12316)
     int     causal;               // 0: every query sees all seq_len cells (test-backend-ops style), 1: llama causal
     unsigned long long * stamps;  // diagnostic build only (PKV_PREFILL_STAMP): per-workgroup phase timestamps
+    // split-KV (few query tiles over a long past, e.g. a 512-token ubatch at ctx 16384): the KV range of a query tile is cut
+    // into n_split parts, one workgroup each; partial (m, l, O) go to scratch and prefill_combine_kernel merges them
+    int     n_split, n_tok_total; // n_split == 1: no scratch, results go straight to `out`
+    float * part_o;               // [n_tok][n_head][n_split][D], un-normalised
+    float * part_ml;              // [n_tok][n_head][n_split][2] = (m * cexp (log2 domain), l)
 };
 
 __device__ __forceinline__ int crow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }  // C/D row of register i
@@ -184,7 +191,8 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     // Causal work grows with the query tile index (tile t visits t/2 + 1 KV tiles): dispatch order = longest first, over
     // ALL sequences and heads (workgroups are handed out in linear block-id order), so the short tiles fill the tail.
     const int lin  = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nhs = gridDim.y * gridDim.z;
-    const int tile = gridDim.x - 1 - lin / nhs, hk = (lin % nhs) % gridDim.y, s = (lin % nhs) / gridDim.y;
+    const int xr   = gridDim.x - 1 - lin / nhs;                     // x = tile * n_split + split, longest tiles first
+    const int tile = xr / a.n_split, sp = xr % a.n_split, hk = (lin % nhs) % gridDim.y, s = (lin % nhs) / gridDim.y;
     const int tok0 = a.q_start[s], n_q = a.q_start[s + 1] - tok0;
     if (tile * QT >= n_q) return;
     const int seq_len = a.seq_lens[s];
@@ -194,7 +202,10 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     const bool q_ok = jr < n_q;
     // index of the last KV cell this query sees, and the workgroup-uniform bound of the KV loop
     const int qpos   = a.causal ? seq_len - n_q + jr : seq_len - 1;
-    const int kv_end = a.causal ? min(seq_len, seq_len - n_q + tile * QT + QT) : seq_len;
+    const int kv_all = a.causal ? min(seq_len, seq_len - n_q + tile * QT + QT) : seq_len;   // cells this query tile can see
+    const int nkt    = (kv_all + KVT - 1) / KVT;                                             // ... in KV tiles
+    const int kv_beg = (int) ((long long) nkt * sp / a.n_split) * KVT;                       // this workgroup's share
+    const int kv_end = min(kv_all, (int) ((long long) nkt * (sp + 1) / a.n_split) * KVT);
 
     floatx16 o[DT + 1];   // o[DT] = row sums (every row of that tile holds l of the lane's query)
 #pragma unroll
@@ -227,7 +238,7 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     };
     // the first KV tile's loads go out BEFORE the Q loads: the block-table lookup and the tile's HBM latency overlap the
     // (row-strided, therefore slow) Q fetch instead of following it
-    prefetch(0);
+    prefetch(min(kv_beg, max(kv_all - 1, 0) / KVT * KVT));   // (an empty share still loads a valid, aligned tile; its loop does not run)
     // ---- Q^T fragments, rounded to f16 (GGML_FP32_TO_FP16 of the reference's q_to_vec_dot for f16 K) ---------------
     half8_t qf[KS];
     {
@@ -245,7 +256,7 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
     if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_q = __builtin_amdgcn_s_memtime(); }
     kst.write(sKb(0), tid);
     vst.write(sVb(0), tid);
-    for (int kv0 = 0, it = 0; kv0 < kv_end; kv0 += KVT, ++it) {
+    for (int kv0 = kv_beg, it = 0; kv0 < kv_end; kv0 += KVT, ++it) {
         if constexpr (STAMP) tt = __builtin_amdgcn_s_memtime();
         const char * sK = sKb(it & 1);
         const char * sV = sVb(it & 1);
@@ -351,7 +362,13 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
         constexpr int CPRW = DH / 4;                           // 16-byte chunks per staged row
         static_assert(32 * DH * 4 * G <= 4 * IMG, "per-wave output strips must fit the tile images");
         float * strip = reinterpret_cast<float *>(smem) + (size_t) g * 32 * DH;
-        const float inv = 1.0f / o[DT][0];
+        const bool  partial = a.n_split > 1;
+        const float inv = partial ? 1.0f : 1.0f / o[DT][0];
+        if (partial && q_ok && h == 0) {                       // (m, l) of this share; an empty share leaves (-inf, 0)
+            float * ml = a.part_ml + (((size_t) (tok0 + jr) * a.n_head + head) * a.n_split + sp) * 2;
+            ml[0] = m == -INFINITY ? -INFINITY : m * cexp;
+            ml[1] = o[DT][0];
+        }
         __syncthreads();                                       // every wave is done reading the last K/V tile
 #pragma unroll
         for (int pass = 0; pass < D / DH; ++pass) {
@@ -369,8 +386,11 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
             for (int it2 = 0; it2 < 32 * CPRW / 64; ++it2) {
                 const int e = it2 * 64 + lane, row = e / CPRW, c = e % CPRW;
                 const float4 v = *reinterpret_cast<const float4 *>(strip + (size_t) row * DH + ((c ^ (row & 7)) * 4));
-                if (tile * QT + row < n_q)
-                    *reinterpret_cast<float4 *>(a.out + ((size_t) (tok0 + tile * QT + row) * a.n_head + head) * D + pass * DH + c * 4) = v;
+                if (tile * QT + row < n_q) {
+                    const size_t th = (size_t) (tok0 + tile * QT + row) * a.n_head + head;
+                    float * dst = partial ? a.part_o + (th * a.n_split + sp) * D : a.out + th * D;
+                    *reinterpret_cast<float4 *>(dst + pass * DH + c * 4) = v;
+                }
             }
             if (pass + 1 < D / DH) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         }
@@ -379,22 +399,45 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const PrefillAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         if (tid == 0) {
-            unsigned long long * o8 = a.stamps + ((size_t) (s * gridDim.y + hk) * gridDim.x + tile) * 8;
+            unsigned long long * o8 = a.stamps + ((size_t) (s * gridDim.y + hk) * gridDim.x + xr) * 8;
             o8[0] = t_q - t_begin; o8[1] = t_loop - t_q; o8[2] = t_end - t_loop; o8[3] = t_stage; o8[4] = t_qk; o8[5] = t_sm; o8[6] = t_pv; o8[7] = t_begin;
         }
     }
+}
+
+// merge of the split-KV shares: out = sum_j O_j 2^(m_j - M) / sum_j l_j 2^(m_j - M); one workgroup per (token, head).
+// Shares are selected, never multiplied, when their weight is zero (an empty share's O is not written).
+template <int D>
+__global__ void __launch_bounds__(D / 4) prefill_combine_kernel(const PrefillArgs a) {
+    const int head = blockIdx.x, tok = blockIdx.y, c = threadIdx.x;
+    const size_t th = (size_t) tok * a.n_head + head;
+    const float * ml = a.part_ml + th * a.n_split * 2;
+    float M = -INFINITY;
+    for (int j = 0; j < a.n_split; ++j) M = fmaxf(M, ml[2 * j]);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float  L = 0.0f;
+    for (int j = 0; j < a.n_split; ++j) {
+        const float mj = ml[2 * j];
+        if (mj == -INFINITY) continue;
+        const float w = exp2f(mj - M);
+        const float4 v = *reinterpret_cast<const float4 *>(a.part_o + (th * a.n_split + j) * D + c * 4);
+        acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y); acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+        L = fmaf(ml[2 * j + 1], w, L);
+    }
+    const float inv = 1.0f / L;   // every cell masked -> 0 * inf = NaN, as the single-share kernel's 1 / 0
+    *reinterpret_cast<float4 *>(a.out + th * D + c * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
 template <int KT, int VT, int D, int G>
 int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
     if constexpr (KT == PKV_TYPE_F16 && VT == PKV_TYPE_F16 && D == 128 && G == 4) {
         if (pa.stamps) {
-            hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, true>), dim3(n_tiles, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
+            hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, true>), dim3(n_tiles * pa.n_split, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa);
             PKV_HIP(hipGetLastError());
             return PKV_OK;
         }
     }
-    const dim3 grid(n_tiles, pa.n_head_kv, n_seq), block(64 * G);
+    const dim3 grid(n_tiles * pa.n_split, pa.n_head_kv, n_seq), block(64 * G);
     if (pa.mask) {
         if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true, false, true>), grid, block, 0, st, pa);
         else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, false, true>), grid, block, 0, st, pa);
@@ -402,6 +445,7 @@ int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
         if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true>), grid, block, 0, st, pa);
         else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false>), grid, block, 0, st, pa);
     }
+    if (pa.n_split > 1) hipLaunchKernelGGL((prefill_combine_kernel<D>), dim3(pa.n_head, pa.n_tok_total), dim3(D / 4), 0, st, pa);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
@@ -439,7 +483,13 @@ int launch_v(const PrefillArgs & pa, int VT, int D, int G, int n_tiles, int n_se
 
 void * g_prefill_stamps = nullptr;  // set by pkv_debug_set_prefill_stamps (diagnostic)
 void set_prefill_stamps(void * p) { g_prefill_stamps = p; }
-size_t prefill_workspace_bytes(int, int, int) { return 0; }
+// scratch of the split-KV path (opportunistic: a call whose workspace is smaller simply runs unsplit).  Splitting only
+// pays when the grid is small, i.e. for at most a few thousand query tokens per launch.
+constexpr int PREFILL_MAX_SPLIT = 8, PREFILL_SPLIT_MAX_TOK = 2048;
+size_t prefill_workspace_bytes(int n_tok, int n_head, int D) {
+    if (n_tok > PREFILL_SPLIT_MAX_TOK) return 0;
+    return (size_t) n_tok * n_head * PREFILL_MAX_SPLIT * (D + 2) * sizeof(float);
+}
 
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.q && a.out && a.k_pool && a.v_pool && a.block_table && a.seq_lens && a.q_start, "pkv_attn_prefill: null pointer");
@@ -463,6 +513,20 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.max_bias == 0.0f || a.mask, "pkv_attn_prefill: max_bias (ALiBi) needs a mask");
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
     const int n_tiles = (a.max_q_per_seq + QT - 1) / QT, G = a.n_head / a.n_head_kv;
+    // split-KV when the launch would leave most of the 256 CUs (2 workgroups each) idle and the past is long enough to share
+    pa.n_split = 1; pa.n_tok_total = a.n_tok; pa.part_o = nullptr; pa.part_ml = nullptr;
+    const long long n_wg = (long long) n_tiles * a.n_head_kv * a.n_seq;
+    const int nkt_max = (a.max_seq_len + KVT - 1) / KVT;
+    if (n_wg < 384 && a.n_tok <= PREFILL_SPLIT_MAX_TOK && !pa.stamps) {
+        int ns = (int) std::min<long long>(PREFILL_MAX_SPLIT, (512 + n_wg - 1) / n_wg);
+        ns = std::min(ns, std::max(1, nkt_max / 8));               // at least ~8 KV tiles (512 cells) per share: below that the merge launch costs more than it saves
+        const size_t need = (size_t) a.n_tok * a.n_head * ns * (a.head_dim + 2) * sizeof(float);
+        if (ns > 1 && a.workspace && a.workspace_bytes >= need) {
+            pa.n_split = ns;
+            pa.part_o  = (float *) a.workspace;
+            pa.part_ml = pa.part_o + (size_t) a.n_tok * a.n_head * ns * a.head_dim;
+        }
+    }
     switch (a.type_k) {
         case PKV_TYPE_F16:  return launch_v<PKV_TYPE_F16>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);
         case PKV_TYPE_Q8_0: return launch_v<PKV_TYPE_Q8_0>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);

@@ -169,6 +169,8 @@ size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq
     return a > b ? a : b;
 }
 
+size_t pkv_attn_prefill_workspace_bytes(int n_tok, int n_head, int head_dim) { return prefill_workspace_bytes(n_tok, n_head, head_dim); }
+
 int pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(workspace != nullptr, "pkv_attn_workspace_init: null workspace");

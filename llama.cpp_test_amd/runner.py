@@ -18,7 +18,7 @@ from typing import List, Sequence
 import numpy as np
 
 from . import (ATTN_NONCAUSAL, PagedKVCache, PkvError, RopeParams, attn_decode, attn_decode_step, attn_prefill,  # noqa: F401
-               attn_workspace, qkv_prepare, rope_cache, rope_params)
+               attn_prefill_workspace_bytes, attn_workspace, qkv_prepare, rope_cache, rope_params)
 
 
 class AttnPathRunner:
@@ -34,8 +34,10 @@ class AttnPathRunner:
         self.rope = rope if rope is not None else rope_params(n_dims=head_dim)
         self.scale = head_dim ** -0.5
         self.max_seq_len = max_seq_len or n_blocks * block_size
-        # scratch of the split-KV decode (one query token per sequence, so at most n_seq_max tokens); prefill needs none
-        self.ws = attn_workspace(n_seq_max, n_head, head_dim, self.max_seq_len, block_size)
+        # scratch of the split-KV decode (one query token per sequence, so at most n_seq_max tokens) and of the prefill
+        # kernel's split-KV mode (small ubatches over a long past)
+        self.ws = attn_workspace(n_seq_max, n_head, head_dim, self.max_seq_len, block_size,
+                                 min_bytes=attn_prefill_workspace_bytes(min(max_batch_tokens, 2048), n_head, head_dim))
         self.max_batch_tokens = max_batch_tokens
 
     # llama_kv_self_* pass-throughs used by drivers

@@ -7,7 +7,7 @@ pkv = _load_pkg.load()
 H, HK, D, BS = 32, 8, 128, 128
 for kv_type in (("f16",) if os.environ.get("PKV_PREFILL_ONE") else ("f16", "q8_0")):
     t = pkv.TYPE_BY_NAME[kv_type]
-    CASES = ((32, 512, 0), (1, 512, 0), (4, 2048, 0), (1, 512, 3584), (1, 4096, 0))
+    CASES = ((32, 512, 0), (1, 512, 0), (4, 2048, 0), (1, 512, 3584), (1, 4096, 0), (1, 512, 15872))
     if os.environ.get("PKV_PREFILL_ONE"):
         CASES = CASES[:1]
     for n_seq, n_q, past in CASES:
@@ -26,7 +26,8 @@ for kv_type in (("f16",) if os.environ.get("PKV_PREFILL_ONE") else ("f16", "q8_0
         qs = torch.arange(0, (n_seq + 1) * n_q, n_q, dtype=torch.int32, device="cuda")
         q = torch.rand((n_seq * n_q, H, D), generator=gen, device="cuda") * 2 - 1
         out = torch.empty_like(q)
-        ws = pkv.attn_workspace(n_seq * n_q, H, D, L, BS)       # allocated once: a per-call workspace costs a fill kernel per launch
+        # allocated once (a per-call workspace costs a fill kernel per launch); sized for the kernel's split-KV mode
+        ws = torch.empty(max(16, pkv.attn_prefill_workspace_bytes(n_seq * n_q, H, D)), dtype=torch.uint8, device="cuda")
         run = lambda: pkv.attn_prefill(q, kp, vp, bt, sl, qs, n_head_kv=HK, type_k=t, type_v=t, block_size=BS, scale=D ** -0.5,
                                        max_seq_len=L, max_q_per_seq=n_q, out=out, workspace=ws)
         for _ in range(3):

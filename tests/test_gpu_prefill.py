@@ -144,3 +144,38 @@ def test_prefill_general_mask_noncausal(pkv, O, tk, max_bias, softcap):
                                softcap=softcap)
         assert nmse(out.cpu().numpy(), ref) <= 5e-4, (n_q,)
         assert np.abs(out.cpu().numpy() - ref).max() <= 3e-3
+
+
+@pytest.mark.parametrize("tk,nkv,nh", [(1, 2, 8), (8, 1, 8), (1, 8, 32)])
+def test_prefill_split_kv_equals_unsplit(pkv, O, tk, nkv, nh):
+    """Small launches over a long past (a 512-token ubatch deep into a long prompt) share each query tile's KV range over
+    several workgroups and merge the (m, l, O) partials.  The split is opportunistic — it needs the scratch
+    pkv_attn_prefill_workspace_bytes asks for — so the same call with a 16-byte workspace runs unsplit.  Both round P to f16
+    relative to their own running maximum, so they agree to the f16 weight quantum (1e-4 on O(0.1) outputs), not bit for
+    bit; the split result itself must meet the oracle bar.  Ragged batch: one sequence shorter than a share."""
+    rng = np.random.default_rng(tk + nkv)
+    D = 128
+    lens, n_qs = [3000, 70, 1500], [96, 64, 33]
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
+    q_start = np.concatenate([[0], np.cumsum(n_qs)]).astype(np.int32)
+    q = rng.uniform(-1, 1, (int(q_start[-1]), nh, D)).astype(np.float32)
+    kw = dict(n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()), max_q_per_seq=max(n_qs))
+    args = (dev(q), dev(kp), dev(vp), dev(bt), dev(sl), dev(q_start))
+    split = pkv.attn_prefill(*args, **kw)                                     # default workspace: split-KV
+    plain = pkv.attn_prefill(*args, workspace=torch.zeros(16, dtype=torch.uint8, device="cuda"), **kw)
+    torch.cuda.synchronize()
+    a, b = split.cpu().numpy(), plain.cpu().numpy()
+    assert np.isfinite(a).all()
+    assert np.abs(a - b).max() <= 1e-4
+    for s, (n, nq) in enumerate(zip(lens, n_qs)):
+        kc = O.pool_gather(kp, tk, 0, bt[s], n, D=D, block_size=128)
+        vc = O.pool_gather(vp, tk, 1, bt[s], n, D=D, block_size=128)
+        mask = np.zeros((nq, n), np.float16)
+        for j in range(nq):
+            mask[j, n - nq + j + 1:] = -np.inf
+        qs = q[q_start[s]:q_start[s + 1]].transpose(1, 0, 2)
+        exact = O.flash_attn_f64(qs, kc, vc, mask, type_k=tk, type_v=tk, scale=D ** -0.5)
+        ref = O.flash_attn_ext(qs, kc, vc, mask, type_k=tk, type_v=tk, scale=D ** -0.5, n_threads=8)
+        got = a[q_start[s]:q_start[s + 1]]                                   # oracle output is [n_q][n_head][D] too
+        assert nmse(got, ref) <= 5e-4
+        assert np.abs(got - exact).max() <= 1e-3
