@@ -1,12 +1,23 @@
+#!/bin/bash
+# End-of-round evidence on the GPU box: the whole -m gpu suite, smoke(), the profile set (probes/profile_round.sh) and the
+# secondary bench configurations quoted in DESIGN.md §5.  Summarise afterwards with probes/summarize_profile.py.
 set -e
-cd $GRAFT_REPO_ROOT
+cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
 tail -3 gpurun_out/gpu_tests.log
-python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-cat gpurun_out/bench_default.json
-python bench.py --no-cpu-baseline --fused-merge > gpurun_out/bench_fusedmerge.json 2>> gpurun_out/bench_default.err
-cat gpurun_out/bench_fusedmerge.json
-rm -rf gpurun_out/trace1 && rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace1 -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 > gpurun_out/trace1.log 2>&1
-python probes/timeline.py gpurun_out/trace1 | tee gpurun_out/timeline1.txt
-rm -rf gpurun_out/trace1
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 && tail -2 gpurun_out/smoke.log
+bash probes/profile_round.sh
+O=gpurun_out/prof_round
+python3 bench.py --no-cpu-baseline --n-seq 32 > $O/bench_nseq32.json
+python3 bench.py --no-cpu-baseline --n-seq 32 --ctx 640 > $O/bench_nseq32_ctx640.json
+python3 bench.py --no-cpu-baseline --kv-type q8_0 > $O/bench_q8_0.json
+python3 bench.py --no-cpu-baseline --kv-type q4_0 > $O/bench_q4_0.json
+python3 bench.py --no-cpu-baseline --model 70b --ctx 16384 > $O/bench_70b_ctx16384.json
+python3 bench.py --no-cpu-baseline --two-call > $O/bench_two_call.json
+python3 probes/bench_prefill.py > $O/bench_prefill.txt
+python3 probes/batched_bench.py > $O/batched_bench.txt
+for f in $O/bench_nseq32.json $O/bench_nseq32_ctx640.json $O/bench_q8_0.json $O/bench_q4_0.json $O/bench_70b_ctx16384.json $O/bench_two_call.json; do
+  python3 -c "import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['kernel_us']['mean'], 'us', d['roofline']['frac'])"
+done
+cat $O/bench_prefill.txt $O/batched_bench.txt
