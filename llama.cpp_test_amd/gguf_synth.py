@@ -1,0 +1,215 @@
+"""Synthetic random-weight GGUF writer + minimal loader.
+
+File format = GGUF v3 as the reference reads and writes it (/root/reference/ggml/include/gguf.h:1-30, 54-67; reader
+/root/reference/ggml/src/gguf.cpp): magic "GGUF", u32 version, i64 n_tensors, i64 n_kv; KV pairs {string key, u32 type,
+value}; tensor infos {string name, u32 n_dims, i64 ne[n_dims], u32 ggml_type, u64 offset}; padding to
+`general.alignment` (default 32); tensor data, each tensor padded to the alignment.  Strings are u64 length + bytes.
+
+`synth_llama()` writes a llama-architecture model with random weights (keys as /root/reference/src/llama-model.cpp:406-521
+reads them, tensors as :1585-1625 creates them, tokenizer "no_vocab", /root/reference/src/llama-vocab.cpp:1358) so that the
+reference's own loader and this package read the same file.  There is no network and no real checkpoint in this build:
+every weight is seeded noise, as BASELINE.md prescribes.  Host-side only (numpy); nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, Iterable, List, Tuple
+
+import numpy as np
+
+MAGIC, VERSION, DEFAULT_ALIGNMENT = b"GGUF", 3, 32
+# gguf_type (gguf.h:54-67)
+T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I64, T_F64 = range(13)
+_SCALAR = {T_U8: "<B", T_I8: "<b", T_U16: "<H", T_I16: "<h", T_U32: "<I", T_I32: "<i", T_F32: "<f", T_BOOL: "<?", T_U64: "<Q",
+           T_I64: "<q", T_F64: "<d"}
+# ggml_type ids used here (/root/reference/ggml/include/ggml.h:351-392)
+GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0 = 0, 1, 2, 8
+_BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34)}   # (elements, bytes) per block
+
+
+def row_bytes(t: int, ne0: int) -> int:
+    n, b = _BLOCK[t]
+    assert ne0 % n == 0
+    return ne0 // n * b
+
+
+def _s(x: str) -> bytes:
+    b = x.encode()
+    return struct.pack("<Q", len(b)) + b
+
+
+def _kv(key: str, typ: int, val) -> bytes:
+    out = _s(key) + struct.pack("<I", typ)
+    if typ == T_STR:
+        return out + _s(val)
+    if typ == T_ARR:
+        et, items = val
+        out += struct.pack("<IQ", et, len(items))
+        return out + (b"".join(_s(v) for v in items) if et == T_STR else b"".join(struct.pack(_SCALAR[et], v) for v in items))
+    return out + struct.pack(_SCALAR[typ], val)
+
+
+def quantize_q8_0(x: np.ndarray) -> bytes:
+    """quantize_row_q8_0_ref (/root/reference/ggml/src/ggml-quants.c:194-215): d = amax/127 as f16, q = roundf(x / d)"""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 32)
+    amax = np.abs(x).max(axis=1)
+    d = (amax / 127.0).astype(np.float32)
+    inv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1), 0).astype(np.float32)
+    y = x * inv[:, None]
+    q = np.trunc(y + np.copysign(np.float32(0.5), y)).astype(np.int8)          # roundf: half away from zero
+    out = np.empty((x.shape[0], 34), np.uint8)
+    out[:, :2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = q.view(np.uint8)
+    return out.tobytes()
+
+
+def encode(x: np.ndarray, t: int) -> bytes:
+    if t == GGML_F32:
+        return np.ascontiguousarray(x, np.float32).tobytes()
+    if t == GGML_F16:
+        return np.ascontiguousarray(x, np.float32).astype(np.float16).tobytes()
+    if t == GGML_Q8_0:
+        return quantize_q8_0(x)
+    raise ValueError(f"unsupported tensor type {t}")
+
+
+def write_gguf(path: str, kv: List[Tuple[str, int, object]], tensors: List[Tuple[str, Tuple[int, ...], int, bytes]],
+               alignment: int = DEFAULT_ALIGNMENT) -> None:
+    """kv: (key, gguf_type, value); tensors: (name, ne (ggml order, ne[0] fastest), ggml_type, raw bytes)"""
+    if alignment != DEFAULT_ALIGNMENT:
+        kv = list(kv) + [("general.alignment", T_U32, alignment)]
+    head = MAGIC + struct.pack("<Iqq", VERSION, len(tensors), len(kv)) + b"".join(_kv(*e) for e in kv)
+    infos, off = [], 0
+    for name, ne, t, data in tensors:
+        assert len(data) == int(np.prod(ne[1:], dtype=np.int64)) * row_bytes(t, ne[0]), name
+        infos.append(_s(name) + struct.pack("<I", len(ne)) + b"".join(struct.pack("<q", n) for n in ne) + struct.pack("<IQ", t, off))
+        off += -(-len(data) // alignment) * alignment
+    meta = head + b"".join(infos)
+    with open(path, "wb") as f:
+        f.write(meta)
+        f.write(b"\0" * (-len(meta) % alignment))
+        for _, _, _, data in tensors:
+            f.write(data)
+            f.write(b"\0" * (-len(data) % alignment))
+
+
+def read_gguf(path: str):
+    """minimal loader: (kv dict key -> (gguf_type, value), tensors dict name -> (ne, ggml_type, offset, np.uint8 view), alignment)"""
+    buf = np.memmap(path, np.uint8, "r")
+    raw = memoryview(buf)
+    pos = 0
+
+    def rd(fmt):
+        nonlocal pos
+        v = struct.unpack_from(fmt, raw, pos)
+        pos += struct.calcsize(fmt)
+        return v if len(v) > 1 else v[0]
+
+    def rs():
+        nonlocal pos
+        n = rd("<Q")
+        s = bytes(raw[pos:pos + n]).decode()
+        pos += n
+        return s
+    if bytes(raw[:4]) != MAGIC:
+        raise ValueError("not a GGUF file")
+    pos = 4
+    version, n_tensors, n_kv = rd("<Iqq")
+    if version != VERSION:
+        raise ValueError(f"GGUF version {version} not supported")
+    kv: Dict[str, Tuple[int, object]] = {}
+    for _ in range(n_kv):
+        key, typ = rs(), rd("<I")
+        if typ == T_STR:
+            val = rs()
+        elif typ == T_ARR:
+            et, n = rd("<IQ")
+            val = (et, [rs() if et == T_STR else rd(_SCALAR[et]) for _ in range(n)])
+        else:
+            val = rd(_SCALAR[typ])
+        kv[key] = (typ, val)
+    infos = []
+    for _ in range(n_tensors):
+        name, nd = rs(), rd("<I")
+        ne = tuple(rd("<q") for _ in range(nd))
+        t, off = rd("<IQ")
+        infos.append((name, ne, t, off))
+    alignment = kv.get("general.alignment", (T_U32, DEFAULT_ALIGNMENT))[1]
+    data0 = -(-pos // alignment) * alignment
+    tensors = {}
+    for name, ne, t, off in infos:
+        n = int(np.prod(ne[1:], dtype=np.int64)) * row_bytes(t, ne[0])
+        tensors[name] = (ne, t, off, buf[data0 + off:data0 + off + n])
+    return kv, tensors, alignment
+
+
+def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv: int, n_ff: int, n_vocab: int, n_ctx: int = 4096,
+                rope_freq_base: float = 10000.0, rms_eps: float = 1e-5, wtype: int = GGML_F16, seed: int = 1234, name: str = "synthetic-llama"):
+    """random-weight llama-arch GGUF (norm weights f32 near 1, matrices N(0, 1/sqrt(fan_in)) in `wtype`)"""
+    rng = np.random.default_rng(seed)
+    hd = n_embd // n_head
+    kv = [("general.architecture", T_STR, "llama"), ("general.name", T_STR, name), ("llama.context_length", T_U32, n_ctx),
+          ("llama.embedding_length", T_U32, n_embd), ("llama.block_count", T_U32, n_layer), ("llama.feed_forward_length", T_U32, n_ff),
+          ("llama.attention.head_count", T_U32, n_head), ("llama.attention.head_count_kv", T_U32, n_head_kv),
+          ("llama.rope.dimension_count", T_U32, hd), ("llama.rope.freq_base", T_F32, rope_freq_base),
+          ("llama.attention.layer_norm_rms_epsilon", T_F32, rms_eps), ("llama.vocab_size", T_U32, n_vocab),
+          ("tokenizer.ggml.model", T_STR, "no_vocab")]
+    tensors = []
+
+    def mat(nm, ne0, ne1):                      # ggml [ne0 = in, ne1 = out]; numpy array [ne1][ne0]
+        w = (rng.standard_normal((ne1, ne0)) / np.sqrt(ne0)).astype(np.float32)
+        tensors.append((nm, (ne0, ne1), wtype, encode(w, wtype)))
+
+    def vec(nm, n):
+        tensors.append((nm, (n,), GGML_F32, encode(1.0 + 0.1 * rng.standard_normal(n), GGML_F32)))
+    mat("token_embd.weight", n_embd, n_vocab)
+    vec("output_norm.weight", n_embd)
+    mat("output.weight", n_embd, n_vocab)
+    for il in range(n_layer):
+        p = f"blk.{il}."
+        vec(p + "attn_norm.weight", n_embd)
+        mat(p + "attn_q.weight", n_embd, n_embd)
+        mat(p + "attn_k.weight", n_embd, hd * n_head_kv)
+        mat(p + "attn_v.weight", n_embd, hd * n_head_kv)
+        mat(p + "attn_output.weight", n_embd, n_embd)
+        vec(p + "ffn_norm.weight", n_embd)
+        mat(p + "ffn_gate.weight", n_embd, n_ff)
+        mat(p + "ffn_down.weight", n_ff, n_embd)
+        mat(p + "ffn_up.weight", n_embd, n_ff)
+    write_gguf(path, kv, tensors)
+    return kv, tensors
+
+
+def describe(path: str) -> str:
+    """canonical text dump (one line per KV / tensor, data as FNV-1a 64) — the parity tests compare it with the same dump
+    produced through the reference's gguf API"""
+    kv, tensors, _ = read_gguf(path)
+    lines = []
+    for k, (t, v) in kv.items():
+        if t == T_ARR:
+            v = f"[{v[0]}:{len(v[1])}] " + ",".join(_fmt(v[0], x) for x in v[1])
+        else:
+            v = _fmt(t, v)
+        lines.append(f"kv {k} {t} {v}")
+    for name, (ne, t, off, data) in tensors.items():
+        lines.append(f"tensor {name} {t} {'x'.join(str(n) for n in ne)} {off} {fnv1a64(data):016x}")
+    return "\n".join(lines) + "\n"
+
+
+def _fmt(t: int, v) -> str:
+    if t == T_F32:
+        return "%.9g" % float(np.float32(v))
+    if t == T_F64:
+        return "%.17g" % float(v)
+    if t == T_BOOL:
+        return "1" if v else "0"
+    return str(v)
+
+
+def fnv1a64(data) -> int:
+    h = 0xcbf29ce484222325
+    a = np.asarray(data, np.uint8)
+    # vectorised over 8-byte lanes would change the hash; files here are small, so plain chunks through Python ints
+    for b in a.tobytes():
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h

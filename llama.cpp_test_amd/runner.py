@@ -40,6 +40,25 @@ class AttnPathRunner:
                                  min_bytes=attn_prefill_workspace_bytes(min(max_batch_tokens, 2048), n_head, head_dim))
         self.max_batch_tokens = max_batch_tokens
 
+    @classmethod
+    def from_gguf(cls, path: str, *, type_k: int, type_v: int, n_blocks: int, n_seq_max: int, **kw):
+        """geometry and RoPE parameters from a llama-architecture GGUF (the keys llama_model::load_hparams reads,
+        /root/reference/src/llama-model.cpp:406-521) — the minimal loader half of SURVEY §8(f) row 2"""
+        from .gguf_synth import read_gguf
+        meta, _, _ = read_gguf(path)
+
+        def get(key, default=None):
+            return meta[key][1] if key in meta else default
+        arch = get("general.architecture")
+        if arch != "llama":
+            raise PkvError(-4, f"unsupported architecture {arch!r} (llama only)")
+        n_embd, n_head = get("llama.embedding_length"), get("llama.attention.head_count")
+        hd = get("llama.attention.key_length", n_embd // n_head)
+        rope = rope_params(n_dims=get("llama.rope.dimension_count", hd), mode=0, n_ctx_orig=get("llama.context_length", 8192),
+                           freq_base=get("llama.rope.freq_base", 10000.0))
+        return cls(n_layer=get("llama.block_count"), n_head=n_head, n_head_kv=get("llama.attention.head_count_kv", n_head),
+                   head_dim=hd, type_k=type_k, type_v=type_v, n_blocks=n_blocks, n_seq_max=n_seq_max, rope=rope, **kw)
+
     # llama_kv_self_* pass-throughs used by drivers
     def clear(self):
         self.cache.clear()

@@ -1,0 +1,78 @@
+"""ctypes front end of the model/GGUF half of oracle/_ref/libref_kv.so (driver oracle/ref_model_driver.cpp): the REFERENCE's
+GGUF reader/writer and its llama runtime on the CPU backend.  TEST INFRASTRUCTURE ONLY; exists only where the reference was
+compiled (this container) — elsewhere tests use the fixtures tests/golden/make_model_golden.py produced with it."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import ref_kv
+
+
+def available() -> bool:
+    return ref_kv.available()
+
+
+def _lib():
+    L = ref_kv.lib()
+    L.refgguf_describe.restype = C.c_int64
+    L.refmodel_load.restype = C.c_void_p
+    L.refmodel_free.restype = None
+    L.refmodel_capture_data.restype = None
+    L.refmodel_seq_rm.restype = None
+    L.refmodel_seq_cp.restype = None
+    return L
+
+
+def gguf_describe(path: str) -> str:
+    n = _lib().refgguf_describe(path.encode(), None, C.c_size_t(0))
+    if n < 0:
+        raise RuntimeError(f"the reference's gguf_init_from_file rejected {path}")
+    buf = C.create_string_buffer(int(n) + 1)
+    _lib().refgguf_describe(path.encode(), buf, C.c_size_t(int(n) + 1))
+    return buf.value.decode()
+
+
+def gguf_write_demo(path: str) -> None:
+    if _lib().refgguf_write_demo(path.encode()) != 0:
+        raise RuntimeError("gguf_write_to_file failed")
+
+
+class RefModel:
+    """llama_model + llama_context of the reference on its CPU backend; decode() returns the captured attention tensors"""
+
+    def __init__(self, path: str, *, n_ctx: int, n_batch: int = 512, n_seq_max: int = 1, flash_attn: bool = True, type_k: int = 1,
+                 type_v: int = 1, n_threads: int = 8):
+        self.h = C.c_void_p(_lib().refmodel_load(path.encode(), n_ctx, n_batch, n_seq_max, int(flash_attn), type_k, type_v, n_threads))
+        if not self.h:
+            raise RuntimeError(f"the reference could not load {path}")
+        self.op_rope = _lib().refmodel_op_rope()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib().refmodel_free(self.h)
+            self.h = None
+
+    def seq_rm(self, s, p0, p1): _lib().refmodel_seq_rm(self.h, s, p0, p1)
+    def seq_cp(self, a, b, p0, p1): _lib().refmodel_seq_cp(self.h, a, b, p0, p1)
+
+    def decode(self, tokens, pos, seq_id):
+        """one llama_decode; returns {layer: dict(q, k, v = un-rotated projections [n_tok][heads][D]; q_rope, k_rope; out = kqv_out
+        [n_tok][n_head][D])}"""
+        t, p, s = (np.ascontiguousarray(x, np.int32) for x in (tokens, pos, seq_id))
+        rc = _lib().refmodel_decode(self.h, t.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), len(t))
+        if rc != 0:
+            raise RuntimeError(f"llama_decode returned {rc}")
+        layers = {}
+        name = C.create_string_buffer(64)
+        for i in range(_lib().refmodel_n_captured(self.h)):
+            op, ne = C.c_int(), (C.c_int64 * 4)()
+            n = _lib().refmodel_capture_info(self.h, i, name, 64, C.byref(op), ne)
+            data = np.empty(n, np.float32)
+            _lib().refmodel_capture_data(self.h, i, data.ctypes.data_as(C.c_void_p))
+            kind, il = name.value.decode().rsplit("-", 1)
+            arr = data.reshape([int(x) for x in reversed(list(ne)) if True])       # ggml ne order reversed = C order
+            key = {"Qcur": "q", "Kcur": "k", "Vcur": "v", "kqv_out": "out"}[kind] + ("_rope" if op.value == self.op_rope else "")
+            layers.setdefault(int(il), {})[key] = arr
+        return layers

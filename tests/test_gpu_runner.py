@@ -71,3 +71,38 @@ def test_runner_matches_dense_model(pkv, O, tk):
     step([0, 1], [lens[0], lens[0]])
     step([1, 0], [lens[0] + 1, lens[0] + 1])
     r.close()
+
+
+def test_tinyllama_tg128_from_empty_cache(pkv, O):
+    """BASELINE config 1 (the reference's own CPU-runnable case): TinyLlama-1.1B geometry (head_dim 64, 32 heads, 4 kv heads,
+    RoPE base 1e4), llama-bench tg128 semantics: one sequence decoded token by token from an EMPTY cache, block_size 128,
+    so the run crosses a block boundary (token 129 allocates the second block).  Every step goes through the fused decode
+    step and is checked against the oracle chain rope -> from_float -> flash_attn_ext over all cells stored so far."""
+    import _load_pkg
+    _load_pkg.load()
+    from llama_cpp_test_amd.runner import AttnPathRunner
+    rng = np.random.default_rng(7)
+    L, H, HK, D = 3, 32, 4, 64
+    rope = pkv.rope_params(n_dims=D, freq_base=10000.0)
+    r = AttnPathRunner(n_layer=L, n_head=H, n_head_kv=HK, head_dim=D, type_k=1, type_v=1, n_blocks=3, n_seq_max=1, rope=rope,
+                       max_batch_tokens=32)
+    ks = [[] for _ in range(L)]
+    vs = [[] for _ in range(L)]
+    for t in range(131):
+        q = [rng.uniform(-1, 1, (1, H, D)).astype(np.float32) for _ in range(L)]
+        k = [rng.uniform(-1, 1, (1, HK, D)).astype(np.float32) for _ in range(L)]
+        v = [rng.uniform(-1, 1, (1, HK, D)).astype(np.float32) for _ in range(L)]
+        outs = r.decode([0], [t], [dev(x) for x in q], [dev(x) for x in k], [dev(x) for x in v])
+        torch.cuda.synchronize()
+        pos = np.array([t], np.int32)
+        for il in range(L):
+            ks[il].append(O.from_float(1, O.rope(k[il], pos, n_dims=D, freq_base=10000.0))[0])
+            vs[il].append(O.from_float(1, v[il])[0])
+            if t % 16 == 0 or t >= 126:                                  # every 16th step and around the block boundary
+                qr = O.rope(q[il], pos, n_dims=D, freq_base=10000.0)[0]
+                kc, vc = np.stack(ks[il]).transpose(1, 0, 2), np.stack(vs[il]).transpose(1, 0, 2)
+                ref = O.flash_attn_ext(qr[:, None, :], kc, vc, None, type_k=1, type_v=1, scale=D ** -0.5)[0]
+                got = outs[il].cpu().numpy()[0]
+                assert np.abs(got - ref).max() <= 2.5e-3 and nmse(got, ref) <= 5e-4, (t, il)
+    assert r.cache.seq_len(0) == 131 and len(r.cache.seq_blocks(0)) == 2
+    r.close()
