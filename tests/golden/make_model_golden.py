@@ -41,8 +41,9 @@ def scenario():
 
 
 def run(path, type_k, type_v, flash_attn, rng):
+    from oracle import cpu_oracle as O
     m = R.RefModel(path, n_ctx=512, n_batch=256, n_seq_max=2, flash_attn=flash_attn, type_k=type_k, type_v=type_v, n_threads=8)
-    out = {}
+    out, store = {}, {}
     for ci, (sid, pos) in enumerate(scenario()):
         tok = rng.integers(0, MODEL["n_vocab"], len(sid))
         layers = m.decode(tok, pos, sid)
@@ -54,6 +55,22 @@ def run(path, type_k, type_v, flash_attn, rng):
             out[f"c{ci}__l{il}__k"] = d["k"].reshape(n, HK, D)
             out[f"c{ci}__l{il}__v"] = d["v"].reshape(n, HK, D)
             out[f"c{ci}__l{il}__out"] = d["out"].reshape(n, H, D)
+            # yardstick: exact (f64) attention over the cells the cache really holds (rope -> stored type -> dequantized), and a
+            # check that the CPU oracle reproduces the model's output bit for bit
+            pos_a = np.array(pos, np.int32)
+            kw = dict(n_dims=D, freq_base=MODEL["rope_freq_base"], n_ctx_orig=MODEL["n_ctx"])
+            qr = O.rope(out[f"c{ci}__l{il}__q"], pos_a, **kw)
+            kr = O.from_float(type_k, O.rope(out[f"c{ci}__l{il}__k"], pos_a, **kw))
+            vr = O.from_float(type_v, out[f"c{ci}__l{il}__v"])
+            exact = np.empty((n, H, D), np.float32)
+            for i, s_ in enumerate(sid):
+                ks, vs = store.setdefault((il, int(s_)), ([], []))
+                ks.append(kr[i]); vs.append(vr[i])
+                kc, vc = np.stack(ks).transpose(1, 0, 2), np.stack(vs).transpose(1, 0, 2)
+                exact[i] = O.flash_attn_f64(qr[i][:, None, :], kc, vc, None, type_k=type_k, type_v=type_v, scale=D ** -0.5)[0]
+                same = O.flash_attn_ext(qr[i][:, None, :], kc, vc, None, type_k=type_k, type_v=type_v, scale=D ** -0.5)[0]
+                assert np.array_equal(same, out[f"c{ci}__l{il}__out"][i]), "the CPU oracle no longer reproduces llama_decode bit for bit"
+            out[f"c{ci}__l{il}__exact"] = exact
     return out
 
 
