@@ -188,6 +188,16 @@ int refmodel_decode(void * h, const int32_t * tokens, const int32_t * pos, const
     llama_batch_free(b);
     return rc;
 }
+// timing runs: the eval callback makes the scheduler compute node by node; a context without it decodes at full speed
+void refmodel_detach_capture(void * h) {
+    auto * rm = (RefModel *) h;
+    llama_context_params cp = llama_context_default_params();
+    cp.n_ctx = llama_n_ctx(rm->ctx); cp.n_batch = llama_n_batch(rm->ctx); cp.n_ubatch = llama_n_ubatch(rm->ctx); cp.n_seq_max = llama_n_seq_max(rm->ctx);
+    cp.n_threads = cp.n_threads_batch = llama_n_threads(rm->ctx);
+    cp.flash_attn = true; cp.no_perf = true;
+    llama_free(rm->ctx);
+    rm->ctx = llama_init_from_model(rm->model, cp);
+}
 void refmodel_seq_rm(void * h, int s, int p0, int p1) { llama_kv_self_seq_rm(((RefModel *) h)->ctx, s, p0, p1); }
 void refmodel_seq_cp(void * h, int a, int b, int p0, int p1) { llama_kv_self_seq_cp(((RefModel *) h)->ctx, a, b, p0, p1); }
 int refmodel_n_captured(void * h) { return (int) ((RefModel *) h)->caps.size(); }
