@@ -196,8 +196,10 @@ ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
 
 bool supports_cpy(const ggml_tensor * op) {
     const ggml_tensor * s = op->src[0], * d = op->src[1];
+    // the KV store of build_attn copies k_cur [head_dim, n_head_kv, n_tokens] into a 1-D view of the cache
+    // (/ref/src/llama-graph.cpp:1375-1397): shapes differ, the element order does not; rows of 64/128 keep quant blocks whole
     return s && d && s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) &&
-           ggml_nelements(s) == ggml_nelements(d) && s->ne[0] == d->ne[0] && s->ne[0] % 64 == 0;
+           ggml_nelements(s) == ggml_nelements(d) && s->ne[0] % 64 == 0;
 }
 ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     const ggml_tensor * s = op->src[0];

@@ -22,7 +22,9 @@ def available() -> bool:
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(_PATH)
+        # ggml first and globally: a ggml-backend plugin dlopen()ed later resolves ggml_backend_buffer_init & co against it
+        C.CDLL(os.path.join(_HERE, "_ref", "libggml_ref.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(_PATH, mode=C.RTLD_GLOBAL)
         L.refkv_create.restype = C.c_void_p
         L.refkv_state_write.restype = C.c_int64
         for f in ("refkv_free", "refkv_advance_head", "refkv_clear", "refkv_seq_cp", "refkv_seq_keep", "refkv_seq_add",

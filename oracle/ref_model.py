@@ -39,6 +39,17 @@ def gguf_write_demo(path: str) -> None:
         raise RuntimeError("gguf_write_to_file failed")
 
 
+def load_backend(so_path: str) -> None:
+    """register a ggml-backend plugin with the reference's registry (ggml_backend_load = what GGML_BACKEND_PATH triggers)"""
+    if _lib().refmodel_load_backend(so_path.encode()) != 0:
+        raise RuntimeError(f"ggml_backend_load({so_path}) failed")
+
+
+def set_gpu_layers(n: int) -> None:
+    """llama_model_params.n_gpu_layers of the models loaded next (0 = everything on the reference's CPU backend)"""
+    _lib().refmodel_set_gpu_layers(n)
+
+
 class RefModel:
     """llama_model + llama_context of the reference on its CPU backend; decode() returns the captured attention tensors"""
 
@@ -53,6 +64,12 @@ class RefModel:
         if getattr(self, "h", None):
             _lib().refmodel_free(self.h)
             self.h = None
+
+    def logits(self, n_vocab: int) -> np.ndarray:
+        out = np.empty(n_vocab, np.float32)
+        if _lib().refmodel_logits(self.h, out.ctypes.data_as(C.c_void_p), n_vocab) != n_vocab:
+            raise RuntimeError("no logits")
+        return out
 
     def seq_rm(self, s, p0, p1): _lib().refmodel_seq_rm(self.h, s, p0, p1)
     def seq_cp(self, a, b, p0, p1): _lib().refmodel_seq_cp(self.h, a, b, p0, p1)

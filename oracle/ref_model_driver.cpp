@@ -152,12 +152,18 @@ int refgguf_write_demo(const char * path) {
     return ok ? 0 : -1;
 }
 
+// load a ggml-backend plugin (what GGML_BACKEND_PATH does inside ggml_backend_load_all, ggml-backend-reg.cpp:581-585)
+int refmodel_load_backend(const char * so_path) { return ggml_backend_load(so_path) != nullptr ? 0 : -1; }
+
+static int g_n_gpu_layers = 0;
+void refmodel_set_gpu_layers(int n) { g_n_gpu_layers = n; }
+
 void * refmodel_load(const char * path, int n_ctx, int n_batch, int n_seq_max, int flash_attn, int type_k, int type_v, int n_threads) {
     static bool init = false;
     if (!init) { llama_backend_init(); init = true; }
     auto * rm = new RefModel();
     llama_model_params mp = llama_model_default_params();
-    mp.n_gpu_layers = 0;
+    mp.n_gpu_layers = g_n_gpu_layers;
     rm->model = llama_model_load_from_file(path, mp);
     if (!rm->model) { delete rm; return nullptr; }
     llama_context_params cp = llama_context_default_params();
@@ -200,6 +206,15 @@ void refmodel_detach_capture(void * h) {
 }
 void refmodel_seq_rm(void * h, int s, int p0, int p1) { llama_kv_self_seq_rm(((RefModel *) h)->ctx, s, p0, p1); }
 void refmodel_seq_cp(void * h, int a, int b, int p0, int p1) { llama_kv_self_seq_cp(((RefModel *) h)->ctx, a, b, p0, p1); }
+// logits of the last token of the last decode (n_vocab floats)
+int refmodel_logits(void * h, float * dst, int cap) {
+    auto * rm = (RefModel *) h;
+    const int nv = llama_vocab_n_tokens(llama_model_get_vocab(rm->model));
+    const float * l = llama_get_logits_ith(rm->ctx, -1);
+    if (!l || nv > cap) return -1;
+    memcpy(dst, l, (size_t) nv * sizeof(float));
+    return nv;
+}
 int refmodel_n_captured(void * h) { return (int) ((RefModel *) h)->caps.size(); }
 int refmodel_capture_info(void * h, int i, char * name, int name_cap, int * op, int64_t * ne) {
     const Capture & c = ((RefModel *) h)->caps[i];

@@ -1,0 +1,51 @@
+"""-m gpu: the UNMODIFIED reference runtime with the attention path on the MI355X.
+
+oracle/_ref/libref_kv.so is the reference's llama library compiled in place (+ our driver).  Here it loads our ggml-backend
+plugin exactly as GGML_BACKEND_PATH does (ggml_backend_load), loads a synthetic llama GGUF with n_gpu_layers = 99 — so the
+KV cache lives in the plugin's buffers and the scheduler sends GGML_OP_CPY (KV store) and GGML_OP_FLASH_ATTN_EXT (and what else
+the device claims) to it, while everything the device does not claim (mat-muls, norms) stays on the reference's CPU backend —
+and runs llama_decode.  The same model and tokens on a CPU-only context of the same library are the expected values:
+per-layer kqv_out NMSE <= 5e-4 (tests/test-backend-ops.cpp:3216), final logits NMSE <= 1e-4 with f16 KV and <= 5e-4 with
+q8_0 KV (there the prefill kernel keeps Q in f16 where the reference quantizes Q to q8_0: different, smaller, rounding noise).
+Skipped where the compiled reference or the plugin is absent."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import nmse
+from oracle import ref_model as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLUGIN = os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so")
+MODEL = dict(n_layer=2, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=96, n_ctx=1024, rope_freq_base=10000.0, seed=77)
+
+
+@pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
+@pytest.mark.parametrize("tk", [1, 8])
+def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk):
+    from llama_cpp_test_amd import gguf_synth as G
+    path = str(tmp_path / "m.gguf")
+    G.synth_llama(path, **MODEL)
+    rng = np.random.default_rng(5)
+    calls = [([0] * 70, list(range(70)))] + [([0], [70 + i]) for i in range(3)]
+    toks = [rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
+
+    def run(gpu_layers):
+        R.set_gpu_layers(gpu_layers)
+        m = R.RefModel(path, n_ctx=512, n_batch=128, flash_attn=True, type_k=tk, type_v=tk, n_threads=8)
+        outs = []
+        for (sid, pos), t in zip(calls, toks):
+            layers = m.decode(t, pos, sid)
+            outs.append(([layers[il]["out"].copy() for il in sorted(layers)], m.logits(MODEL["n_vocab"]).copy()))
+        return outs
+    cpu = run(0)
+    R.load_backend(PLUGIN)
+    gpu = run(99)
+    R.set_gpu_layers(0)
+    for ci, ((lc, logit_c), (lg, logit_g)) in enumerate(zip(cpu, gpu)):
+        for il, (a, b) in enumerate(zip(lc, lg)):
+            assert np.isfinite(b).all()
+            assert nmse(b, a) <= 5e-4, (ci, il)
+        assert nmse(logit_g, logit_c) <= (1e-4 if tk == 1 else 5e-4), ci
