@@ -22,6 +22,7 @@ def _lib():
     L.refmodel_capture_data.restype = None
     L.refmodel_seq_rm.restype = None
     L.refmodel_seq_cp.restype = None
+    L.refmodel_seq_add.restype = None
     return L
 
 
@@ -73,6 +74,7 @@ class RefModel:
 
     def seq_rm(self, s, p0, p1): _lib().refmodel_seq_rm(self.h, s, p0, p1)
     def seq_cp(self, a, b, p0, p1): _lib().refmodel_seq_cp(self.h, a, b, p0, p1)
+    def seq_add(self, s, p0, p1, d): _lib().refmodel_seq_add(self.h, s, p0, p1, d)
 
     def decode(self, tokens, pos, seq_id):
         """one llama_decode; returns {layer: dict(q, k, v = un-rotated projections [n_tok][heads][D]; q_rope, k_rope; out = kqv_out

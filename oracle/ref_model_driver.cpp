@@ -205,6 +205,7 @@ void refmodel_detach_capture(void * h) {
     rm->ctx = llama_init_from_model(rm->model, cp);
 }
 void refmodel_seq_rm(void * h, int s, int p0, int p1) { llama_kv_self_seq_rm(((RefModel *) h)->ctx, s, p0, p1); }
+void refmodel_seq_add(void * h, int s, int p0, int p1, int d) { llama_kv_self_seq_add(((RefModel *) h)->ctx, s, p0, p1, d); }
 void refmodel_seq_cp(void * h, int a, int b, int p0, int p1) { llama_kv_self_seq_cp(((RefModel *) h)->ctx, a, b, p0, p1); }
 // logits of the last token of the last decode (n_vocab floats)
 int refmodel_logits(void * h, float * dst, int cap) {

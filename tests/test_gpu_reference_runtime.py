@@ -29,14 +29,24 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk):
     path = str(tmp_path / "m.gguf")
     G.synth_llama(path, **MODEL)
     rng = np.random.default_rng(5)
-    calls = [([0] * 70, list(range(70)))] + [([0], [70 + i]) for i in range(3)]
-    toks = [rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
+    # two sequences: both prompts in ONE batch, interleaved decode steps (cells of the two sequences alternate in the ring,
+    # the KQ_mask separates them), then — f16 K only, the quantized K-shift graph needs a dequantizing CPY the device does not
+    # claim — a context shift of sequence 0 (seq_rm + seq_add: the K-shift RoPE runs in place on the cache, in our buffers)
+    calls = [([0] * 70 + [1] * 33, list(range(70)) + list(range(33)))] + [([0, 1], [70 + i, 33 + i]) for i in range(3)]
+    if tk == 1:
+        calls += ["shift", ([0, 1], [63, 36]), ([1, 0], [37, 64])]
+    toks = [None if c == "shift" else rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
 
     def run(gpu_layers):
         R.set_gpu_layers(gpu_layers)
-        m = R.RefModel(path, n_ctx=512, n_batch=128, flash_attn=True, type_k=tk, type_v=tk, n_threads=8)
+        m = R.RefModel(path, n_ctx=512, n_batch=128, n_seq_max=2, flash_attn=True, type_k=tk, type_v=tk, n_threads=8)
         outs = []
-        for (sid, pos), t in zip(calls, toks):
+        for c, t in zip(calls, toks):
+            if c == "shift":
+                m.seq_rm(0, 10, 20)                              # drop 10 tokens ...
+                m.seq_add(0, 20, -1, -10)                        # ... and slide the rest down: applied by the next llama_decode
+                continue
+            sid, pos = c
             layers = m.decode(t, pos, sid)
             outs.append(([layers[il]["out"].copy() for il in sorted(layers)], m.logits(MODEL["n_vocab"]).copy()))
         return outs
