@@ -287,6 +287,20 @@ void * pkv_cache_v_pool(pkv_cache * c, int layer);
  * pending K-shift (has_shift) to every layer on `stream`, then clear the deltas. */
 int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream);
 
+/* ---- FIRST SLICE of the rest of the decoder layer (correct and parity-checked, not yet tuned) ----
+ * What a llama layer needs besides the attention path, so that the reference runtime can keep whole layers on the device
+ * through the ggml-backend plugin.  All tensors device, f32, contiguous rows.
+ *   pkv_rms_norm_f32 : ggml_rms_norm, y[r] = x[r] / sqrt(mean(x[r]^2) + eps)   (/ref/ggml/src/ggml-cpu/ggml-cpu.c:8215-8260)
+ *   pkv_add_f32 / pkv_mul_f32 : y[r][i] = a[r][i] (+|*) b[r % b_rows][i]      (ggml_add / ggml_mul with row broadcast)
+ *   pkv_silu_f32     : x / (1 + exp(-x))                                       (ggml_silu, :2015)
+ *   pkv_mul_mat      : ggml_mul_mat, y[c][m] = sum_k W[m][k] x[c][k]; W = M rows of K elements in f32 / f16 / q8_0 (reference
+ *                      row format), x = n_cols rows of K f32, y = n_cols rows of M f32   (:7467-7640) */
+int pkv_rms_norm_f32(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, void * stream);
+int pkv_add_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
+int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
+int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream);
+int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream);
+
 /* Session state of the KV cache in the reference's byte format: llama_kv_cache_unified::state_write / state_read
  * (/ref/src/llama-kv-cache.cpp:848-1221; reached through llama_state_get_data / llama_state_seq_get_data,
  * /ref/include/llama.h:793-876).  Layout: u32 cell_count | per cell {i32 pos, u32 n_seq_id, i32 seq_id[n_seq_id]} |

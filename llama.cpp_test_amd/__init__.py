@@ -318,6 +318,50 @@ def pool_gather_rows(pool, rows, *, type, is_v, slot_block, slot_off, n_head_kv,
     return rows
 
 
+# ---- first slice of the rest of the decoder layer ----------------------------------------------------------
+def rms_norm(x, eps: float, out=None, stream=None):
+    """ggml_rms_norm over the last dim of a contiguous f32 tensor"""
+    out = x.new_empty(x.shape) if out is None else out
+    check(lib().pkv_rms_norm_f32(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), C.c_int64(x.numel() // x.shape[-1]), C.c_int64(x.shape[-1]),
+                                 C.c_float(eps), C.c_void_p(_stream(stream))))
+    return out
+
+
+def _binary(fn, a, b, out, stream):
+    out = a.new_empty(a.shape) if out is None else out
+    ne0 = a.shape[-1]
+    check(fn(C.c_void_p(_ptr(a)), C.c_void_p(_ptr(b)), C.c_void_p(_ptr(out)), C.c_int64(a.numel() // ne0), C.c_int64(ne0),
+             C.c_int64(b.numel() // ne0), C.c_void_p(_stream(stream))))
+    return out
+
+
+def add(a, b, out=None, stream=None):
+    """ggml_add: a + b, b's rows repeating over a's rows (same shape, residual, bias)"""
+    return _binary(lib().pkv_add_f32, a, b, out, stream)
+
+
+def mul(a, b, out=None, stream=None):
+    """ggml_mul: a * b with the same row broadcast (norm weights)"""
+    return _binary(lib().pkv_mul_f32, a, b, out, stream)
+
+
+def silu(x, out=None, stream=None):
+    out = x.new_empty(x.shape) if out is None else out
+    check(lib().pkv_silu_f32(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), C.c_int64(x.numel()), C.c_void_p(_stream(stream))))
+    return out
+
+
+def mul_mat(w, type_w: int, M: int, K: int, x, out=None, stream=None):
+    """ggml_mul_mat: w = M rows of K elements in f32 / f16 / q8_0 reference row format (device bytes), x f32 [n_cols][K] ->
+    f32 [n_cols][M]"""
+    import torch
+    n_cols = x.shape[0]
+    out = torch.empty((n_cols, M), dtype=torch.float32, device=x.device) if out is None else out
+    check(lib().pkv_mul_mat(C.c_void_p(_ptr(w)), type_w, C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), C.c_int64(M), C.c_int64(K),
+                            C.c_int64(n_cols), C.c_void_p(_stream(stream))))
+    return out
+
+
 # ---- llama_kv_cache mirror ---------------------------------------------------------------------------------------------
 class PagedKVCache:
     """`llama_kv_cache` method set (/root/reference/src/llama-kv-cache.h:17-26) over the C++ block manager.

@@ -209,6 +209,50 @@ ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     return GGML_STATUS_SUCCESS;
 }
 
+// ---- first slice of the rest of the decoder layer (include/mi355_paged_kv.h: pkv_rms_norm_f32 ... pkv_mul_mat) --------------------------
+bool f32c(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32 && ggml_is_contiguous(t); }
+bool supports_rms_norm(const ggml_tensor * op) { return f32c(op->src[0]) && f32c(op) && op->src[0]->ne[0] > 0; }
+// same shape, or src1 = a block of rows that repeats over src0's rows (norm weight [ne0], residual [ne0, n]); no other broadcast
+bool supports_binary(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    if (!f32c(a) || !f32c(b) || !f32c(op) || a->ne[0] != b->ne[0] || !ggml_are_same_shape(a, op)) return false;
+    const int64_t ra = ggml_nrows(a), rb = ggml_nrows(b);
+    if (rb <= 0 || ra % rb != 0) return false;
+    // rows of b must tile rows of a in order: b's higher dims are either equal to a's or 1 from some dim upward
+    bool tail = false;
+    for (int d = 1; d < 4; ++d) {
+        if (b->ne[d] == a->ne[d] && !tail) continue;
+        if (b->ne[d] == 1) { tail = true; continue; }
+        return false;
+    }
+    return true;
+}
+bool supports_silu(const ggml_tensor * op) { return ggml_get_unary_op(op) == GGML_UNARY_OP_SILU && f32c(op->src[0]) && f32c(op); }
+bool supports_mul_mat(const ggml_tensor * op) {
+    const ggml_tensor * w = op->src[0], * x = op->src[1];
+    if (!w || !f32c(x) || !f32c(op) || !ggml_is_contiguous(w)) return false;
+    if (w->type != GGML_TYPE_F32 && w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q8_0) return false;
+    if (w->ne[2] != 1 || w->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1) return false;   // plain 2-D products only
+    return w->ne[0] == x->ne[0] && w->ne[0] % (w->type == GGML_TYPE_F32 ? 4 : (w->type == GGML_TYPE_F16 ? 8 : 32)) == 0;
+}
+ggml_status run_layer_op(backend_ctx * bc, ggml_tensor * op) {
+    int rc = PKV_ERR_UNSUPPORTED;
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    switch (op->op) {
+        case GGML_OP_RMS_NORM: {
+            float eps; memcpy(&eps, op->op_params, sizeof(float));
+            rc = pkv_rms_norm_f32((const float *) a->data, (float *) op->data, ggml_nrows(a), a->ne[0], eps, bc->stream);
+        } break;
+        case GGML_OP_ADD: rc = pkv_add_f32((const float *) a->data, (const float *) b->data, (float *) op->data, ggml_nrows(a), a->ne[0], ggml_nrows(b), bc->stream); break;
+        case GGML_OP_MUL: rc = pkv_mul_f32((const float *) a->data, (const float *) b->data, (float *) op->data, ggml_nrows(a), a->ne[0], ggml_nrows(b), bc->stream); break;
+        case GGML_OP_UNARY: rc = pkv_silu_f32((const float *) a->data, (float *) op->data, ggml_nelements(a), bc->stream); break;
+        case GGML_OP_MUL_MAT: rc = pkv_mul_mat(a->data, a->type, (const float *) b->data, (float *) op->data, a->ne[1], a->ne[0], b->ne[1], bc->stream); break;
+        default: break;
+    }
+    if (rc) { MI355_LOG("%s failed: %s\n", ggml_op_name(op->op), pkv_last_error()); return GGML_STATUS_FAILED; }
+    return GGML_STATUS_SUCCESS;
+}
+
 // ---- backend -----------------------------------------------------------------------------------------------------------------
 const char * be_name(ggml_backend_t) { return "MI355"; }
 void be_free(ggml_backend_t b) {
@@ -231,6 +275,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             case GGML_OP_ROPE:           st = run_rope(bc, n, false); break;
             case GGML_OP_ROPE_BACK:      st = run_rope(bc, n, true); break;
             case GGML_OP_CPY:            st = run_cpy(bc, n); break;
+            case GGML_OP_RMS_NORM: case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_UNARY: case GGML_OP_MUL_MAT: st = run_layer_op(bc, n); break;
             default: MI355_LOG("op %s reached graph_compute but is not supported\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
         }
         if (st != GGML_STATUS_SUCCESS) return st;
@@ -286,6 +331,10 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
         case GGML_OP_FLASH_ATTN_EXT: return supports_flash_attn(op);
         case GGML_OP_ROPE: case GGML_OP_ROPE_BACK: return supports_rope(op);
         case GGML_OP_CPY: return supports_cpy(op);
+        case GGML_OP_RMS_NORM: return supports_rms_norm(op);
+        case GGML_OP_ADD: case GGML_OP_MUL: return supports_binary(op);
+        case GGML_OP_UNARY: return supports_silu(op);
+        case GGML_OP_MUL_MAT: return supports_mul_mat(op);
         default: return false;
     }
 }

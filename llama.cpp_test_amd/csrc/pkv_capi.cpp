@@ -432,6 +432,35 @@ int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream)
     return PKV_OK;
 }
 
+// ---- first slice of the rest of the decoder layer ---------------------------------------------------------------
+int pkv_rms_norm_f32(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && y && n_rows >= 0 && ne0 > 0 && eps >= 0.0f, "pkv_rms_norm_f32: bad arguments");
+    return launch_rms_norm(x, y, n_rows, ne0, eps, (hipStream_t) stream);
+}
+int pkv_add_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(a && b && y && n_rows >= 0 && ne0 > 0 && b_rows > 0 && n_rows % b_rows == 0, "pkv_add_f32: bad arguments");
+    return launch_binary(0, a, b, y, n_rows, ne0, b_rows, (hipStream_t) stream);
+}
+int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(a && b && y && n_rows >= 0 && ne0 > 0 && b_rows > 0 && n_rows % b_rows == 0, "pkv_mul_f32: bad arguments");
+    return launch_binary(1, a, b, y, n_rows, ne0, b_rows, (hipStream_t) stream);
+}
+int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && y && n >= 0, "pkv_silu_f32: bad arguments");
+    return launch_silu(x, y, n, (hipStream_t) stream);
+}
+int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0, "pkv_mul_mat: bad arguments");
+    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : PKV_QK)) == 0 && ((uintptr_t) x % 16) == 0 &&
+                ((uintptr_t) w % (type_w == PKV_TYPE_Q8_0 ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
+    return launch_mul_mat(w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
+}
+
 // ---- session state: llama_kv_cache_unified::state_write / state_read in the reference's byte format ------------------------
 // (/ref/src/llama-kv-cache.cpp:848-1221)   u32 cell_count | per cell: i32 pos, u32 n_seq_id, i32 seq_id[n_seq_id] |
 //   u32 v_trans | u32 n_layer | per layer: i32 type_k, u64 k_size_row, K rows | per layer: i32 type_v, u64 v_size_row, V rows

@@ -72,6 +72,11 @@ int launch_copy_cells(void * pool, int type, int is_v, const int32_t * sb, const
                       const int32_t * dof, int n, int n_head_kv, int D, int block_size, hipStream_t st);
 int launch_rows_io(void * pool, int type, int is_v, void * rows, const int32_t * slot_block, const int32_t * slot_off, int n_tok,
                    int n_head_kv, int D, int block_size, bool scatter, hipStream_t st, int64_t rs_tok = 0, int64_t rs_head = 0);
+// first slice of the rest of the decoder layer (pkv_layer_ops.hip)
+int launch_rms_norm(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st);
+int launch_binary(int op, const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, hipStream_t st);
+int launch_silu(const float * x, float * y, int64_t n, hipStream_t st);
+int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st);
 int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);
 
 }  // namespace pkv

@@ -1,7 +1,9 @@
 """Sanity anchor (dev container only): BASELINE config 1 on the REFERENCE itself — TinyLlama-1.1B geometry, Q8_0
 weights (synthetic random GGUF written by llama.cpp_test_amd/gguf_synth.py), tg128 from an empty cache on the reference's CPU
 backend (oracle/_ref/libref_kv.so, 8 threads of this container).  llama-bench semantics: 1 warm-up token, then 128 timed
-single-token llama_decode calls.  usage: python probes/ref_cpu_tinyllama.py [n_threads]"""
+single-token llama_decode calls.  usage: python probes/ref_cpu_tinyllama.py [n_threads] [--plugin]
+--plugin (GPU box): the same loop with our ggml-backend plugin registered and n_gpu_layers = 99: every layer (weights, KV cache,
+attention, the first-slice layer ops) on the MI355X, the reference runtime unmodified; CPU-only and plugin runs back to back."""
 import os, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,24 +14,43 @@ from llama_cpp_test_amd import gguf_synth as G
 from oracle import ref_model as R
 import ctypes as C
 
-nth = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+nth = int(args[0]) if args else 8
+plugin = "--plugin" in sys.argv
 path = os.path.join(tempfile.mkdtemp(dir="/tmp"), "tinyllama-synth-q8_0.gguf")
 t0 = time.time()
 G.synth_llama(path, n_layer=22, n_embd=2048, n_head=32, n_head_kv=4, n_ff=5632, n_vocab=32000, n_ctx=2048, rope_freq_base=10000.0,
               wtype=G.GGML_Q8_0, seed=1)
 print(f"wrote {os.path.getsize(path) / 2**20:.0f} MiB in {time.time() - t0:.0f} s", flush=True)
 L = R._lib()
-h = C.c_void_p(L.refmodel_load(path.encode(), 512, 512, 1, 1, 1, 1, nth))   # flash_attn on, f16 KV
-assert h
 L.refmodel_detach_capture.restype = None
-L.refmodel_detach_capture(h)                                                    # plain decode, no per-node callbacks
-def step(tok, pos):
-    a = np.array([tok], np.int32); p = np.array([pos], np.int32); s = np.zeros(1, np.int32)
-    assert L.refmodel_decode(h, a.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), 1) == 0
-step(1, 0)
-t0 = time.time()
-for i in range(128):
-    step(int(i * 7 % 32000), i + 1)
-dt = time.time() - t0
-print(f"reference CPU backend, TinyLlama-1.1B geometry Q8_0, tg128, {nth} threads: {128 / dt:.2f} tok/s ({dt / 128 * 1e3:.1f} ms/token)")
+
+
+def tg128(label):
+    h = C.c_void_p(L.refmodel_load(path.encode(), 512, 512, 1, 1, 1, 1, nth))   # flash_attn on, f16 KV
+    assert h
+    L.refmodel_detach_capture(h)                                                # plain decode, no per-node callbacks
+
+    def step(tok, pos):
+        a = np.array([tok], np.int32); p = np.array([pos], np.int32); s = np.zeros(1, np.int32)
+        assert L.refmodel_decode(h, a.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), 1) == 0
+    step(1, 0)
+    t0 = time.time()
+    for i in range(128):
+        step(int(i * 7 % 32000), i + 1)
+    dt = time.time() - t0
+    logits = np.empty(32000, np.float32)
+    L.refmodel_logits(h, logits.ctypes.data_as(C.c_void_p), 32000)
+    print(f"{label}, TinyLlama-1.1B geometry Q8_0, tg128: {128 / dt:.2f} tok/s ({dt / 128 * 1e3:.2f} ms/token)", flush=True)
+    L.refmodel_free(h)
+    return logits
+
+
+cpu = tg128(f"reference CPU backend, {nth} threads")
+if plugin:
+    R.load_backend(os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so"))
+    R.set_gpu_layers(99)
+    gpu = tg128("reference runtime + libggml-mi355.so, all layers on the MI355X")
+    err = float(((gpu - cpu) ** 2).sum() / (cpu ** 2).sum())
+    print(f"last-token logits, plugin vs CPU: NMSE {err:.2e}")
 os.remove(path)

@@ -1,0 +1,48 @@
+"""-m gpu: first slice of the rest of the decoder layer (pkv_rms_norm_f32, pkv_add_f32 / pkv_mul_f32, pkv_silu_f32, pkv_mul_mat)
+through the C ABI against exact (f64) arithmetic on the same stored weights.  The reference's own criterion — NMSE vs its CPU
+backend in test-backend-ops (1e-7 / 5e-4 for MUL_MAT) — is checked through the plugin in tests/test_gpu_reference_harness.py; here
+the bar is exactness: the kernels keep activations in f32 (the reference's CPU path rounds them to f16 / q8_0 for f16 / q8_0
+weights), so they must sit within f32 accumulation error of the f64 result."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rms_norm_add_mul_silu(pkv):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((37, 2048)).astype(np.float32) * 3
+    w = rng.standard_normal(2048).astype(np.float32)
+    r = rng.standard_normal((37, 2048)).astype(np.float32)
+    y = pkv.rms_norm(dev(x), 1e-5).cpu().numpy()
+    ref = x / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + 1e-5)
+    assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert np.array_equal(pkv.mul(dev(x), dev(w)).cpu().numpy(), x * w)          # row broadcast: the norm weight
+    assert np.array_equal(pkv.add(dev(x), dev(r)).cpu().numpy(), x + r)          # same shape: the residual
+    x3 = x.reshape(37, 2, 1024)
+    b3 = r[0].reshape(1, 2, 1024)                                                # a block of rows that repeats
+    assert np.array_equal(pkv.add(dev(x3), dev(b3)).cpu().numpy(), x3 + b3)
+    s = pkv.silu(dev(x)).cpu().numpy()
+    sref = x.astype(np.float64) / (1 + np.exp(-x.astype(np.float64)))
+    assert np.abs(s - sref).max() <= 2e-6 * np.abs(sref).max()
+
+
+@pytest.mark.parametrize("tname,M,K,N", [("f32", 64, 256, 1), ("f16", 300, 2048, 1), ("q8_0", 2048, 2048, 1), ("q8_0", 96, 5632, 3),
+                                         ("f16", 32, 512, 19), ("q8_0", 257, 96, 9)])
+def test_mul_mat(pkv, O, tname, M, K, N):
+    t = {"f32": 0, "f16": 1, "q8_0": 8}[tname]
+    rng = np.random.default_rng(M + K + N)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    if t == 0:
+        wb, wd = w.view(np.uint8), w.astype(np.float64)
+    else:
+        wb = O.from_float(t, w, variant="ref") if t == 8 else O.from_float(t, w)
+        wd = O.to_float(t, wb, K).astype(np.float64)
+    y = pkv.mul_mat(dev(np.ascontiguousarray(wb).reshape(-1)), t, M, K, dev(x)).cpu().numpy()
+    ref = x.astype(np.float64) @ wd.T
+    assert y.shape == (N, M)
+    assert np.abs(y - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()) * np.sqrt(K / 256)
