@@ -53,8 +53,11 @@ __global__ void __launch_bounds__(256) silu_kernel(const float * x, float * y, i
 // y[c][m] = sum_k W[m][k] x[c][k].  One wave per weight row (4 rows per workgroup); activation columns go in tiles of CT held in
 // registers, so the weights leave HBM once and later column tiles re-read them from cache.  f32 / f16 rows are read with 16-byte
 // loads; q8_0 rows one 34-byte block per lane with 2-byte loads (the blocks are only 2-byte aligned).  Measured alternatives for
-// q8_0 that lost: staging rows through LDS with coalesced dword loads (10.4 us per product in a TinyLlama decode step against
-// ~7 us), and one row per workgroup split over its 4 waves (14.8 us).
+// q8_0 that lost (average per product in a TinyLlama-1.1B decode step, 8.8 us here): rows staged through LDS with coalesced dword
+// loads 10.4 us; one row per workgroup split over its 4 waves 14.8 us; weights repacked to int8 qs[M][K] + half d[M][K/32] with q8_0-
+// quantized activations and v_dot4: 7.4 us + 3.3 us for the quantize launch, 9.7 us with the quantization fused into the product.
+// At these sizes (4-12 MB per product, 17-48 KB per CU) the products are one memory round trip plus the launch floor, not
+// bandwidth-bound: the next step is fewer, larger launches (fused gate/up, persistent layer kernel), not a different inner loop.
 constexpr int MM_CT = 8;
 template <int WT>
 __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols,
