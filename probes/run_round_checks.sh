@@ -20,4 +20,12 @@ python3 probes/batched_bench.py > $O/batched_bench.txt
 for f in $O/bench_nseq32.json $O/bench_nseq32_ctx640.json $O/bench_q8_0.json $O/bench_q4_0.json $O/bench_70b_ctx16384.json $O/bench_two_call.json; do
   python3 -c "import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['kernel_us']['mean'], 'us', d['roofline']['frac'])"
 done
-cat $O/bench_prefill.txt $O/batched_bench.txt
+PKV_PREFILL_GEOM=70b python3 probes/bench_prefill.py > $O/bench_prefill_70b.txt
+python3 probes/ref_cpu_tinyllama.py 32 --plugin 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/tinyllama_e2e.txt
+export GGML_BACKEND_PATH=$PWD/llama.cpp_test_amd/libggml-mi355.so
+for op in FLASH_ATTN_EXT ROPE ROPE_BACK CPY RMS_NORM ADD MUL SILU MUL_MAT; do
+  oracle/_ref/test-backend-ops test -o $op 2>&1 | sed 's/\x1b\[[0-9;]*m//g' > $O/tbo_$op.txt
+  echo "$op OK=$(grep -c ': OK' $O/tbo_$op.txt) FAIL=$(grep -c FAIL $O/tbo_$op.txt)"
+done
+unset GGML_BACKEND_PATH
+cat $O/bench_prefill.txt $O/batched_bench.txt $O/tinyllama_e2e.txt

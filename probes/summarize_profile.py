@@ -63,6 +63,19 @@ try:
                               "attn_prefill_kernel_avg_per_launch": pre | pre2}
 except Exception as e:   # counters not available on this box
     summary["prefill_pmc"] = {"error": str(e)}
+for extra, name in (("bench_prefill.txt", "bench_prefill"), ("bench_prefill_70b.txt", "bench_prefill_70b"), ("batched_bench.txt", "batched_bench"),
+                    ("tinyllama_e2e.txt", "tinyllama_e2e_plugin")):
+    if os.path.exists(os.path.join(SRC, extra)):
+        shutil.copy(os.path.join(SRC, extra), os.path.join(P, f"{tag}_{name}.txt"))
+for f in glob.glob(os.path.join(SRC, "tbo_*.txt")):
+    shutil.copy(f, os.path.join(P, f"{tag}_test_backend_ops_{os.path.basename(f)[4:]}"))
+cfg = {}
+for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
+    d = json.load(open(f))
+    cfg[os.path.basename(f)[:-5]] = {"tok_s": d["value"], "ms_per_step": d["ms_per_step"], "kernel_us": d["roofline"]["kernel_us"],
+                                      "frac_events": d["roofline"]["frac"], "bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"],
+                                      "step": d["config"]["step"], "workload": d["config"]["workload"]}
+json.dump(cfg, open(os.path.join(P, f"{tag}_bench_configs.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
 tr = json.load(open(os.path.join(P, "traffic.json")))
 tr["f16_ctx4096_nseq1"] = hbm
