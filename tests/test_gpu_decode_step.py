@@ -156,3 +156,27 @@ def test_step_rejects_unsupported(pkv, O):
     with pytest.raises(pkv.PkvError):
         pkv.attn_decode_step(dev(q), dev(kc), dev(vc), dev(pos), None, dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=4, type_k=1,
                              type_v=1, block_size=128, scale=1.0, max_seq_len=100, logit_softcap=30.0)
+
+
+def test_step_with_llama3_rope_frequency_factors(pkv, O):
+    """Llama-3.1-style `rope_freqs` (ggml_rope_ext src[2], /root/reference/src/llama-model.cpp:11431-11443): the per-step RoPE cache
+    carries them, so the fused step must still equal the two-call path bit for bit and the oracle within tolerance"""
+    rng = np.random.default_rng(314)
+    D, nh, nkv = 128, 32, 8
+    lens = [5, 129, 700]
+    kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, lens, D, nh, nkv, 8, 8)
+    ff = (1.0 + 7.0 * rng.uniform(0, 1, D // 2) ** 3).astype(np.float32)          # factors between 1 and 8, like the llama-3 table
+    rope = pkv.rope_params(n_dims=D, mode=0, freq_base=500000.0, freq_factors=dev(ff))
+    a = _two_call(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=8, tv=8)
+    for shared in (False, True):
+        b = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=8, tv=8, shared_cache=shared)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    qr = O.rope(q, pos, ff, n_dims=D, freq_base=500000.0)
+    kr = O.rope(kc, pos, ff, n_dims=D, freq_base=500000.0)
+    last = sl - 1
+    sb, so = bt[np.arange(len(sl)), last // 128].astype(np.int32), (last % 128).astype(np.int32)
+    O.pool_store(kp, 8, 0, O.from_float(8, kr), sb, so, D=D, block_size=128)
+    O.pool_store(vp, 8, 1, O.from_float(8, vc), sb, so, D=D, block_size=128)
+    ref = O.attn_paged(qr[:, :, None, :], kp, vp, bt, sl, n_q=1, type_k=8, type_v=8, block_size=128, scale=D ** -0.5)[:, 0]
+    assert np.abs(b[0] - ref).max() <= 1e-3 and nmse(b[0], ref) <= 5e-4
