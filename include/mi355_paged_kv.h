@@ -173,7 +173,8 @@ int pkv_attn_decode(const pkv_attn_args * args, void * stream);
  * one-token-per-sequence micro-batch.  The new token of sequence s is cell seq_lens[s]-1 (its block must already be
  * in block_table: find_slot ran).  Differences from the two calls: args->q is read un-rotated and NOT modified (the
  * rotated Q goes straight into the QK^T operand), and the results are bit-identical to pkv_qkv_prepare +
- * pkv_attn_decode, pools included.  PKV_ERR_UNSUPPORTED with softcap, slot_pos or merge flags (use the two calls). */
+ * pkv_attn_decode, pools included.  PKV_ATTN_NO_COMBINE / PKV_ATTN_FUSED_COMBINE act as in pkv_attn_decode.
+ * PKV_ERR_UNSUPPORTED with softcap or slot_pos (use the two calls). */
 typedef struct pkv_step_args {
     const float *   k_cur;            /* device f32 [n_seq][n_head_kv][head_dim], this step's K rows, un-rotated  */
     const float *   v_cur;            /* device f32 [n_seq][n_head_kv][head_dim]                                  */

@@ -887,8 +887,8 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     if (step) {
         PKV_REQUIRE(step->k_cur && step->v_cur, "pkv_attn_decode_step: null pointer");
         PKV_REQUIRE(((uintptr_t) step->k_cur % 8) == 0 && ((uintptr_t) step->v_cur % 8) == 0 && (a.q_stride_head % 2) == 0, "pkv_attn_decode_step: rows must be 8-byte aligned");
-        if (a.logit_softcap != 0.0f || a.slot_pos || (a.flags & PKV_ATTN_NO_COMBINE)) {
-            set_error("pkv_attn_decode_step: softcap / irregular sequences / NO_COMBINE take pkv_qkv_prepare + pkv_attn_decode");
+        if (a.logit_softcap != 0.0f || a.slot_pos) {
+            set_error("pkv_attn_decode_step: softcap / irregular sequences take pkv_qkv_prepare + pkv_attn_decode");
             return PKV_ERR_UNSUPPORTED;
         }
         da.k_cur = step->k_cur; da.v_cur = step->v_cur;
