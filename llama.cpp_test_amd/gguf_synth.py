@@ -144,8 +144,10 @@ def read_gguf(path: str):
 
 
 def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv: int, n_ff: int, n_vocab: int, n_ctx: int = 4096,
-                rope_freq_base: float = 10000.0, rms_eps: float = 1e-5, wtype: int = GGML_F16, seed: int = 1234, name: str = "synthetic-llama"):
-    """random-weight llama-arch GGUF (norm weights f32 near 1, matrices N(0, 1/sqrt(fan_in)) in `wtype`)"""
+                rope_freq_base: float = 10000.0, rms_eps: float = 1e-5, wtype: int = GGML_F16, seed: int = 1234, name: str = "synthetic-llama",
+                rope_freqs: bool = False):
+    """random-weight llama-arch GGUF (norm weights f32 near 1, matrices N(0, 1/sqrt(fan_in)) in `wtype`); rope_freqs adds the
+    Llama-3.1-style `rope_freqs.weight` table of per-pair frequency factors (/root/reference/src/llama-model.cpp:1625, :11431-11443)"""
     rng = np.random.default_rng(seed)
     hd = n_embd // n_head
     kv = [("general.architecture", T_STR, "llama"), ("general.name", T_STR, name), ("llama.context_length", T_U32, n_ctx),
@@ -165,6 +167,9 @@ def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv:
     mat("token_embd.weight", n_embd, n_vocab)
     vec("output_norm.weight", n_embd)
     mat("output.weight", n_embd, n_vocab)
+    if rope_freqs:   # factors 1 (high frequencies) ... 8 (low frequencies), the shape of the llama-3 long-context table
+        ff = np.clip(8.0 * (np.arange(hd // 2) / (hd // 2 - 1)) ** 3, 1.0, 8.0).astype(np.float32)
+        tensors.append(("rope_freqs.weight", (hd // 2,), GGML_F32, encode(ff, GGML_F32)))
     for il in range(n_layer):
         p = f"blk.{il}."
         vec(p + "attn_norm.weight", n_embd)

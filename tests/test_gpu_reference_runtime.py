@@ -19,13 +19,21 @@ from oracle import ref_model as R
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLUGIN = os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so")
-MODEL = dict(n_layer=2, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=96, n_ctx=1024, rope_freq_base=10000.0, seed=77)
+MODELS = {
+    # head_dim 64, gqa 2, f16 weights, RoPE base 1e4 (TinyLlama-like)
+    "tiny": dict(n_layer=2, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=96, n_ctx=1024, rope_freq_base=10000.0, seed=77),
+    # head_dim 128, gqa 4, Q8_0 weights, RoPE base 5e5 + rope_freqs table (Llama-3.1-like)
+    "llama3": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=78,
+                   rope_freqs=True, wtype=8),
+}
 
 
 @pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
 @pytest.mark.parametrize("tk", [1, 8])
-def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk):
+@pytest.mark.parametrize("model", ["tiny", "llama3"])
+def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
     from llama_cpp_test_amd import gguf_synth as G
+    MODEL = MODELS[model]
     path = str(tmp_path / "m.gguf")
     G.synth_llama(path, **MODEL)
     rng = np.random.default_rng(5)
@@ -58,4 +66,7 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk):
         for il, (a, b) in enumerate(zip(lc, lg)):
             assert np.isfinite(b).all()
             assert nmse(b, a) <= 5e-4, (ci, il)
-        assert nmse(logit_g, logit_c) <= (1e-4 if tk == 1 else 5e-4), ci
+        # Q8_0 weights: the CPU backend rounds the activations to q8_0 before every product (0.4 % of the block maximum per
+        # element, 14 products deep), the device keeps them in f32: the runs differ by the CPU path's own quantization noise
+        bar = 2e-3 if MODEL.get("wtype") == 8 else (1e-4 if tk == 1 else 5e-4)
+        assert nmse(logit_g, logit_c) <= bar, (ci, bar)
