@@ -140,7 +140,7 @@ typedef struct pkv_attn_args {
     float   logit_softcap;        /* op_params[2]; 0 = off.  max_bias (ALiBi) != 0 is PKV_ERR_UNSUPPORTED       */
     int32_t max_seq_len;          /* upper bound of seq_lens[] known on the host (sizes the split-KV grid)      */
     int32_t flags;                /* PKV_ATTN_* bits                                                            */
-    const void * mask;            /* pkv_attn_prefill only: optional additive mask, device f16 [n_tok][mask_stride] (row =  */
+    const void * mask;            /* optional additive mask (pkv_attn_decode: -inf / finite per cell, no ALiBi), device f16 [n_tok][mask_stride] (row = */
     int64_t mask_stride;          /* token, column = logical KV cell): the general KQ_mask of ggml_flash_attn_ext            */
     float   max_bias;             /* (/ref/ggml/include/ggml.h:1794-1807); max_bias > 0 = ALiBi slopes, needs a mask.      */
                                   /* NULL = the causal-by-position structure of llama (no mask tensor at all)              */

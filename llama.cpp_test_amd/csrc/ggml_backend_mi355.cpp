@@ -151,8 +151,10 @@ ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
     a.block_size = BLOCK; a.max_blocks = n_blocks; a.type_k = k->type; a.type_v = v->type;
     a.scale = scale; a.logit_softcap = softcap; a.max_seq_len = n_kv;
     if (!rc) {
-        if (n_q == 1 && !m) {
-            rc = pkv_attn_decode(&a, bc->stream);          // the split-KV decode kernel (causal by length == all cells)
+        if (n_q == 1 && (!m || max_bias == 0.0f)) {
+            // the split-KV decode kernel; the reference's decode step always carries a KQ_mask row (0 / -inf per cell)
+            a.mask = m ? m->data : nullptr; a.mask_stride = m ? (int64_t) m->ne[0] : 0;
+            rc = pkv_attn_decode(&a, bc->stream);
         } else {
             a.q_start = tab + n_blocks + 1;
             a.flags = PKV_ATTN_NONCAUSAL;

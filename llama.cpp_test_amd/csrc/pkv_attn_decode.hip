@@ -72,6 +72,8 @@ struct DecodeArgs {
     const int32_t * seq_lens;
     const int32_t * slot_pos;
     const int32_t * q_pos;
+    const _Float16 * mask;    // optional additive KQ_mask row per sequence (f16 [n_seq][mask_stride], column = logical cell):
+    int64_t         mask_stride;   // -inf hides the cell; rides on the SLOTPOS variant of the kernel
     float *         part_o;   // [n_seq][n_head][n_splits][D]
     float *         part_ml;  // [n_seq][n_head][n_splits][2]
     float *         out;      // [n_seq][n_head][D]
@@ -483,8 +485,10 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     }
     reduce_scatter<NV, K_LPR>(x, lane);
 
-    const int32_t * spos = SLOTPOS ? a.slot_pos + (size_t) s * a.max_blocks * a.block_size + base : nullptr;
-    const int qpos = SLOTPOS ? a.q_pos[s] : 0;
+    const bool use_mask = SLOTPOS && a.mask != nullptr;       // launch-uniform: explicit mask row instead of cell positions
+    const int32_t * spos = SLOTPOS && !use_mask ? a.slot_pos + (size_t) s * a.max_blocks * a.block_size + base : nullptr;
+    const _Float16 * mrow = use_mask ? a.mask + (size_t) s * a.mask_stride + base : nullptr;
+    const int qpos = SLOTPOS && !use_mask ? a.q_pos[s] : 0;
     const int cidx = NVF * (kc >> (ilog2(K_LPR) - NS));       // original index of x[0]
     float mg[NVF], pj[NVF];
     int   tok[NVF];
@@ -493,9 +497,14 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         const int idx = cidx + j;
         tok[j] = wave * TPW + (idx / G) * K_RPL + kr;         // token inside the workgroup's 128
         bool ok = tok[j] < n_valid;
-        if constexpr (SLOTPOS) { const int p = spos[min(tok[j], n_valid - 1)]; ok = ok && p >= 0 && p <= qpos; }
+        float mv = 0.0f;
+        if constexpr (SLOTPOS) {
+            if (use_mask) { mv = (float) mrow[min(tok[j], n_valid - 1)]; ok = ok && mv != -INFINITY; }   // :12349-12351
+            else          { const int p = spos[min(tok[j], n_valid - 1)]; ok = ok && p >= 0 && p <= qpos; }
+        }
         float v = x[j] * a.scale;                             // :12359
         if constexpr (SOFTCAP) v = a.softcap * tanhf(v);      // :12361-12363 (scale pre-divided on the host)
+        v += mv;                                              // :12365 (slope 1: ALiBi goes through pkv_attn_prefill)
         x[j]  = ok ? v : -INFINITY;                           // mask == -inf -> skipped cell (:12349)
         mg[j] = head_reduce<TPW, true>(x[j]);                 // wave-local max of this head
         pj[j] = mg[j] == -INFINITY ? 0.0f : __expf(x[j] - mg[j]);
@@ -782,7 +791,7 @@ template <int KT, int VT, int D, int G>
 int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     dim3 grid(da.n_splits, da.n_head_kv, n_seq);
     const dim3 block(64 * Geo<KT, VT, D>::NW);
-    const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr;
+    const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr || da.mask != nullptr;
     if (da.k_cur && da.counters) {   // the whole decode step of a layer in ONE launch
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, true>, grid, block, st, da);
     } else if (da.k_cur) {      // fused decode step: RoPE(Q), RoPE(K) + KV store and the split-KV attention in one launch
@@ -851,10 +860,11 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     PKV_REQUIRE(a.max_seq_len > 0 && a.max_seq_len <= a.max_blocks * a.block_size, "pkv_attn_decode: max_seq_len out of range");
     PKV_REQUIRE((a.q_stride_head % 4) == 0 && (a.q_stride_tok % 4) == 0 && ((uintptr_t) a.q % 16) == 0, "pkv_attn_decode: q must be 16-byte aligned");
     PKV_REQUIRE(a.slot_pos == nullptr || a.q_pos != nullptr, "pkv_attn_decode: slot_pos needs q_pos");
-    if (a.mask || a.max_bias != 0.0f || (a.flags & PKV_ATTN_NONCAUSAL)) {
-        set_error("pkv_attn_decode: explicit masks / ALiBi go through pkv_attn_prefill (decode is causal by length)");
+    if (a.max_bias != 0.0f || (a.flags & PKV_ATTN_NONCAUSAL) || (a.mask && (a.slot_pos || step))) {
+        set_error("pkv_attn_decode: ALiBi / non-causal go through pkv_attn_prefill; a mask excludes slot_pos and the fused step");
         return PKV_ERR_UNSUPPORTED;
     }
+    PKV_REQUIRE(!a.mask || a.mask_stride >= a.max_seq_len, "pkv_attn_decode: mask rows shorter than max_seq_len");
     const size_t need = decode_workspace_bytes(a.n_tok, a.n_head, a.head_dim, a.max_seq_len);
     PKV_REQUIRE(a.workspace && a.workspace_bytes >= need, "pkv_attn_decode: workspace too small (%zu < %zu)", a.workspace_bytes, need);
 
@@ -868,6 +878,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.q = a.q; da.q_stride_tok = a.q_stride_tok; da.q_stride_head = a.q_stride_head;
     da.k_pool = (const char *) a.k_pool; da.v_pool = (const char *) a.v_pool;
     da.block_table = a.block_table; da.seq_lens = a.seq_lens; da.slot_pos = a.slot_pos; da.q_pos = a.q_pos;
+    da.mask = (const _Float16 *) a.mask; da.mask_stride = a.mask_stride;
     da.n_head = a.n_head; da.n_head_kv = a.n_head_kv; da.block_size = a.block_size; da.max_blocks = a.max_blocks;
     da.n_splits = (a.max_seq_len + WG_TOK - 1) / WG_TOK;
     da.bs_shift = 0;
@@ -878,7 +889,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.counters = nullptr;
     const size_t po_bytes = (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim * sizeof(float);
     da.part_o_bytes = (int) po_bytes; da.part_ml_bytes = (int) (po_bytes / a.head_dim * 2);
-    if ((a.flags & PKV_ATTN_FUSED_COMBINE) && !(a.flags & PKV_ATTN_NO_COMBINE) && a.logit_softcap == 0.0f && !a.slot_pos &&
+    if ((a.flags & PKV_ATTN_FUSED_COMBINE) && !(a.flags & PKV_ATTN_NO_COMBINE) && a.logit_softcap == 0.0f && !a.slot_pos && !a.mask &&
         po_bytes < ((size_t) 1 << 31))   // 32-bit buffer offsets; larger slabs take the two-launch path
         da.counters = reinterpret_cast<unsigned *>(da.part_ml + (size_t) a.n_tok * a.n_head * da.n_splits * 2);
     da.softcap = a.logit_softcap;

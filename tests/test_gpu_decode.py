@@ -213,3 +213,34 @@ def test_decode_matches_non_flash_attention_path(pkv, O):
         probs = np.exp(z - z.max(1, keepdims=True)); probs /= probs.sum(1, keepdims=True)
     ref = np.einsum("hn,hnd->hd", probs.astype(np.float16).astype(np.float32), np.repeat(V, nh // nkv, 0))
     assert np.abs(got - ref).max() <= 1e-3 and nmse(got, ref) <= 5e-4
+
+
+@pytest.mark.parametrize("tk", [1, 8])
+def test_decode_with_explicit_mask_row(pkv, O, tk):
+    """the reference's decode step always carries a KQ_mask row (0 = visible, -inf = hidden, /root/reference/src/llama-graph.cpp:
+    403-468): pkv_attn_decode takes it in place of the causal-by-length structure (the ggml-backend plugin's decode path).
+    Hidden cells in the middle of the sequence and finite additive values are honoured like ggml-cpu.c:12349-12365."""
+    rng = np.random.default_rng(50 + tk)
+    D, nh, nkv = 128, 8, 2
+    lens = [300, 129, 640]
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
+    q = rng.uniform(-1, 1, (len(lens), nh, D)).astype(np.float32)
+    stride = 768
+    mask = np.zeros((len(lens), stride), np.float16)
+    for s, n in enumerate(lens):
+        mask[s, n:] = -np.inf
+        hide = rng.choice(n, size=n // 5, replace=False)          # holes anywhere, like cells of another sequence in the ring
+        mask[s, hide] = -np.inf
+        mask[s, rng.choice(n, size=7, replace=False)] += np.float16(-0.75)   # a finite bias on a few cells
+    full = np.full(len(lens), 640, np.int32)                      # every sequence "sees" all cells; the mask decides
+    bt_full = np.zeros((len(lens), 5), np.int32)
+    bt_full[:, :bt.shape[1]] = bt
+    out = pkv.attn_decode(dev(q), dev(kp), dev(vp), dev(bt_full), dev(np.minimum(full, np.array([384, 256, 640], np.int32))),
+                          n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5, max_seq_len=640, mask=dev(mask))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for s, n in enumerate(lens):
+        kc = O.pool_gather(kp, tk, 0, bt[s], n, D=D, block_size=128)
+        vc = O.pool_gather(vp, tk, 1, bt[s], n, D=D, block_size=128)
+        ref = O.flash_attn_ext(q[s][:, None, :], kc, vc, mask[s:s + 1, :n], type_k=tk, type_v=tk, scale=D ** -0.5)[0]
+        assert np.abs(got[s] - ref).max() <= 1e-3 and nmse(got[s], ref) <= 5e-4, s
