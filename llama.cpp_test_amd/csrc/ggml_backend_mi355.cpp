@@ -24,6 +24,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/mi355_paged_kv.h"
@@ -34,7 +36,23 @@ namespace {
 
 constexpr int BLOCK = 128;
 
-struct buffer_ctx { void * base; };
+// Persistent paged mirror of a KV cache tensor that lives in this buffer (the reference's flat `cache_k_l%d` / `cache_v_l%d`,
+// /ref/src/llama-kv-cache.cpp:100-103): the attention kernels read 128-token tiles, so instead of re-scattering all n_kv cells at
+// every FLASH_ATTN_EXT the plugin keeps a pool beside the flat tensor and re-scatters only the byte ranges written since the
+// last attention call (the KV-store CPY of the step; anything else that writes — set_tensor, clear, the K-shift RoPE — marks
+// the whole tensor).  Identity block table: block b = cells [128 b, 128 b + 128).
+struct kv_mirror {
+    void * pool = nullptr;
+    int    type = 0, is_v = 0, n_head_kv = 0, D = 0;
+    int64_t n_cells = 0;
+    std::vector<std::pair<size_t, size_t>> dirty;    // byte ranges [begin, end) of the flat tensor not yet in the pool
+};
+struct buffer_ctx {
+    void * base;
+    std::unordered_map<const void *, kv_mirror> mirrors;   // keyed by the flat tensor's data pointer
+    std::unordered_map<const void *, size_t>    tracked;   // flat tensors we have seen as K/V roots -> their byte size
+    ~buffer_ctx() { for (auto & kv : mirrors) if (kv.second.pool) (void) hipFree(kv.second.pool); }
+};
 struct backend_ctx {
     hipStream_t stream = nullptr;
     void *      scratch = nullptr;
@@ -60,18 +78,34 @@ void buf_free(ggml_backend_buffer_t b) {
     (void) hipFree(c->base);
     delete c;
 }
+// a write of [off, off + n) bytes into tensor t (or into the tensor it is a view of): remember it for the mirrors
+void note_write(const ggml_tensor * t, size_t off, size_t n) {
+    const ggml_tensor * root = t;
+    while (root->view_src) { off += root->view_offs; root = root->view_src; }
+    if (!root->buffer || root->buffer->iface.free_buffer != buf_free) return;
+    auto * c = (buffer_ctx *) root->buffer->context;
+    auto it = c->mirrors.find(root->data);
+    if (it != c->mirrors.end()) it->second.dirty.emplace_back(off, off + n);
+}
+void note_write_all(const ggml_tensor * t) { note_write(t, 0, ggml_nbytes(t)); }
 void * buf_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->context)->base; }
 void buf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t n) {
     (void) hipMemset((char *) t->data + off, v, n);
+    note_write(t, off, n);
 }
 void buf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t n) {
     (void) hipMemcpy((char *) t->data + off, d, n, hipMemcpyHostToDevice);
+    note_write(t, off, n);
 }
 void buf_get(ggml_backend_buffer_t, const ggml_tensor * t, void * d, size_t off, size_t n) {
     (void) hipDeviceSynchronize();
     (void) hipMemcpy(d, (const char *) t->data + off, n, hipMemcpyDeviceToHost);
 }
-void buf_clear(ggml_backend_buffer_t b, uint8_t v) { (void) hipMemset(((buffer_ctx *) b->context)->base, v, b->size); }
+void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
+    auto * c = (buffer_ctx *) b->context;
+    (void) hipMemset(c->base, v, b->size);
+    for (auto & kv : c->mirrors) { kv.second.dirty.clear(); kv.second.dirty.emplace_back(0, (size_t) -1); }
+}
 
 const ggml_backend_buffer_i BUFFER_IFACE = {
     /* free_buffer   */ buf_free,
@@ -91,7 +125,9 @@ ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
     void * p = nullptr;
     if (hipMalloc(&p, size ? size : 1) != hipSuccess) { MI355_LOG("hipMalloc(%zu) failed\n", size); return nullptr; }
     (void) hipMemset(p, 0, size ? size : 1);
-    return ggml_backend_buffer_init(buft, BUFFER_IFACE, new buffer_ctx{p}, size);
+    auto * c = new buffer_ctx();
+    c->base = p;
+    return ggml_backend_buffer_init(buft, BUFFER_IFACE, c, size);
 }
 size_t buft_align(ggml_backend_buffer_type_t) { return 256; }
 
@@ -116,6 +152,46 @@ bool supports_flash_attn(const ggml_tensor * op) {
     return true;
 }
 
+// Returns the mirror pool of the flat tensor `t` views, brought up to date for cells [0, n_kv), or NULL when `t` is not such a
+// view (test-backend-ops hands over free-standing K/V tensors: those take the scratch path).
+char * mirror_sync(backend_ctx * bc, const ggml_tensor * t, int is_v, int n_kv, int n_head_kv, int D) {
+    const ggml_tensor * root = t->view_src;
+    if (!root || root->view_src || t->view_offs != 0 || !root->buffer || root->buffer->iface.free_buffer != buf_free) return nullptr;
+    const size_t row_head = ggml_row_size(t->type, D), row_cell = row_head * n_head_kv;
+    if (t->nb[1] != row_cell || t->nb[2] != row_head || !ggml_is_contiguous(root) || ggml_nbytes(root) % row_cell != 0) return nullptr;
+    auto * c = (buffer_ctx *) root->buffer->context;
+    kv_mirror & m = c->mirrors[root->data];
+    const int64_t n_cells = (int64_t) (ggml_nbytes(root) / row_cell);
+    if (!m.pool || m.type != (int) t->type || m.n_head_kv != n_head_kv || m.D != D || m.n_cells != n_cells) {
+        if (m.pool) (void) hipFree(m.pool);
+        m = kv_mirror();
+        const int64_t nb = (n_cells + BLOCK - 1) / BLOCK;
+        const size_t bytes = pkv_pool_bytes(t->type, (int) nb, n_head_kv, BLOCK, D);
+        if (hipMalloc(&m.pool, bytes) != hipSuccess) { m.pool = nullptr; return nullptr; }
+        (void) hipMemsetAsync(m.pool, 0, bytes, bc->stream);
+        m.type = t->type; m.is_v = is_v; m.n_head_kv = n_head_kv; m.D = D; m.n_cells = n_cells;
+        m.dirty.emplace_back(0, (size_t) -1);
+    }
+    // bring the dirty byte ranges into the pool: whole blocks (identity placement starts at a block boundary)
+    const size_t tile_block = pkv_pool_bytes(t->type, 1, n_head_kv, BLOCK, D);
+    for (const auto & r : m.dirty) {
+        int64_t c0 = (int64_t) (r.first / row_cell), c1 = r.second == (size_t) -1 ? n_cells : (int64_t) ((r.second + row_cell - 1) / row_cell);
+        c1 = std::min<int64_t>(c1, std::min<int64_t>(n_cells, ((int64_t) n_kv + BLOCK - 1) / BLOCK * BLOCK));   // cells beyond n_kv stay dirty-free: they are re-marked below
+        c0 = c0 / BLOCK * BLOCK;
+        if (c1 <= c0) continue;
+        const int rc = pkv_pool_scatter_rows_strided((char *) m.pool + (size_t) (c0 / BLOCK) * tile_block, t->type, is_v,
+                                                     (const char *) root->data + (size_t) c0 * row_cell, (int64_t) row_cell, (int64_t) row_head,
+                                                     nullptr, nullptr, (int) (c1 - c0), n_head_kv, D, BLOCK, bc->stream);
+        if (rc) return nullptr;
+    }
+    // ranges that reached past the cells this call sees must be kept for a later, longer call
+    std::vector<std::pair<size_t, size_t>> keep;
+    const size_t seen = (size_t) std::min<int64_t>(n_cells, ((int64_t) n_kv + BLOCK - 1) / BLOCK * BLOCK) * row_cell;
+    for (const auto & r : m.dirty) if (r.second > seen) keep.emplace_back(std::max(r.first, seen), r.second);
+    m.dirty.swap(keep);
+    return (char *) m.pool;
+}
+
 ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
     const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * m = op->src[3];
     float scale, max_bias, softcap;
@@ -124,7 +200,11 @@ ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
     memcpy(&softcap, (const float *) op->op_params + 2, sizeof(float));
     const int D = (int) q->ne[0], n_q = (int) q->ne[1], n_head = (int) q->ne[2], n_kv = (int) k->ne[1], n_head_kv = (int) k->ne[2];
     const int n_blocks = (n_kv + BLOCK - 1) / BLOCK;
-    const size_t kb = pkv_pool_bytes(k->type, n_blocks, n_head_kv, BLOCK, D), vb = pkv_pool_bytes(v->type, n_blocks, n_head_kv, BLOCK, D);
+    // K/V of a llama graph are views of the flat cache tensors (cell-major rows of n_head_kv * D elements, first cell 0):
+    // serve them from the persistent mirrors
+    char * mk = mirror_sync(bc, k, 0, n_kv, n_head_kv, D), * mv = mirror_sync(bc, v, 1, n_kv, n_head_kv, D);
+    const bool mirrored = mk && mv;
+    const size_t kb = mirrored ? 0 : pkv_pool_bytes(k->type, n_blocks, n_head_kv, BLOCK, D), vb = mirrored ? 0 : pkv_pool_bytes(v->type, n_blocks, n_head_kv, BLOCK, D);
     const size_t wsb = pkv_attn_workspace_bytes(n_q, n_head, D, n_kv, BLOCK);
     const size_t meta = ((size_t) n_blocks + 4) * sizeof(int32_t);
     auto up = [](size_t x) { return (x + 255) & ~(size_t) 255; };
@@ -137,12 +217,17 @@ ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
     h[n_blocks] = n_kv; h[n_blocks + 1] = 0; h[n_blocks + 2] = n_q;  // seq_lens[1], q_start[2]
     if (hipMemcpyAsync(tab, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, bc->stream) != hipSuccess) return GGML_STATUS_FAILED;
     (void) hipStreamSynchronize(bc->stream);               // h is a stack-frame object
-    // the pools are private scratch: clear them so that the tail of the last block is finite
-    (void) hipMemsetAsync(kp, 0, up(kb) + up(vb), bc->stream);
-    int rc = pkv_pool_scatter_rows_strided(kp, k->type, 0, k->data, (int64_t) k->nb[1], (int64_t) k->nb[2], nullptr, nullptr, n_kv,
+    int rc = 0;
+    if (mirrored) {
+        kp = mk; vp = mv;
+    } else {
+        // the pools are private scratch: clear them so that the tail of the last block is finite
+        (void) hipMemsetAsync(kp, 0, up(kb) + up(vb), bc->stream);
+        rc = pkv_pool_scatter_rows_strided(kp, k->type, 0, k->data, (int64_t) k->nb[1], (int64_t) k->nb[2], nullptr, nullptr, n_kv,
                                            n_head_kv, D, BLOCK, bc->stream);
-    if (!rc) rc = pkv_pool_scatter_rows_strided(vp, v->type, 1, v->data, (int64_t) v->nb[1], (int64_t) v->nb[2], nullptr, nullptr,
-                                                n_kv, n_head_kv, D, BLOCK, bc->stream);
+        if (!rc) rc = pkv_pool_scatter_rows_strided(vp, v->type, 1, v->data, (int64_t) v->nb[1], (int64_t) v->nb[2], nullptr, nullptr,
+                                                    n_kv, n_head_kv, D, BLOCK, bc->stream);
+    }
     pkv_attn_args a = {};
     a.q = (const float *) q->data; a.q_stride_tok = (int64_t) (q->nb[1] / sizeof(float)); a.q_stride_head = (int64_t) (q->nb[2] / sizeof(float));
     a.out = (float *) op->data; a.k_pool = kp; a.v_pool = vp; a.block_table = tab; a.seq_lens = tab + n_blocks;
@@ -193,6 +278,7 @@ ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
         : pkv_rope_f16_strided(x->data, (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data, op->data,
                                (int) x->ne[2], (int) x->ne[1], (int) x->ne[0], &rp, back ? 1 : 0, bc->stream);
     if (rc) { MI355_LOG("rope failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+    note_write_all(op);                                     // in-place K-shift on the cache (/ref/src/llama-context.cpp:447-496)
     return GGML_STATUS_SUCCESS;
 }
 
@@ -208,6 +294,7 @@ ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     ggml_tensor * d = op->src[1];
     const int rc = pkv_convert_f32((const float *) s->data, d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
     if (rc) { MI355_LOG("cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+    note_write_all(d);                                      // the KV store of the step: the next attention re-scatters just these cells
     return GGML_STATUS_SUCCESS;
 }
 

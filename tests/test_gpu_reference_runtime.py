@@ -40,9 +40,12 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
     # two sequences: both prompts in ONE batch, interleaved decode steps (cells of the two sequences alternate in the ring,
     # the KQ_mask separates them), then — f16 K only, the quantized K-shift graph needs a dequantizing CPY the device does not
     # claim — a context shift of sequence 0 (seq_rm + seq_add: the K-shift RoPE runs in place on the cache, in our buffers)
-    calls = [([0] * 70 + [1] * 33, list(range(70)) + list(range(33)))] + [([0, 1], [70 + i, 33 + i]) for i in range(3)]
+    # (sequence 0's prompt comes in three ubatches and ends beyond two 128-cell blocks: the plugin's paged mirrors of the cache
+    # tensors are extended incrementally, ubatch by ubatch and token by token)
+    calls = [([0] * 100, list(range(100))), ([0] * 100, list(range(100, 200))),
+             ([0] * 70 + [1] * 33, list(range(200, 270)) + list(range(33)))] + [([0, 1], [270 + i, 33 + i]) for i in range(3)]
     if tk == 1:
-        calls += ["shift", ([0, 1], [63, 36]), ([1, 0], [37, 64])]
+        calls += ["shift", ([0, 1], [263, 36]), ([1, 0], [37, 264])]
     toks = [None if c == "shift" else rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
 
     def run(gpu_layers):
