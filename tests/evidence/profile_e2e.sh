@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 rm -rf gpurun_out/e2e_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/e2e_prof -- python3 probes/ref_cpu_tinyllama.py 32 --plugin > gpurun_out/e2e_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/e2e_prof -- python3 tests/evidence/ref_cpu_tinyllama.py 32 --plugin > gpurun_out/e2e_prof.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/e2e_prof/**/*kernel_stats.csv', recursive=True)[0]

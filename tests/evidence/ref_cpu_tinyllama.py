@@ -1,12 +1,12 @@
 """Sanity anchor (dev container only): BASELINE config 1 on the REFERENCE itself — TinyLlama-1.1B geometry, Q8_0
 weights (synthetic random GGUF written by llama.cpp_test_amd/gguf_synth.py), tg128 from an empty cache on the reference's CPU
 backend (oracle/_ref/libref_kv.so, 8 threads of this container).  llama-bench semantics: 1 warm-up token, then 128 timed
-single-token llama_decode calls.  usage: python probes/ref_cpu_tinyllama.py [n_threads] [--plugin]
+single-token llama_decode calls.  usage: python tests/evidence/ref_cpu_tinyllama.py [n_threads] [--plugin]
 --plugin (GPU box): the same loop with our ggml-backend plugin registered and n_gpu_layers = 99: every layer (weights, KV cache,
 attention, the first-slice layer ops) on the MI355X, the reference runtime unmodified; CPU-only and plugin runs back to back."""
 import os, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import _load_pkg
 _load_pkg.load()

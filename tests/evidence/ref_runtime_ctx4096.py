@@ -3,10 +3,10 @@ attention geometry (32 heads, 8 kv heads, head_dim 128), ctx 4096, loaded by the
 registered and n_gpu_layers = 99.  4064 prompt tokens go in as eight 508-token ubatches (masked MFMA prefill kernel, the paged
 mirrors of the cache tensors grow ubatch by ubatch), then 32 single-token llama_decode calls are timed: each runs the split-KV
 decode kernel on ~4096 cells with the KQ_mask row the reference built.  Run under rocprofv3 --kernel-trace --stats to see the
-kernels.  usage: python probes/ref_runtime_ctx4096.py"""
+kernels.  usage: python tests/evidence/ref_runtime_ctx4096.py"""
 import os, sys, tempfile, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import _load_pkg
 _load_pkg.load()

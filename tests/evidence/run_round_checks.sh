@@ -21,7 +21,7 @@ for f in $O/bench_nseq32.json $O/bench_nseq32_ctx640.json $O/bench_q8_0.json $O/
   python3 -c "import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], 'tok/s', d['ms_per_step'], 'ms', d['roofline']['kernel_us']['mean'], 'us', d['roofline']['frac'])"
 done
 PKV_PREFILL_GEOM=70b python3 probes/bench_prefill.py > $O/bench_prefill_70b.txt
-python3 probes/ref_cpu_tinyllama.py 32 --plugin 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/tinyllama_e2e.txt
+python3 tests/evidence/ref_cpu_tinyllama.py 32 --plugin 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/tinyllama_e2e.txt
 export GGML_BACKEND_PATH=$PWD/llama.cpp_test_amd/libggml-mi355.so
 for op in FLASH_ATTN_EXT ROPE ROPE_BACK CPY RMS_NORM ADD MUL SILU MUL_MAT; do
   oracle/_ref/test-backend-ops test -o $op 2>&1 | sed 's/\x1b\[[0-9;]*m//g' > $O/tbo_$op.txt
