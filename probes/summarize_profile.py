@@ -56,11 +56,23 @@ summary = {
     "attn_decode_kernel_hbm_bytes_per_launch": hbm,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
 }
-try:
-    pre = counters(one("prefill_pmc/**/*counter_collection.csv")).get("attn_prefill_kernel", {})
-    pre2 = counters(one("prefill_pmc2/**/*counter_collection.csv")).get("attn_prefill_kernel", {})
-    summary["prefill_pmc"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES / --pmc GRBM_GUI_ACTIVE -- python3 probes/bench_prefill.py",
-                              "attn_prefill_kernel_avg_per_launch": pre | pre2}
+try:   # MFMA-busy fraction of the prefill kernel, per case (kernel template type, grid size)
+    def per_case(path):
+        out = defaultdict(lambda: defaultdict(list))
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if "attn_prefill_kernel" in r["Kernel_Name"]:
+                    out[(r["Kernel_Name"].split("<")[1].split(",")[0], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        return out
+    pa, pb = per_case(one("prefill_pmc/**/*counter_collection.csv")), per_case(one("prefill_pmc2/**/*counter_collection.csv"))
+    cases = {}
+    for k in pa:
+        mf = sum(pa[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(pa[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
+        gui = sum(pb[k]["GRBM_GUI_ACTIVE"]) / len(pb[k]["GRBM_GUI_ACTIVE"])
+        cases[f"type_k={k[0]} grid_threads={k[1]}"] = {"SQ_VALU_MFMA_BUSY_CYCLES": mf, "GRBM_GUI_ACTIVE": gui, "mfma_busy_frac": round(mf / (gui / 8 * 1024), 4)}
+    summary["prefill_pmc"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES  /  --pmc GRBM_GUI_ACTIVE (separate passes) -- python3 probes/bench_prefill.py",
+                              "reading": "SQ_VALU_MFMA_BUSY_CYCLES sums busy cycles over the 1024 SIMDs (32 per v_mfma_f32_32x32x16_f16); GRBM_GUI_ACTIVE sums the 8 XCDs: mfma_busy_frac = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024)",
+                              "per_case": cases}
 except Exception as e:   # counters not available on this box
     summary["prefill_pmc"] = {"error": str(e)}
 for extra, name in (("bench_prefill.txt", "bench_prefill"), ("bench_prefill_70b.txt", "bench_prefill_70b"), ("batched_bench.txt", "batched_bench"),
