@@ -47,7 +47,8 @@ extern "C" {
 #define PKV_ABI_VERSION 1
 
 /* values follow enum ggml_type (/ref/ggml/include/ggml.h:351-360) */
-enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8 };
+enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8,
+                PKV_TYPE_Q4_K = 12 /* weights of pkv_mul_mat only (block_q4_K, /ref/ggml/src/ggml-common.h:279-290); not a KV type */ };
 
 enum pkv_status {
     PKV_OK              =  0,
@@ -294,8 +295,9 @@ int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream)
  *   pkv_rms_norm_f32 : ggml_rms_norm, y[r] = x[r] / sqrt(mean(x[r]^2) + eps)   (/ref/ggml/src/ggml-cpu/ggml-cpu.c:8215-8260)
  *   pkv_add_f32 / pkv_mul_f32 : y[r][i] = a[r][i] (+|*) b[r % b_rows][i]      (ggml_add / ggml_mul with row broadcast)
  *   pkv_silu_f32     : x / (1 + exp(-x))                                       (ggml_silu, :2015)
- *   pkv_mul_mat      : ggml_mul_mat, y[c][m] = sum_k W[m][k] x[c][k]; W = M rows of K elements in f32 / f16 / q8_0 (reference
- *                      row format), x = n_cols rows of K f32, y = n_cols rows of M f32   (:7467-7640) */
+ *   pkv_mul_mat      : ggml_mul_mat, y[c][m] = sum_k W[m][k] x[c][k]; W = M rows of K elements in f32 / f16 / q8_0 / q4_K (reference
+ *                      row format; q4_K dequantized as dequantize_row_q4_K, /ref/ggml/src/ggml-quants.c:1280-1302), x = n_cols rows
+ *                      of K f32, y = n_cols rows of M f32   (:7467-7640) */
 int pkv_rms_norm_f32(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, void * stream);
 int pkv_add_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);

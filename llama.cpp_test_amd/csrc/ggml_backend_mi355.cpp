@@ -320,9 +320,9 @@ bool supports_silu(const ggml_tensor * op) { return ggml_get_unary_op(op) == GGM
 bool supports_mul_mat(const ggml_tensor * op) {
     const ggml_tensor * w = op->src[0], * x = op->src[1];
     if (!w || !f32c(x) || !f32c(op) || !ggml_is_contiguous(w)) return false;
-    if (w->type != GGML_TYPE_F32 && w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q8_0) return false;
+    if (w->type != GGML_TYPE_F32 && w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q8_0 && w->type != GGML_TYPE_Q4_K) return false;
     if (w->ne[2] != 1 || w->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1) return false;   // plain 2-D products only
-    return w->ne[0] == x->ne[0] && w->ne[0] % (w->type == GGML_TYPE_F32 ? 4 : (w->type == GGML_TYPE_F16 ? 8 : 32)) == 0;
+    return w->ne[0] == x->ne[0] && w->ne[0] % (w->type == GGML_TYPE_F32 ? 4 : (w->type == GGML_TYPE_F16 ? 8 : (w->type == GGML_TYPE_Q4_K ? 256 : 32))) == 0;
 }
 ggml_status run_layer_op(backend_ctx * bc, ggml_tensor * op) {
     int rc = PKV_ERR_UNSUPPORTED;

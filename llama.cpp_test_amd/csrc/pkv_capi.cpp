@@ -456,8 +456,8 @@ int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream) {
 int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0, "pkv_mul_mat: bad arguments");
-    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : PKV_QK)) == 0 && ((uintptr_t) x % 16) == 0 &&
-                ((uintptr_t) w % (type_w == PKV_TYPE_Q8_0 ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
+    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : (type_w == PKV_TYPE_Q4_K ? 256 : PKV_QK))) == 0 &&
+                ((uintptr_t) x % 16) == 0 && ((uintptr_t) w % (type_w == PKV_TYPE_Q8_0 ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
     return launch_mul_mat(w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
 }
 

@@ -39,7 +39,8 @@ __host__ __device__ inline size_t row_size(int type, int64_t ne) {
     return type == PKV_TYPE_F32  ? (size_t) ne * 4
          : type == PKV_TYPE_F16  ? (size_t) ne * 2
          : type == PKV_TYPE_Q8_0 ? (size_t) (ne / PKV_QK) * 34
-         : type == PKV_TYPE_Q4_0 ? (size_t) (ne / PKV_QK) * 18 : 0;
+         : type == PKV_TYPE_Q4_0 ? (size_t) (ne / PKV_QK) * 18
+         : type == PKV_TYPE_Q4_K ? (size_t) (ne / 256) * 144 : 0;
 }
 inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0; }
 

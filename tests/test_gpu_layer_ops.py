@@ -31,13 +31,17 @@ def test_rms_norm_add_mul_silu(pkv):
 
 
 @pytest.mark.parametrize("tname,M,K,N", [("f32", 64, 256, 1), ("f16", 300, 2048, 1), ("q8_0", 2048, 2048, 1), ("q8_0", 96, 5632, 3),
-                                         ("f16", 32, 512, 19), ("q8_0", 257, 96, 9)])
+                                         ("f16", 32, 512, 19), ("q8_0", 257, 96, 9), ("q4_K", 4096, 4096, 1), ("q4_K", 130, 768, 11)])
 def test_mul_mat(pkv, O, tname, M, K, N):
-    t = {"f32": 0, "f16": 1, "q8_0": 8}[tname]
+    t = {"f32": 0, "f16": 1, "q8_0": 8, "q4_K": 12}[tname]
     rng = np.random.default_rng(M + K + N)
     w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
     x = rng.standard_normal((N, K)).astype(np.float32)
-    if t == 0:
+    if t == 12:      # random well-formed block_q4_K rows, checked against dequantize_row_q4_K (== the reference's, tests/test_gguf.py)
+        from llama_cpp_test_amd import gguf_synth as G
+        raw = G.random_q4_K(rng, M, K)
+        wb, wd = np.frombuffer(raw, np.uint8).copy(), G.dequantize_q4_K(raw, K).astype(np.float64)
+    elif t == 0:
         wb, wd = w.view(np.uint8), w.astype(np.float64)
     else:
         wb = O.from_float(t, w, variant="ref") if t == 8 else O.from_float(t, w)
