@@ -204,6 +204,11 @@ void refmodel_detach_capture(void * h) {
     llama_free(rm->ctx);
     rm->ctx = llama_init_from_model(rm->model, cp);
 }
+// llama_state_seq_set_data (/root/reference/include/llama.h): restore one sequence's KV cells from a session blob
+// (= llama_kv_cache_unified::state_read, src/llama-kv-cache.cpp:886); returns the bytes consumed, 0 on failure
+size_t refmodel_state_seq_set(void * h, const void * data, size_t size, int seq_id) {
+    return llama_state_seq_set_data(((RefModel *) h)->ctx, (const uint8_t *) data, size, seq_id);
+}
 void refmodel_seq_rm(void * h, int s, int p0, int p1) { llama_kv_self_seq_rm(((RefModel *) h)->ctx, s, p0, p1); }
 void refmodel_seq_add(void * h, int s, int p0, int p1, int d) { llama_kv_self_seq_add(((RefModel *) h)->ctx, s, p0, p1, d); }
 void refmodel_seq_cp(void * h, int a, int b, int p0, int p1) { llama_kv_self_seq_cp(((RefModel *) h)->ctx, a, b, p0, p1); }
