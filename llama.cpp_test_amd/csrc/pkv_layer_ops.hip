@@ -65,6 +65,61 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t m = (int64_t) blockIdx.x * 4 + wv;
     const char * wr = w + (size_t) min(m, M - 1) * w_row_bytes;            // surplus waves redo the last row and do not store
+    if constexpr (WT == PKV_TYPE_Q4_K) {
+        // block_q4_K: half d, half dmin, 12 bytes of packed 6-bit (scale, min) pairs, 128 bytes of nibbles = 256 elements in 4 groups
+        // of 64 (low nibbles = first 32 elements of the group, high nibbles = the next 32).  A lane owns one 64-element group of a
+        // 4096-element chunk.  The chunk of the activation column is staged ONCE per workgroup in LDS, transposed (element-major,
+        // row stride 65) so that both the coalesced staging writes and the per-lane reads are bank-conflict free; read straight
+        // from global memory every lane's 64 floats are 256 bytes apart and each load instruction touches 64 cache lines.
+        constexpr int KC = 4096, NG = KC / 64;
+        __shared__ float sx[64 * 65];
+        for (int64_t c = 0; c < n_cols; ++c) {
+            const float * xc = x + (size_t) c * K;
+            float acc = 0.0f;
+            for (int64_t k0 = 0; k0 < K; k0 += KC) {
+                const int kc = (int) min((int64_t) KC, K - k0), ng = kc / 64;
+                __syncthreads();                                   // the previous chunk is no longer read
+                for (int i = threadIdx.x; i < kc; i += 256) sx[(i & 63) * 65 + (i >> 6)] = xc[k0 + i];
+                __syncthreads();
+                if (lane < ng) {
+                    const int64_t blk = (k0 >> 8) + (lane >> 2);
+                    const int p = lane & 3;
+                    const unsigned char * bp = reinterpret_cast<const unsigned char *>(wr) + (size_t) blk * 144;
+                    const uint32_t dm = *reinterpret_cast<const uint32_t *>(bp);
+                    const uint16_t dlo = (uint16_t) (dm & 0xFFFF), dhi = (uint16_t) (dm >> 16);
+                    const float d = (float) *reinterpret_cast<const _Float16 *>(&dlo), dmin = (float) *reinterpret_cast<const _Float16 *>(&dhi);
+                    const unsigned char * sc = bp + 4;
+                    auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
+                        if (j < 4) { s_ = sc[j] & 63; m_ = sc[j + 4] & 63; }
+                        else       { s_ = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4); m_ = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4); }
+                    };
+                    int s1, m1, s2, m2;
+                    scale_min(2 * p, s1, m1);
+                    scale_min(2 * p + 1, s2, m2);
+                    const uint4 qa = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p), qb = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
+                    const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+                    float slo = 0.0f, shi = 0.0f, xlo = 0.0f, xhi = 0.0f;
+#pragma unroll
+                    for (int w4 = 0; w4 < 8; ++w4) {
+                        const uint32_t q = qw[w4];
+#pragma unroll
+                        for (int b4 = 0; b4 < 4; ++b4) {
+                            const int l = 4 * w4 + b4;
+                            const float xl = sx[l * 65 + lane], xh = sx[(32 + l) * 65 + lane];
+                            slo = fmaf((float) ((q >> (8 * b4)) & 0xF), xl, slo);
+                            shi = fmaf((float) ((q >> (8 * b4 + 4)) & 0xF), xh, shi);
+                            xlo += xl; xhi += xh;
+                        }
+                    }
+                    // sum (d*sc*q - dmin*m) x = d*sc*sum(q x) - dmin*m*sum(x)
+                    acc += (d * (float) s1 * slo - dmin * (float) m1 * xlo) + (d * (float) s2 * shi - dmin * (float) m2 * xhi);
+                }
+            }
+            const float v = wave_sum_f(acc);
+            if (lane == 0 && m < M) y[(size_t) c * M + m] = v;
+        }
+        return;
+    }
     for (int64_t c0 = 0; c0 < n_cols; c0 += MM_CT) {
         const int nc = (int) min((int64_t) MM_CT, n_cols - c0);
         float acc[MM_CT];
@@ -97,46 +152,7 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
                 }
             }
         } else if constexpr (WT == PKV_TYPE_Q4_K) {
-            // block_q4_K: half d, half dmin, 12 bytes of packed 6-bit (scale, min) pairs, 128 bytes of nibbles = 256 elements in 4
-            // groups of 64 (low nibbles = first 32, high nibbles = next 32).  4 lanes per block, one 64-element group each.
-            for (int64_t u = lane; u < K / 64; u += 64) {
-                const int64_t blk = u >> 2;
-                const int p = (int) (u & 3);
-                const unsigned char * bp = reinterpret_cast<const unsigned char *>(wr) + (size_t) blk * 144;
-                const uint32_t dm = *reinterpret_cast<const uint32_t *>(bp);
-                const uint16_t dlo = (uint16_t) (dm & 0xFFFF), dhi = (uint16_t) (dm >> 16);
-                const float d = (float) *reinterpret_cast<const _Float16 *>(&dlo), dmin = (float) *reinterpret_cast<const _Float16 *>(&dhi);
-                const unsigned char * sc = bp + 4;
-                auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
-                    if (j < 4) { s_ = sc[j] & 63; m_ = sc[j + 4] & 63; }
-                    else       { s_ = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4); m_ = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4); }
-                };
-                int s1, m1, s2, m2;
-                scale_min(2 * p, s1, m1);
-                scale_min(2 * p + 1, s2, m2);
-                const float d1 = d * (float) s1, mm1 = dmin * (float) m1, d2 = d * (float) s2, mm2 = dmin * (float) m2;
-                const uint4 qa = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p), qb = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
-                const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-#pragma unroll
-                for (int c = 0; c < MM_CT; ++c) {
-                    if (c < nc) {
-                        const float * xc = x + (size_t) (c0 + c) * K + blk * 256 + p * 64;
-                        float slo = 0.0f, shi = 0.0f, xlo = 0.0f, xhi = 0.0f;
-#pragma unroll
-                        for (int w4 = 0; w4 < 8; ++w4) {
-                            const float4 a = *reinterpret_cast<const float4 *>(xc + 4 * w4), b = *reinterpret_cast<const float4 *>(xc + 32 + 4 * w4);
-                            const uint32_t q = qw[w4];
-                            slo = fmaf((float) (q & 0xF), a.x, slo); slo = fmaf((float) ((q >> 8) & 0xF), a.y, slo);
-                            slo = fmaf((float) ((q >> 16) & 0xF), a.z, slo); slo = fmaf((float) ((q >> 24) & 0xF), a.w, slo);
-                            shi = fmaf((float) ((q >> 4) & 0xF), b.x, shi); shi = fmaf((float) ((q >> 12) & 0xF), b.y, shi);
-                            shi = fmaf((float) ((q >> 20) & 0xF), b.z, shi); shi = fmaf((float) (q >> 28), b.w, shi);
-                            xlo += (a.x + a.y) + (a.z + a.w);
-                            xhi += (b.x + b.y) + (b.z + b.w);
-                        }
-                        acc[c] += (d1 * slo - mm1 * xlo) + (d2 * shi - mm2 * xhi);   // sum (d*sc*q - dmin*m) x = d*sc*sum(q x) - dmin*m*sum(x)
-                    }
-                }
-            }
+            // handled below (activations staged through LDS): nothing in the generic column-tile loop
         } else {
             for (int64_t blk = lane; blk < K / PKV_QK; blk += 64) {
                 const uint16_t * bp = reinterpret_cast<const uint16_t *>(wr + (size_t) blk * 34);
