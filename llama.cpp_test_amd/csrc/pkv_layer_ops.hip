@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256) silu_kernel(const float * x, float * y, i
 // y[c][m] = sum_k W[m][k] x[c][k].  One wave per weight row (4 rows per workgroup); activation columns go in tiles of CT held in
 // registers, so the weights leave HBM once and later column tiles re-read them from cache.  f32 / f16 rows are read with 16-byte
 // loads; q8_0 rows one 34-byte block per lane with 2-byte loads (the blocks are only 2-byte aligned).  Measured alternatives for
-// q8_0 that lost (average per product in a TinyLlama-1.1B decode step, 8.8 us here): rows staged through LDS with coalesced dword
+// q8_0 that lost (average per product in a TinyLlama-1.1B decode step, 8.8 us with direct activation loads; what helped afterwards is
+// the ACTIVATION side: the chunk staged once per workgroup in LDS, transposed, see the q8_0 / q4_K branches): rows staged through LDS with coalesced dword
 // loads 10.4 us; one row per workgroup split over its 4 waves 14.8 us; weights repacked to int8 qs[M][K] + half d[M][K/32] with q8_0-
 // quantized activations and v_dot4: 7.4 us + 3.3 us for the quantize launch, 9.7 us with the quantization fused into the product.
 // At these sizes (4-12 MB per product, 17-48 KB per CU) the products are one memory round trip plus the launch floor, not
@@ -113,6 +114,38 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
                     }
                     // sum (d*sc*q - dmin*m) x = d*sc*sum(q x) - dmin*m*sum(x)
                     acc += (d * (float) s1 * slo - dmin * (float) m1 * xlo) + (d * (float) s2 * shi - dmin * (float) m2 * xhi);
+                }
+            }
+            const float v = wave_sum_f(acc);
+            if (lane == 0 && m < M) y[(size_t) c * M + m] = v;
+        }
+        return;
+    }
+    if constexpr (WT == PKV_TYPE_Q8_0) {
+        // same scheme for block_q8_0 rows: a lane owns one 32-element block of a 2048-element chunk, the activation chunk is staged
+        // once per workgroup in LDS, transposed (row stride 65)
+        constexpr int KC = 2048;
+        __shared__ float sx[32 * 65];
+        for (int64_t c = 0; c < n_cols; ++c) {
+            const float * xc = x + (size_t) c * K;
+            float acc = 0.0f;
+            for (int64_t k0 = 0; k0 < K; k0 += KC) {
+                const int kc = (int) min((int64_t) KC, K - k0), nb = kc / PKV_QK;
+                __syncthreads();
+                for (int i = threadIdx.x; i < kc; i += 256) sx[(i & 31) * 65 + (i >> 5)] = xc[k0 + i];
+                __syncthreads();
+                if (lane < nb) {
+                    const uint16_t * bp = reinterpret_cast<const uint16_t *>(wr + (size_t) (k0 / PKV_QK + lane) * 34);
+                    const uint16_t db = bp[0];
+                    const float d = (float) *reinterpret_cast<const _Float16 *>(&db);
+                    float sdot = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint16_t two = bp[1 + j];
+                        sdot = fmaf((float) (int) (signed char) (two & 0xFF), sx[(2 * j) * 65 + lane], sdot);
+                        sdot = fmaf((float) (int) (signed char) (two >> 8), sx[(2 * j + 1) * 65 + lane], sdot);
+                    }
+                    acc = fmaf(d, sdot, acc);
                 }
             }
             const float v = wave_sum_f(acc);
