@@ -76,7 +76,7 @@ try:   # MFMA-busy fraction of the prefill kernel, per case (kernel template typ
 except Exception as e:   # counters not available on this box
     summary["prefill_pmc"] = {"error": str(e)}
 for extra, name in (("bench_prefill.txt", "bench_prefill"), ("bench_prefill_70b.txt", "bench_prefill_70b"), ("batched_bench.txt", "batched_bench"),
-                    ("tinyllama_e2e.txt", "tinyllama_e2e_plugin")):
+                    ("tinyllama_e2e.txt", "tinyllama_e2e_plugin"), ("e2e_8b_q4k.txt", "e2e_8b_q4k_plugin")):
     if os.path.exists(os.path.join(SRC, extra)):
         shutil.copy(os.path.join(SRC, extra), os.path.join(P, f"{tag}_{name}.txt"))
 for f in glob.glob(os.path.join(SRC, "tbo_*.txt")):

@@ -22,10 +22,12 @@ for f in $O/bench_nseq32.json $O/bench_nseq32_ctx640.json $O/bench_q8_0.json $O/
 done
 PKV_PREFILL_GEOM=70b python3 probes/bench_prefill.py > $O/bench_prefill_70b.txt
 python3 tests/evidence/ref_cpu_tinyllama.py 32 --plugin 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/tinyllama_e2e.txt
+python3 tests/evidence/ref_runtime_8b_q4k.py --cpu 32 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/e2e_8b_q4k.txt
+python3 tests/evidence/ref_runtime_ctx4096.py 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/ref_runtime_ctx4096.txt
 export GGML_BACKEND_PATH=$PWD/llama.cpp_test_amd/libggml-mi355.so
 for op in FLASH_ATTN_EXT ROPE ROPE_BACK CPY RMS_NORM ADD MUL SILU MUL_MAT; do
   oracle/_ref/test-backend-ops test -o $op 2>&1 | sed 's/\x1b\[[0-9;]*m//g' > $O/tbo_$op.txt
   echo "$op OK=$(grep -c ': OK' $O/tbo_$op.txt) FAIL=$(grep -c FAIL $O/tbo_$op.txt)"
 done
 unset GGML_BACKEND_PATH
-cat $O/bench_prefill.txt $O/batched_bench.txt $O/tinyllama_e2e.txt
+cat $O/bench_prefill.txt $O/batched_bench.txt $O/tinyllama_e2e.txt $O/e2e_8b_q4k.txt $O/ref_runtime_ctx4096.txt
