@@ -72,48 +72,59 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
         // 4096-element chunk.  The chunk of the activation column is staged ONCE per workgroup in LDS, transposed (element-major,
         // row stride 65) so that both the coalesced staging writes and the per-lane reads are bank-conflict free; read straight
         // from global memory every lane's 64 floats are 256 bytes apart and each load instruction touches 64 cache lines.
-        constexpr int KC = 4096, NG = KC / 64;
-        __shared__ float sx[64 * 65];
+        // ... and QUANTIZED while staged (int8 per 32-element sub-block, d = amax / 127 kept in f32 — finer than the q8_K blocks of 256
+        // the reference's CPU backend quantizes activations to before a q4_K product, vec_dot_type of q4_K, ggml-cpu.c:7467-7640): the
+        // nibbles then meet them in v_dot4_i32_i8, 4 elements per instruction instead of one convert + one FMA each.
+        constexpr int KC = 4096;
+        __shared__ uint32_t sq[16 * 65];      // [dword of the group (4 int8)][group] : lane = group reads stride-1
+        __shared__ float    sd[2 * 65], ss[2 * 65];   // per (half of the group, group): scale, scale * sum of the int8
         for (int64_t c = 0; c < n_cols; ++c) {
             const float * xc = x + (size_t) c * K;
             float acc = 0.0f;
             for (int64_t k0 = 0; k0 < K; k0 += KC) {
                 const int kc = (int) min((int64_t) KC, K - k0), ng = kc / 64;
+                // this lane's slice of the weight row is requested FIRST (it does not depend on the activations): its HBM latency runs
+                // under the staging of the chunk.  (lanes past the end of a short chunk re-read the last group and drop it)
+                const int p = lane & 3;
+                const unsigned char * bp = reinterpret_cast<const unsigned char *>(wr) + (size_t) ((k0 >> 8) + (min(lane, ng - 1) >> 2)) * 144;
+                const uint4 hdr = *reinterpret_cast<const uint4 *>(bp);   // d, dmin and the 12 scale bytes in ONE 16-byte load
+                const uint4 qa = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p), qb = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
                 __syncthreads();                                   // the previous chunk is no longer read
-                for (int i = threadIdx.x; i < kc; i += 256) sx[(i & 63) * 65 + (i >> 6)] = xc[k0 + i];
+                for (int i4 = threadIdx.x; i4 < kc / 4; i4 += 256) {   // 4 elements per thread, 8 threads per 32-element sub-block
+                    const float4 v = *reinterpret_cast<const float4 *>(xc + k0 + 4 * i4);
+                    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+                    const float dq = amax / 127.0f, id = amax != 0.0f ? 127.0f / amax : 0.0f;
+                    const int q0 = (int) __builtin_rintf(v.x * id), q1 = (int) __builtin_rintf(v.y * id), q2 = (int) __builtin_rintf(v.z * id),
+                              q3 = (int) __builtin_rintf(v.w * id);
+                    int qs = q0 + q1 + q2 + q3;
+                    qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
+                    const int grp = i4 >> 4, w = i4 & 15;          // group of 64 elements, dword inside it
+                    sq[w * 65 + grp] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+                    if ((i4 & 7) == 0) { sd[(w >> 3) * 65 + grp] = dq; ss[(w >> 3) * 65 + grp] = dq * (float) qs; }
+                }
                 __syncthreads();
                 if (lane < ng) {
-                    const int64_t blk = (k0 >> 8) + (lane >> 2);
-                    const int p = lane & 3;
-                    const unsigned char * bp = reinterpret_cast<const unsigned char *>(wr) + (size_t) blk * 144;
-                    const uint32_t dm = *reinterpret_cast<const uint32_t *>(bp);
-                    const uint16_t dlo = (uint16_t) (dm & 0xFFFF), dhi = (uint16_t) (dm >> 16);
+                    const uint16_t dlo = (uint16_t) (hdr.x & 0xFFFF), dhi = (uint16_t) (hdr.x >> 16);
                     const float d = (float) *reinterpret_cast<const _Float16 *>(&dlo), dmin = (float) *reinterpret_cast<const _Float16 *>(&dhi);
-                    const unsigned char * sc = bp + 4;
+                    auto sc = [&](int k) -> int { const uint32_t w = k < 4 ? hdr.y : (k < 8 ? hdr.z : hdr.w); return (int) ((w >> (8 * (k & 3))) & 0xFF); };
                     auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
-                        if (j < 4) { s_ = sc[j] & 63; m_ = sc[j + 4] & 63; }
-                        else       { s_ = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4); m_ = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4); }
+                        if (j < 4) { s_ = sc(j) & 63; m_ = sc(j + 4) & 63; }
+                        else       { s_ = (sc(j + 4) & 0xF) | ((sc(j - 4) >> 6) << 4); m_ = (sc(j + 4) >> 4) | ((sc(j) >> 6) << 4); }
                     };
                     int s1, m1, s2, m2;
                     scale_min(2 * p, s1, m1);
                     scale_min(2 * p + 1, s2, m2);
-                    const uint4 qa = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p), qb = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
                     const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-                    float slo = 0.0f, shi = 0.0f, xlo = 0.0f, xhi = 0.0f;
+                    int ilo = 0, ihi = 0;
 #pragma unroll
-                    for (int w4 = 0; w4 < 8; ++w4) {
-                        const uint32_t q = qw[w4];
-#pragma unroll
-                        for (int b4 = 0; b4 < 4; ++b4) {
-                            const int l = 4 * w4 + b4;
-                            const float xl = sx[l * 65 + lane], xh = sx[(32 + l) * 65 + lane];
-                            slo = fmaf((float) ((q >> (8 * b4)) & 0xF), xl, slo);
-                            shi = fmaf((float) ((q >> (8 * b4 + 4)) & 0xF), xh, shi);
-                            xlo += xl; xhi += xh;
-                        }
+                    for (int w4 = 0; w4 < 8; ++w4) {               // byte b of dword w4: low nibble = element 4 w4 + b, high = 32 + 4 w4 + b
+                        ilo = __builtin_amdgcn_sdot4((int) (qw[w4] & 0x0F0F0F0Fu), (int) sq[w4 * 65 + lane], ilo, false);
+                        ihi = __builtin_amdgcn_sdot4((int) ((qw[w4] >> 4) & 0x0F0F0F0Fu), (int) sq[(8 + w4) * 65 + lane], ihi, false);
                     }
-                    // sum (d*sc*q - dmin*m) x = d*sc*sum(q x) - dmin*m*sum(x)
-                    acc += (d * (float) s1 * slo - dmin * (float) m1 * xlo) + (d * (float) s2 * shi - dmin * (float) m2 * xhi);
+                    // sum (d*sc*q - dmin*m) x  with x ~ dx * xq :  d*sc*dx*sum(q xq) - dmin*m*dx*sum(xq)
+                    acc += (d * (float) s1 * sd[lane] * (float) ilo - dmin * (float) m1 * ss[lane]) +
+                           (d * (float) s2 * sd[65 + lane] * (float) ihi - dmin * (float) m2 * ss[65 + lane]);
                 }
             }
             const float v = wave_sum_f(acc);

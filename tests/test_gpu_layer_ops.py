@@ -49,4 +49,17 @@ def test_mul_mat(pkv, O, tname, M, K, N):
     y = pkv.mul_mat(dev(np.ascontiguousarray(wb).reshape(-1)), t, M, K, dev(x)).cpu().numpy()
     ref = x.astype(np.float64) @ wd.T
     assert y.shape == (N, M)
+    if t == 12:
+        # the q4_K product quantizes the activations to int8 per 32-element sub-block (d = amax / 127, round-to-nearest-even) and
+        # runs integer dots — the reference's CPU backend does the same with coarser q8_K blocks of 256.  Tight against that
+        # arithmetic in f64, and within the harness bar (NMSE 5e-4, we ask 1e-4) of the unquantized product.
+        xb = x.reshape(N, K // 32, 32)
+        amax = np.abs(xb).max(-1, keepdims=True)
+        dq = (amax / np.float32(127.0)).astype(np.float32)
+        idq = np.where(amax != 0, np.float32(127.0) / np.where(amax != 0, amax, 1), 0).astype(np.float32)
+        xh = (dq.astype(np.float64) * np.rint((xb * idq).astype(np.float32))).reshape(N, K)
+        ref_q = xh @ wd.T
+        assert np.abs(y - ref_q).max() <= 3e-6 * max(1.0, np.abs(ref_q).max()) * np.sqrt(K / 256)
+        assert float(((y - ref) ** 2).sum() / (ref ** 2).sum()) <= 1e-4
+        return
     assert np.abs(y - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()) * np.sqrt(K / 256)
