@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) silu_kernel(const float * x, float * y, i
 // quantized activations and v_dot4: 7.4 us + 3.3 us for the quantize launch, 9.7 us with the quantization fused into the product.
 // At these sizes (4-12 MB per product, 17-48 KB per CU) the products are one memory round trip plus the launch floor, not
 // bandwidth-bound: the next step is fewer, larger launches (fused gate/up, persistent layer kernel), not a different inner loop.
-constexpr int MM_CT = 8;
+constexpr int MM_CT = 8, Q4K_ROWS = 2;
 template <int WT>
 __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols,
                                                       size_t w_row_bytes) {
@@ -75,20 +75,30 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
         // ... and QUANTIZED while staged (int8 per 32-element sub-block, d = amax / 127 kept in f32 — finer than the q8_K blocks of 256
         // the reference's CPU backend quantizes activations to before a q4_K product, vec_dot_type of q4_K, ggml-cpu.c:7467-7640): the
         // nibbles then meet them in v_dot4_i32_i8, 4 elements per instruction instead of one convert + one FMA each.
-        constexpr int KC = 4096;
+        constexpr int KC = 4096, R = Q4K_ROWS;   // R weight rows per wave: the staged chunk serves 4 R rows, R x 3 loads in flight per lane
         __shared__ uint32_t sq[16 * 65];      // [dword of the group (4 int8)][group] : lane = group reads stride-1
         __shared__ float    sd[2 * 65], ss[2 * 65];   // per (half of the group, group): scale, scale * sum of the int8
+        const int64_t m0 = ((int64_t) blockIdx.x * 4 + wv) * R;
         for (int64_t c = 0; c < n_cols; ++c) {
             const float * xc = x + (size_t) c * K;
-            float acc = 0.0f;
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = 0.0f;
             for (int64_t k0 = 0; k0 < K; k0 += KC) {
                 const int kc = (int) min((int64_t) KC, K - k0), ng = kc / 64;
-                // this lane's slice of the weight row is requested FIRST (it does not depend on the activations): its HBM latency runs
-                // under the staging of the chunk.  (lanes past the end of a short chunk re-read the last group and drop it)
+                // this lane's slices of the weight rows are requested FIRST (they do not depend on the activations): their HBM latency
+                // runs under the staging of the chunk.  (lanes past the end of a short chunk re-read the last group and drop it;
+                // rows past M re-read the last row and are not stored)
                 const int p = lane & 3;
-                const unsigned char * bp = reinterpret_cast<const unsigned char *>(wr) + (size_t) ((k0 >> 8) + (min(lane, ng - 1) >> 2)) * 144;
-                const uint4 hdr = *reinterpret_cast<const uint4 *>(bp);   // d, dmin and the 12 scale bytes in ONE 16-byte load
-                const uint4 qa = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p), qb = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
+                uint4 hdr[R], qa[R], qb[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const unsigned char * bp = reinterpret_cast<const unsigned char *>(w) + (size_t) min(m0 + r, M - 1) * w_row_bytes +
+                                               (size_t) ((k0 >> 8) + (min(lane, ng - 1) >> 2)) * 144;
+                    hdr[r] = *reinterpret_cast<const uint4 *>(bp);   // d, dmin and the 12 scale bytes in ONE 16-byte load
+                    qa[r]  = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p);
+                    qb[r]  = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
+                }
                 __syncthreads();                                   // the previous chunk is no longer read
                 for (int i4 = threadIdx.x; i4 < kc / 4; i4 += 256) {   // 4 elements per thread, 8 threads per 32-element sub-block
                     const float4 v = *reinterpret_cast<const float4 *>(xc + k0 + 4 * i4);
@@ -99,36 +109,45 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
                               q3 = (int) __builtin_rintf(v.w * id);
                     int qs = q0 + q1 + q2 + q3;
                     qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
-                    const int grp = i4 >> 4, w = i4 & 15;          // group of 64 elements, dword inside it
-                    sq[w * 65 + grp] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
-                    if ((i4 & 7) == 0) { sd[(w >> 3) * 65 + grp] = dq; ss[(w >> 3) * 65 + grp] = dq * (float) qs; }
+                    const int grp = i4 >> 4, wi = i4 & 15;         // group of 64 elements, dword inside it
+                    sq[wi * 65 + grp] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+                    if ((i4 & 7) == 0) { sd[(wi >> 3) * 65 + grp] = dq; ss[(wi >> 3) * 65 + grp] = dq * (float) qs; }
                 }
                 __syncthreads();
                 if (lane < ng) {
-                    const uint16_t dlo = (uint16_t) (hdr.x & 0xFFFF), dhi = (uint16_t) (hdr.x >> 16);
-                    const float d = (float) *reinterpret_cast<const _Float16 *>(&dlo), dmin = (float) *reinterpret_cast<const _Float16 *>(&dhi);
-                    auto sc = [&](int k) -> int { const uint32_t w = k < 4 ? hdr.y : (k < 8 ? hdr.z : hdr.w); return (int) ((w >> (8 * (k & 3))) & 0xFF); };
-                    auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
-                        if (j < 4) { s_ = sc(j) & 63; m_ = sc(j + 4) & 63; }
-                        else       { s_ = (sc(j + 4) & 0xF) | ((sc(j - 4) >> 6) << 4); m_ = (sc(j + 4) >> 4) | ((sc(j) >> 6) << 4); }
-                    };
-                    int s1, m1, s2, m2;
-                    scale_min(2 * p, s1, m1);
-                    scale_min(2 * p + 1, s2, m2);
-                    const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-                    int ilo = 0, ihi = 0;
+                    uint32_t xq[16];
 #pragma unroll
-                    for (int w4 = 0; w4 < 8; ++w4) {               // byte b of dword w4: low nibble = element 4 w4 + b, high = 32 + 4 w4 + b
-                        ilo = __builtin_amdgcn_sdot4((int) (qw[w4] & 0x0F0F0F0Fu), (int) sq[w4 * 65 + lane], ilo, false);
-                        ihi = __builtin_amdgcn_sdot4((int) ((qw[w4] >> 4) & 0x0F0F0F0Fu), (int) sq[(8 + w4) * 65 + lane], ihi, false);
+                    for (int i = 0; i < 16; ++i) xq[i] = sq[i * 65 + lane];
+                    const float dx0 = sd[lane], dx1 = sd[65 + lane], sx0 = ss[lane], sx1 = ss[65 + lane];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint16_t dlo = (uint16_t) (hdr[r].x & 0xFFFF), dhi = (uint16_t) (hdr[r].x >> 16);
+                        const float d = (float) *reinterpret_cast<const _Float16 *>(&dlo), dmin = (float) *reinterpret_cast<const _Float16 *>(&dhi);
+                        auto sc = [&](int k) -> int { const uint32_t wd_ = k < 4 ? hdr[r].y : (k < 8 ? hdr[r].z : hdr[r].w); return (int) ((wd_ >> (8 * (k & 3))) & 0xFF); };
+                        auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
+                            if (j < 4) { s_ = sc(j) & 63; m_ = sc(j + 4) & 63; }
+                            else       { s_ = (sc(j + 4) & 0xF) | ((sc(j - 4) >> 6) << 4); m_ = (sc(j + 4) >> 4) | ((sc(j) >> 6) << 4); }
+                        };
+                        int s1, m1, s2, m2;
+                        scale_min(2 * p, s1, m1);
+                        scale_min(2 * p + 1, s2, m2);
+                        const uint32_t qw[8] = {qa[r].x, qa[r].y, qa[r].z, qa[r].w, qb[r].x, qb[r].y, qb[r].z, qb[r].w};
+                        int ilo = 0, ihi = 0;
+#pragma unroll
+                        for (int w4 = 0; w4 < 8; ++w4) {           // byte b of dword w4: low nibble = element 4 w4 + b, high = 32 + 4 w4 + b
+                            ilo = __builtin_amdgcn_sdot4((int) (qw[w4] & 0x0F0F0F0Fu), (int) xq[w4], ilo, false);
+                            ihi = __builtin_amdgcn_sdot4((int) ((qw[w4] >> 4) & 0x0F0F0F0Fu), (int) xq[8 + w4], ihi, false);
+                        }
+                        // sum (d*sc*q - dmin*m) x  with x ~ dx * xq :  d*sc*dx*sum(q xq) - dmin*m*dx*sum(xq)
+                        acc[r] += (d * (float) s1 * dx0 * (float) ilo - dmin * (float) m1 * sx0) + (d * (float) s2 * dx1 * (float) ihi - dmin * (float) m2 * sx1);
                     }
-                    // sum (d*sc*q - dmin*m) x  with x ~ dx * xq :  d*sc*dx*sum(q xq) - dmin*m*dx*sum(xq)
-                    acc += (d * (float) s1 * sd[lane] * (float) ilo - dmin * (float) m1 * ss[lane]) +
-                           (d * (float) s2 * sd[65 + lane] * (float) ihi - dmin * (float) m2 * ss[65 + lane]);
                 }
             }
-            const float v = wave_sum_f(acc);
-            if (lane == 0 && m < M) y[(size_t) c * M + m] = v;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float v = wave_sum_f(acc[r]);
+                if (lane == 0 && m0 + r < M) y[(size_t) c * M + m0 + r] = v;
+            }
         }
         return;
     }
@@ -257,7 +276,8 @@ int launch_silu(const float * x, float * y, int64_t n, hipStream_t st) {
 }
 int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st) {
     if (M == 0 || n_cols == 0) return PKV_OK;
-    const dim3 grid((unsigned) ((M + 3) / 4));
+    const int rows_wg = type_w == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
+    const dim3 grid((unsigned) ((M + rows_wg - 1) / rows_wg));
     const size_t rb = row_size(type_w, K);
     switch (type_w) {
         case PKV_TYPE_F32:  hipLaunchKernelGGL(mul_mat_kernel<PKV_TYPE_F32>, grid, dim3(256), 0, st, (const char *) w, x, y, M, K, n_cols, rb); break;
