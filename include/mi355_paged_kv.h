@@ -299,6 +299,10 @@ int pkv_cache_update(pkv_cache * c, const pkv_rope_params * rope, void * stream)
  *                      row format; q4_K dequantized as dequantize_row_q4_K, /ref/ggml/src/ggml-quants.c:1280-1302), x = n_cols rows
  *                      of K f32, y = n_cols rows of M f32   (:7467-7640) */
 int pkv_rms_norm_f32(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, void * stream);
+/* the two pairs every llama layer runs back to back, as one launch each: y = rms_norm(x) * w (w = one row of ne0 weights) and
+ * y = silu(g) * u; y_norm / y_silu receive the intermediate when non-NULL (a graph that still names it) */
+int pkv_rms_norm_mul_f32(const float * x, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps, void * stream);
+int pkv_silu_mul_f32(const float * g, const float * u, float * y_silu, float * y, int64_t n, void * stream);
 int pkv_add_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream);

@@ -327,6 +327,21 @@ def rms_norm(x, eps: float, out=None, stream=None):
     return out
 
 
+def rms_norm_mul(x, w, eps: float, stream=None):
+    """rms_norm(x) * w in one launch (w: one row of x.shape[-1] weights)"""
+    out = x.new_empty(x.shape)
+    check(lib().pkv_rms_norm_mul_f32(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(w)), None, C.c_void_p(_ptr(out)), C.c_int64(x.numel() // x.shape[-1]),
+                                     C.c_int64(x.shape[-1]), C.c_float(eps), C.c_void_p(_stream(stream))))
+    return out
+
+
+def silu_mul(g, u, stream=None):
+    """silu(g) * u in one launch"""
+    out = g.new_empty(g.shape)
+    check(lib().pkv_silu_mul_f32(C.c_void_p(_ptr(g)), C.c_void_p(_ptr(u)), None, C.c_void_p(_ptr(out)), C.c_int64(g.numel()), C.c_void_p(_stream(stream))))
+    return out
+
+
 def _binary(fn, a, b, out, stream):
     out = a.new_empty(a.shape) if out is None else out
     ne0 = a.shape[-1]

@@ -358,6 +358,28 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     for (int i = 0; i < ggml_graph_n_nodes(g); ++i) {
         ggml_tensor * n = ggml_graph_node(g, i);
         ggml_status st = GGML_STATUS_SUCCESS;
+        // two-node patterns of a llama layer run as one launch (both outputs are still written: the graph names them):
+        //   RMS_NORM -> MUL(norm, weight row)      (/ref/src/llama-model.cpp: build_norm)
+        //   UNARY(SILU)(gate) -> MUL(silu, up)     (build_ffn, LLM_FFN_SILU + LLM_FFN_PAR)
+        if (i + 1 < ggml_graph_n_nodes(g)) {
+            ggml_tensor * nx = ggml_graph_node(g, i + 1);
+            if (n->op == GGML_OP_RMS_NORM && nx->op == GGML_OP_MUL && nx->src[0] == n && supports_rms_norm(n) && supports_binary(nx) &&
+                ggml_nrows(nx->src[1]) == 1) {
+                float eps; memcpy(&eps, n->op_params, sizeof(float));
+                if (pkv_rms_norm_mul_f32((const float *) n->src[0]->data, (const float *) nx->src[1]->data, (float *) n->data, (float *) nx->data,
+                                         ggml_nrows(n), n->ne[0], eps, bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
+                ++i;
+                continue;
+            }
+            if (n->op == GGML_OP_UNARY && nx->op == GGML_OP_MUL && supports_silu(n) && supports_binary(nx) && ggml_are_same_shape(nx->src[0], nx->src[1]) &&
+                (nx->src[0] == n || nx->src[1] == n)) {
+                const ggml_tensor * up = nx->src[0] == n ? nx->src[1] : nx->src[0];
+                if (pkv_silu_mul_f32((const float *) n->src[0]->data, (const float *) up->data, (float *) n->data, (float *) nx->data,
+                                     ggml_nelements(n), bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
+                ++i;
+                continue;
+            }
+        }
         switch (n->op) {
             case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
             case GGML_OP_FLASH_ATTN_EXT: st = run_flash_attn(bc, n); break;

@@ -32,6 +32,32 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(const float * x, float * 
     for (int64_t i = threadIdx.x; i < ne0; i += 256) yr[i] = xr[i] * scale;
 }
 
+// RMSNorm followed by the row-broadcast product with the norm weight (every norm of a llama layer): one launch for the pair
+__global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, const float * w, float * y_norm, float * y, int64_t ne0, float eps) {
+    __shared__ float sred[4];
+    const float * xr = x + (size_t) blockIdx.x * ne0;
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < ne0; i += 256) { const float v = xr[i]; s = fmaf(v, v, s); }
+    s = wave_sum_f(s);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean  = (sred[0] + sred[1] + sred[2] + sred[3]) / (float) ne0;
+    const float scale = 1.0f / sqrtf(mean + eps);
+    for (int64_t i = threadIdx.x; i < ne0; i += 256) {
+        const float n = xr[i] * scale;
+        if (y_norm) y_norm[(size_t) blockIdx.x * ne0 + i] = n;
+        y[(size_t) blockIdx.x * ne0 + i] = n * w[i];
+    }
+}
+// SiLU(gate) * up (the SwiGLU product of the FFN): one launch for the pair
+__global__ void __launch_bounds__(256) silu_mul_kernel(const float * g, const float * u, float * y_silu, float * y, int64_t n) {
+    for (int64_t e = (int64_t) blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t) gridDim.x * 256) {
+        const float v = g[e], sv = v / (1.0f + expf(-v));
+        if (y_silu) y_silu[e] = sv;
+        y[e] = sv * u[e];
+    }
+}
+
 // y[r][i] = a[r][i] (op) b[r % b_rows][i]
 template <int OP>
 __global__ void __launch_bounds__(256) binary_kernel(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows) {
@@ -258,6 +284,18 @@ int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int) (g < 1
 int launch_rms_norm(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st) {
     if (n_rows == 0) return PKV_OK;
     hipLaunchKernelGGL(rms_norm_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, y, ne0, eps);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+int launch_rms_norm_mul(const float * x, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st) {
+    if (n_rows == 0) return PKV_OK;
+    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, w, y_norm, y, ne0, eps);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+int launch_silu_mul(const float * g, const float * u, float * y_silu, float * y, int64_t n, hipStream_t st) {
+    if (n == 0) return PKV_OK;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3(grid_for(n)), dim3(256), 0, st, g, u, y_silu, y, n);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

@@ -28,6 +28,9 @@ def test_rms_norm_add_mul_silu(pkv):
     s = pkv.silu(dev(x)).cpu().numpy()
     sref = x.astype(np.float64) / (1 + np.exp(-x.astype(np.float64)))
     assert np.abs(s - sref).max() <= 2e-6 * np.abs(sref).max()
+    # the fused pairs are the two separate launches, bit for bit
+    assert torch.equal(pkv.rms_norm_mul(dev(x), dev(w), 1e-5), pkv.mul(pkv.rms_norm(dev(x), 1e-5), dev(w)))
+    assert torch.equal(pkv.silu_mul(dev(x), dev(r)), pkv.mul(pkv.silu(dev(x)), dev(r)))
 
 
 @pytest.mark.parametrize("tname,M,K,N", [("f32", 64, 256, 1), ("f16", 300, 2048, 1), ("q8_0", 2048, 2048, 1), ("q8_0", 96, 5632, 3),
