@@ -355,27 +355,47 @@ void be_sync(ggml_backend_t b) { (void) hipStreamSynchronize(((backend_ctx *) b-
 ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     auto * bc = (backend_ctx *) b->context;
     (void) hipDeviceSynchronize();  // set_tensor uses the null stream
-    for (int i = 0; i < ggml_graph_n_nodes(g); ++i) {
+    const int n_nodes = ggml_graph_n_nodes(g);
+    std::vector<int> silu_of(n_nodes, -1);   // MUL node -> the SILU node whose launch was deferred into it
+    auto overlaps = [](const ggml_tensor * a, const ggml_tensor * t) {
+        const char * a0 = (const char *) a->data, * t0 = (const char *) t->data;
+        return a0 && t0 && a0 < t0 + ggml_nbytes(t) && t0 < a0 + ggml_nbytes(a);
+    };
+    for (int i = 0; i < n_nodes; ++i) {
         ggml_tensor * n = ggml_graph_node(g, i);
         ggml_status st = GGML_STATUS_SUCCESS;
         // two-node patterns of a llama layer run as one launch (both outputs are still written: the graph names them):
         //   RMS_NORM -> MUL(norm, weight row)      (/ref/src/llama-model.cpp: build_norm)
-        //   UNARY(SILU)(gate) -> MUL(silu, up)     (build_ffn, LLM_FFN_SILU + LLM_FFN_PAR)
-        if (i + 1 < ggml_graph_n_nodes(g)) {
+        //   UNARY(SILU)(gate) ... MUL(silu, up)    (build_ffn, LLM_FFN_SILU + LLM_FFN_PAR).  The graph's topological order puts the up
+        //   product BETWEEN the two (gate product, silu, up product, mul): the SILU launch is deferred into the MUL when no node in
+        //   between reads the silu result or writes over it or over the gate.
+        if (silu_of[i] >= 0) {
+            ggml_tensor * sn = ggml_graph_node(g, silu_of[i]);
+            const ggml_tensor * up = n->src[0] == sn ? n->src[1] : n->src[0];
+            if (pkv_silu_mul_f32((const float *) sn->src[0]->data, (const float *) up->data, (float *) sn->data, (float *) n->data,
+                                 ggml_nelements(sn), bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
+            continue;
+        }
+        if (n->op == GGML_OP_UNARY && supports_silu(n)) {
+            int j = -1;
+            for (int k = i + 1; k < n_nodes && k <= i + 3; ++k) {
+                ggml_tensor * nk = ggml_graph_node(g, k);
+                bool reads = false;
+                for (int s_ = 0; s_ < GGML_MAX_SRC; ++s_) reads = reads || (nk->src[s_] && (nk->src[s_] == n || nk->src[s_]->view_src == n));
+                if (nk->op == GGML_OP_MUL && reads && supports_binary(nk) && ggml_are_same_shape(nk->src[0], nk->src[1]) &&
+                    (nk->src[0] == n) != (nk->src[1] == n) &&
+                    (!overlaps(nk, n->src[0]) || nk->data == n->src[0]->data) && (!overlaps(nk, n) || nk->data == n->data)) { j = k; break; }   // ggml-alloc runs SILU and MUL in place (ggml-alloc.c:41-67): exact aliases are element-wise safe
+                if (reads || nk->view_src == n || overlaps(nk, n) || overlaps(nk, n->src[0])) break;
+            }
+            if (j >= 0) { silu_of[j] = i; continue; }
+        }
+        if (i + 1 < n_nodes) {
             ggml_tensor * nx = ggml_graph_node(g, i + 1);
             if (n->op == GGML_OP_RMS_NORM && nx->op == GGML_OP_MUL && nx->src[0] == n && supports_rms_norm(n) && supports_binary(nx) &&
                 ggml_nrows(nx->src[1]) == 1) {
                 float eps; memcpy(&eps, n->op_params, sizeof(float));
                 if (pkv_rms_norm_mul_f32((const float *) n->src[0]->data, (const float *) nx->src[1]->data, (float *) n->data, (float *) nx->data,
                                          ggml_nrows(n), n->ne[0], eps, bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
-                ++i;
-                continue;
-            }
-            if (n->op == GGML_OP_UNARY && nx->op == GGML_OP_MUL && supports_silu(n) && supports_binary(nx) && ggml_are_same_shape(nx->src[0], nx->src[1]) &&
-                (nx->src[0] == n || nx->src[1] == n)) {
-                const ggml_tensor * up = nx->src[0] == n ? nx->src[1] : nx->src[0];
-                if (pkv_silu_mul_f32((const float *) n->src[0]->data, (const float *) up->data, (float *) n->data, (float *) nx->data,
-                                     ggml_nelements(n), bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
                 ++i;
                 continue;
             }

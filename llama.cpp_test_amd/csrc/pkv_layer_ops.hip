@@ -17,36 +17,55 @@ __device__ __forceinline__ float wave_sum_f(float x) {
     return x;
 }
 
-// one 256-thread workgroup per row
-__global__ void __launch_bounds__(256) rms_norm_kernel(const float * x, float * y, int64_t ne0, float eps) {
-    __shared__ float sred[4];
-    const float * xr = x + (size_t) blockIdx.x * ne0;
-    float *       yr = y + (size_t) blockIdx.x * ne0;
-    float s = 0.0f;
-    for (int64_t i = threadIdx.x; i < ne0; i += 256) { const float v = xr[i]; s = fmaf(v, v, s); }
-    s = wave_sum_f(s);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float mean  = (sred[0] + sred[1] + sred[2] + sred[3]) / (float) ne0;
-    const float scale = 1.0f / sqrtf(mean + eps);
-    for (int64_t i = threadIdx.x; i < ne0; i += 256) yr[i] = xr[i] * scale;
-}
-
-// RMSNorm followed by the row-broadcast product with the norm weight (every norm of a llama layer): one launch for the pair
+// one 256-thread workgroup per row; rows of up to 8192 elements stay in registers between the sum of squares and the scaling
+// (one memory round trip instead of two: at decode there is ONE row, so the kernel is a latency chain, not a bandwidth problem).
+// y_norm may be NULL; w (one row of ne0 weights) may be NULL (plain rms_norm: y = the normalised row).
+// The weight row is requested together with x (it does not depend on the reduction), so its HBM latency is not a second trip.
+constexpr int RMS_MAX_V4 = 8;   // float4 per thread: rows of up to 256 * 4 * 8 = 8192 elements
 __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, const float * w, float * y_norm, float * y, int64_t ne0, float eps) {
     __shared__ float sred[4];
-    const float * xr = x + (size_t) blockIdx.x * ne0;
+    const size_t ro = (size_t) blockIdx.x * ne0;
+    const float * xr = x + ro;
+    const bool in_regs = (ne0 & 3) == 0 && ne0 <= 256 * 4 * RMS_MAX_V4;
+    float4 v[RMS_MAX_V4], wv[RMS_MAX_V4];
     float s = 0.0f;
-    for (int64_t i = threadIdx.x; i < ne0; i += 256) { const float v = xr[i]; s = fmaf(v, v, s); }
+    if (in_regs) {
+        const int64_t n4 = ne0 >> 2;
+#pragma unroll
+        for (int j = 0; j < RMS_MAX_V4; ++j) {
+            const int64_t i = threadIdx.x + 256 * j;
+            v[j]  = i < n4 ? reinterpret_cast<const float4 *>(xr)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[j] = (w && i < n4) ? reinterpret_cast<const float4 *>(w)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int j = 0; j < RMS_MAX_V4; ++j) {   // same element order per thread as the scalar loop would not matter: the sum is re-associated by the tree anyway
+            s = fmaf(v[j].x, v[j].x, s); s = fmaf(v[j].y, v[j].y, s); s = fmaf(v[j].z, v[j].z, s); s = fmaf(v[j].w, v[j].w, s);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < ne0; i += 256) { const float t = xr[i]; s = fmaf(t, t, s); }
+    }
     s = wave_sum_f(s);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
     __syncthreads();
     const float mean  = (sred[0] + sred[1] + sred[2] + sred[3]) / (float) ne0;
     const float scale = 1.0f / sqrtf(mean + eps);
-    for (int64_t i = threadIdx.x; i < ne0; i += 256) {
-        const float n = xr[i] * scale;
-        if (y_norm) y_norm[(size_t) blockIdx.x * ne0 + i] = n;
-        y[(size_t) blockIdx.x * ne0 + i] = n * w[i];
+    if (in_regs) {
+        const int64_t n4 = ne0 >> 2;
+#pragma unroll
+        for (int j = 0; j < RMS_MAX_V4; ++j) {
+            const int64_t i = threadIdx.x + 256 * j;
+            if (i < n4) {
+                const float4 n = make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
+                if (y_norm) reinterpret_cast<float4 *>(y_norm + ro)[i] = n;
+                if (y) reinterpret_cast<float4 *>(y + ro)[i] = w ? make_float4(n.x * wv[j].x, n.y * wv[j].y, n.z * wv[j].z, n.w * wv[j].w) : n;
+            }
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < ne0; i += 256) {
+            const float n = xr[i] * scale;
+            if (y_norm) y_norm[ro + i] = n;
+            if (y) y[ro + i] = w ? n * w[i] : n;
+        }
     }
 }
 // SiLU(gate) * up (the SwiGLU product of the FFN): one launch for the pair
@@ -283,7 +302,7 @@ int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int) (g < 1
 
 int launch_rms_norm(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st) {
     if (n_rows == 0) return PKV_OK;
-    hipLaunchKernelGGL(rms_norm_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, y, ne0, eps);
+    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, (const float *) nullptr, (float *) nullptr, y, ne0, eps);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
