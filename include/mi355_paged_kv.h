@@ -307,6 +307,12 @@ int pkv_add_f32(const float * a, const float * b, float * y, int64_t n_rows, int
 int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream);
 int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream);
+/* n (1..PKV_MUL_MAT_MAX) products that share x, K, n_cols and the weight type — wq / wk / wv of a layer, gate / up of its FFN
+ * (/ref/src/llama-model.cpp build_attn inputs, build_ffn LLM_FFN_PAR) — results identical to n pkv_mul_mat calls; q4_K weights
+ * run as ONE launch (at decode a product is mostly its launch-and-latency floor) */
+#define PKV_MUL_MAT_MAX 4
+int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
+                      void * stream);
 
 /* Session state of the KV cache in the reference's byte format: llama_kv_cache_unified::state_write / state_read
  * (/ref/src/llama-kv-cache.cpp:848-1221; reached through llama_state_get_data / llama_state_seq_get_data,

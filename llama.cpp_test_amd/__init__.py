@@ -377,6 +377,19 @@ def mul_mat(w, type_w: int, M: int, K: int, x, out=None, stream=None):
     return out
 
 
+def mul_mat_multi(ws, type_w: int, Ms, K: int, x, stream=None):
+    """pkv_mul_mat_multi: len(ws) products on the same activations x (wq / wk / wv, gate / up); q4_K weights run as one launch.
+    Returns the list of f32 [n_cols][M_i] results."""
+    import torch
+    n, n_cols = len(ws), x.shape[0]
+    outs = [torch.empty((n_cols, int(M)), dtype=torch.float32, device=x.device) for M in Ms]
+    wp = (C.c_void_p * n)(*[_ptr(w) for w in ws])
+    yp = (C.c_void_p * n)(*[_ptr(o) for o in outs])
+    mp = (C.c_int64 * n)(*[int(M) for M in Ms])
+    check(lib().pkv_mul_mat_multi(n, wp, type_w, C.c_void_p(_ptr(x)), yp, mp, C.c_int64(K), C.c_int64(n_cols), C.c_void_p(_stream(stream))))
+    return outs
+
+
 # ---- llama_kv_cache mirror ---------------------------------------------------------------------------------------------
 class PagedKVCache:
     """`llama_kv_cache` method set (/root/reference/src/llama-kv-cache.h:17-26) over the C++ block manager.

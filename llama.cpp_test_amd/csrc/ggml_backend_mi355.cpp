@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <utility>
@@ -361,9 +362,48 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         const char * a0 = (const char *) a->data, * t0 = (const char *) t->data;
         return a0 && t0 && a0 < t0 + ggml_nbytes(t) && t0 < a0 + ggml_nbytes(a);
     };
+    static const bool trace = getenv("GGML_MI355_TRACE") != nullptr;   // node list of every graph, for working on the fusion rules
+    if (trace) for (int i = 0; i < n_nodes; ++i) {
+        const ggml_tensor * t = ggml_graph_node(g, i);
+        MI355_LOG("node %3d %-14s %-24s data %p nbytes %zu src0 %s src1 %s\n", i, ggml_op_name(t->op), t->name, t->data, ggml_nbytes(t),
+                  t->src[0] ? t->src[0]->name : "-", t->src[1] ? t->src[1]->name : "-");
+    }
+    std::vector<char> done(n_nodes, 0);      // MUL_MAT nodes already run together with an earlier product on the same activations
     for (int i = 0; i < n_nodes; ++i) {
         ggml_tensor * n = ggml_graph_node(g, i);
         ggml_status st = GGML_STATUS_SUCCESS;
+        if (done[i]) continue;
+        // q4_K products that read the SAME activation tensor (wq / wk / wv of a layer, gate / up of its FFN) run as one launch: the later
+        // ones are pulled forward to the first, when their output does not alias anything the nodes in between read or write
+        // (ggml-alloc hands freed ranges to later nodes, ggml-alloc.c:470-560)
+        if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_Q4_K && supports_mul_mat(n)) {
+            int grp[PKV_MUL_MAT_MAX], ngp = 1;
+            grp[0] = i;
+            for (int k = i + 1; k < n_nodes && k <= i + 16 && ngp < PKV_MUL_MAT_MAX; ++k) {
+                ggml_tensor * nk = ggml_graph_node(g, k);
+                if (nk->op != GGML_OP_MUL_MAT || nk->src[1] != n->src[1] || !nk->src[0] || nk->src[0]->type != GGML_TYPE_Q4_K || !supports_mul_mat(nk) || done[k]) continue;
+                bool safe = true;
+                for (int q = i; q < k && safe; ++q) {
+                    const ggml_tensor * nq = ggml_graph_node(g, q);
+                    if (overlaps(nk, nq)) safe = false;
+                    for (int s_ = 0; s_ < GGML_MAX_SRC && safe; ++s_) if (nq->src[s_] && overlaps(nk, nq->src[s_])) safe = false;
+                }
+                if (safe) grp[ngp++] = k;
+            }
+            if (ngp > 1) {
+                const void * wv[PKV_MUL_MAT_MAX]; float * yv[PKV_MUL_MAT_MAX]; int64_t mv[PKV_MUL_MAT_MAX];
+                for (int q = 0; q < ngp; ++q) {
+                    const ggml_tensor * nq = ggml_graph_node(g, grp[q]);
+                    wv[q] = nq->src[0]->data; yv[q] = (float *) nq->data; mv[q] = nq->src[0]->ne[1];
+                    done[grp[q]] = 1;
+                }
+                if (pkv_mul_mat_multi(ngp, wv, PKV_TYPE_Q4_K, (const float *) n->src[1]->data, yv, mv, n->src[0]->ne[0], n->src[1]->ne[1], bc->stream) != PKV_OK) {
+                    MI355_LOG("mul_mat_multi failed: %s\n", pkv_last_error());
+                    return GGML_STATUS_FAILED;
+                }
+                continue;
+            }
+        }
         // two-node patterns of a llama layer run as one launch (both outputs are still written: the graph names them):
         //   RMS_NORM -> MUL(norm, weight row)      (/ref/src/llama-model.cpp: build_norm)
         //   UNARY(SILU)(gate) ... MUL(silu, up)    (build_ffn, LLM_FFN_SILU + LLM_FFN_PAR).  The graph's topological order puts the up

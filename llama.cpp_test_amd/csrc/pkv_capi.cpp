@@ -470,6 +470,16 @@ int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t 
                 ((uintptr_t) x % 16) == 0 && ((uintptr_t) w % (type_w == PKV_TYPE_Q8_0 ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
     return launch_mul_mat(w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
 }
+int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
+                      void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(n >= 1 && n <= PKV_MUL_MAT_MAX && w && x && y && M && K > 0 && n_cols >= 0, "pkv_mul_mat_multi: bad arguments");
+    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : (type_w == PKV_TYPE_Q4_K ? 256 : PKV_QK))) == 0 && ((uintptr_t) x % 16) == 0,
+                "pkv_mul_mat_multi: K / alignment not supported");
+    for (int i = 0; i < n; ++i)
+        PKV_REQUIRE(w[i] && y[i] && M[i] >= 0 && ((uintptr_t) w[i] % (type_w == PKV_TYPE_Q8_0 ? 2 : 16)) == 0, "pkv_mul_mat_multi: bad product %d", i);
+    return launch_mul_mat_multi(n, w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
+}
 
 // ---- session state: llama_kv_cache_unified::state_write / state_read in the reference's byte format ------------------------
 // (/ref/src/llama-kv-cache.cpp:848-1221)   u32 cell_count | per cell: i32 pos, u32 n_seq_id, i32 seq_id[n_seq_id] |

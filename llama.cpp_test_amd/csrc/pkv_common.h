@@ -80,6 +80,8 @@ int launch_silu_mul(const float * g, const float * u, float * y_silu, float * y,
 int launch_binary(int op, const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, hipStream_t st);
 int launch_silu(const float * x, float * y, int64_t n, hipStream_t st);
 int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st);
+int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
+                         hipStream_t st);
 int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);
 
 }  // namespace pkv

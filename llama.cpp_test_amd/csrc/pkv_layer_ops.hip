@@ -105,13 +105,11 @@ __global__ void __launch_bounds__(256) silu_kernel(const float * x, float * y, i
 // At these sizes (4-12 MB per product, 17-48 KB per CU) the products are one memory round trip plus the launch floor, not
 // bandwidth-bound: the next step is fewer, larger launches (fused gate/up, persistent layer kernel), not a different inner loop.
 constexpr int MM_CT = 8, Q4K_ROWS = 2;
-template <int WT>
-__global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols,
-                                                      size_t w_row_bytes) {
+// block_q4_K rows x one f32 activation column per pass; `wg` = index of the group of 4 Q4K_ROWS rows this workgroup owns
+__device__ __forceinline__ void q4k_rows(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, size_t w_row_bytes,
+                                         int64_t wg) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t m = (int64_t) blockIdx.x * 4 + wv;
-    const char * wr = w + (size_t) min(m, M - 1) * w_row_bytes;            // surplus waves redo the last row and do not store
-    if constexpr (WT == PKV_TYPE_Q4_K) {
+
         // block_q4_K: half d, half dmin, 12 bytes of packed 6-bit (scale, min) pairs, 128 bytes of nibbles = 256 elements in 4 groups
         // of 64 (low nibbles = first 32 elements of the group, high nibbles = the next 32).  A lane owns one 64-element group of a
         // 4096-element chunk.  The chunk of the activation column is staged ONCE per workgroup in LDS, transposed (element-major,
@@ -123,7 +121,7 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
         constexpr int KC = 4096, R = Q4K_ROWS;   // R weight rows per wave: the staged chunk serves 4 R rows, R x 3 loads in flight per lane
         __shared__ uint32_t sq[16 * 65];      // [dword of the group (4 int8)][group] : lane = group reads stride-1
         __shared__ float    sd[2 * 65], ss[2 * 65];   // per (half of the group, group): scale, scale * sum of the int8
-        const int64_t m0 = ((int64_t) blockIdx.x * 4 + wv) * R;
+        const int64_t m0 = (wg * 4 + wv) * R;
         for (int64_t c = 0; c < n_cols; ++c) {
             const float * xc = x + (size_t) c * K;
             float acc[R];
@@ -144,9 +142,19 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
                     qa[r]  = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p);
                     qb[r]  = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
                 }
+                // the chunk's activations: all of a thread's float4 are requested before any is used (a loop over them would pay
+                // the L2 latency once per iteration: kc is not a compile-time constant)
+                float4 xv[KC / 1024];
+#pragma unroll
+                for (int u = 0; u < KC / 1024; ++u) {
+                    const int i4 = threadIdx.x + 256 * u;
+                    xv[u] = i4 < kc / 4 ? *reinterpret_cast<const float4 *>(xc + k0 + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 __syncthreads();                                   // the previous chunk is no longer read
-                for (int i4 = threadIdx.x; i4 < kc / 4; i4 += 256) {   // 4 elements per thread, 8 threads per 32-element sub-block
-                    const float4 v = *reinterpret_cast<const float4 *>(xc + k0 + 4 * i4);
+#pragma unroll
+                for (int u = 0; u < KC / 1024; ++u) {                  // 4 elements per thread, 8 threads per 32-element sub-block
+                    const int i4 = threadIdx.x + 256 * u;
+                    const float4 v = xv[u];
                     float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
                     amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
                     const float dq = amax / 127.0f, id = amax != 0.0f ? 127.0f / amax : 0.0f;
@@ -155,8 +163,10 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
                     int qs = q0 + q1 + q2 + q3;
                     qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
                     const int grp = i4 >> 4, wi = i4 & 15;         // group of 64 elements, dword inside it
-                    sq[wi * 65 + grp] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
-                    if ((i4 & 7) == 0) { sd[(wi >> 3) * 65 + grp] = dq; ss[(wi >> 3) * 65 + grp] = dq * (float) qs; }
+                    if (i4 < kc / 4) {
+                        sq[wi * 65 + grp] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+                        if ((i4 & 7) == 0) { sd[(wi >> 3) * 65 + grp] = dq; ss[(wi >> 3) * 65 + grp] = dq * (float) qs; }
+                    }
                 }
                 __syncthreads();
                 if (lane < ng) {
@@ -194,8 +204,24 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
                 if (lane == 0 && m0 + r < M) y[(size_t) c * M + m0 + r] = v;
             }
         }
-        return;
-    }
+        }
+
+// up to PKV_MUL_MAT_MAX products that share the activation column(s) and K (the q / k / v projections of a layer, gate / up of its
+// FFN) in ONE launch: at decode each product is a ~5 us launch-and-latency floor plus its bytes, so three launches cost three floors
+struct MulMatMulti { const char * w[PKV_MUL_MAT_MAX]; float * y[PKV_MUL_MAT_MAX]; int64_t M[PKV_MUL_MAT_MAX]; int wg_end[PKV_MUL_MAT_MAX]; int n; };
+__global__ void __launch_bounds__(256) mul_mat_q4k_multi_kernel(MulMatMulti a, const float * x, int64_t K, int64_t n_cols, size_t w_row_bytes) {
+    int i = 0;
+    while (i + 1 < a.n && (int) blockIdx.x >= a.wg_end[i]) ++i;
+    q4k_rows(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, (int64_t) blockIdx.x - (i ? a.wg_end[i - 1] : 0));
+}
+
+template <int WT>
+__global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols,
+                                                      size_t w_row_bytes) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t m = (int64_t) blockIdx.x * 4 + wv;
+    const char * wr = w + (size_t) min(m, M - 1) * w_row_bytes;            // surplus waves redo the last row and do not store
+    if constexpr (WT == PKV_TYPE_Q4_K) { q4k_rows(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
     if constexpr (WT == PKV_TYPE_Q8_0) {
         // same scheme for block_q8_0 rows: a lane owns one 32-element block of a 2048-element chunk, the activation chunk is staged
         // once per workgroup in LDS, transposed (row stride 65)
@@ -343,6 +369,27 @@ int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64
         case PKV_TYPE_Q4_K: hipLaunchKernelGGL(mul_mat_kernel<PKV_TYPE_Q4_K>, grid, dim3(256), 0, st, (const char *) w, x, y, M, K, n_cols, rb); break;
         default: set_error("pkv_mul_mat: weight type %d not supported (f32, f16, q8_0, q4_K)", type_w); return PKV_ERR_UNSUPPORTED;
     }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+
+int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
+                         hipStream_t st) {
+    if (type_w != PKV_TYPE_Q4_K) {                                 // one launch each for the other weight types
+        for (int i = 0; i < n; ++i) if (int rc = launch_mul_mat(w[i], type_w, x, y[i], M[i], K, n_cols, st)) return rc;
+        return PKV_OK;
+    }
+    if (n_cols == 0) return PKV_OK;
+    MulMatMulti a = {};
+    int tot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (M[i] == 0) continue;
+        a.w[a.n] = (const char *) w[i]; a.y[a.n] = y[i]; a.M[a.n] = M[i];
+        tot += (int) ((M[i] + 4 * Q4K_ROWS - 1) / (4 * Q4K_ROWS));
+        a.wg_end[a.n++] = tot;
+    }
+    if (a.n == 0) return PKV_OK;
+    hipLaunchKernelGGL(mul_mat_q4k_multi_kernel, dim3((unsigned) tot), dim3(256), 0, st, a, x, K, n_cols, row_size(PKV_TYPE_Q4_K, K));
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

@@ -34,7 +34,10 @@ def test_rms_norm_add_mul_silu(pkv):
 
 
 @pytest.mark.parametrize("tname,M,K,N", [("f32", 64, 256, 1), ("f16", 300, 2048, 1), ("q8_0", 2048, 2048, 1), ("q8_0", 96, 5632, 3),
-                                         ("f16", 32, 512, 19), ("q8_0", 257, 96, 9), ("q4_K", 4096, 4096, 1), ("q4_K", 130, 768, 11)])
+                                         ("f16", 32, 512, 19), ("q8_0", 257, 96, 9), ("q4_K", 4096, 4096, 1), ("q4_K", 130, 768, 11),
+                                         # several row groups per workgroup (grid capped), 3.5 chunks of one staged column, a column
+                                         # longer than one staging (super-chunks), and all of it with two columns
+                                         ("q4_K", 14336, 4096, 1), ("q4_K", 1030, 14336, 2), ("q4_K", 70, 20480, 2), ("q4_K", 8200, 512, 2)])
 def test_mul_mat(pkv, O, tname, M, K, N):
     t = {"f32": 0, "f16": 1, "q8_0": 8, "q4_K": 12}[tname]
     rng = np.random.default_rng(M + K + N)
@@ -66,3 +69,21 @@ def test_mul_mat(pkv, O, tname, M, K, N):
         assert float(((y - ref) ** 2).sum() / (ref ** 2).sum()) <= 1e-4
         return
     assert np.abs(y - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()) * np.sqrt(K / 256)
+
+
+@pytest.mark.parametrize("tname,Ms,K,N", [("q4_K", (4096, 1024, 1024), 4096, 1), ("q4_K", (14336, 14336), 4096, 1), ("q4_K", (70, 9, 257, 8), 768, 3),
+                                          ("q8_0", (64, 96), 256, 2)])
+def test_mul_mat_multi(pkv, tname, Ms, K, N):
+    """pkv_mul_mat_multi == the separate pkv_mul_mat calls, bit for bit (same arithmetic, one launch for q4_K)"""
+    t = {"q8_0": 8, "q4_K": 12}[tname]
+    rng = np.random.default_rng(sum(Ms) + K)
+    from llama_cpp_test_amd import gguf_synth as G
+    x = dev(rng.standard_normal((N, K)).astype(np.float32))
+    if t == 12:
+        ws = [dev(np.frombuffer(G.random_q4_K(rng, M, K), np.uint8).copy()) for M in Ms]
+    else:
+        ws = [dev(np.frombuffer(G.quantize_q8_0((rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)), np.uint8).copy()) for M in Ms]
+    got = pkv.mul_mat_multi(ws, t, Ms, K, x)
+    for w, M, y in zip(ws, Ms, got):
+        want = pkv.mul_mat(w, t, M, K, x)
+        assert y.shape == (N, M) and torch.equal(y, want)
