@@ -303,6 +303,10 @@ int pkv_rms_norm_f32(const float * x, float * y, int64_t n_rows, int64_t ne0, fl
  * y = silu(g) * u; y_norm / y_silu receive the intermediate when non-NULL (a graph that still names it) */
 int pkv_rms_norm_mul_f32(const float * x, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps, void * stream);
 int pkv_silu_mul_f32(const float * g, const float * u, float * y_silu, float * y, int64_t n, void * stream);
+/* the residual add in front of the norm in the same launch: sum = a + b (same shape; sum may be a or b: in-place ADD of ggml-alloc),
+ * y = rms_norm(sum) * w — ffn_inp = attn_out + inpL -> ffn_norm, l_out = ffn_out + ffn_inp -> the next layer's attn_norm */
+int pkv_add_rms_norm_mul_f32(const float * a, const float * b, float * sum, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps,
+                             void * stream);
 int pkv_add_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream);

@@ -335,6 +335,15 @@ def rms_norm_mul(x, w, eps: float, stream=None):
     return out
 
 
+def add_rms_norm_mul(a, b, w, eps: float, in_place: bool = False, stream=None):
+    """(a + b, rms_norm(a + b) * w) in one launch; in_place writes the sum over a (what ggml-alloc's in-place ADD does)"""
+    s_ = a if in_place else a.new_empty(a.shape)
+    out = a.new_empty(a.shape)
+    check(lib().pkv_add_rms_norm_mul_f32(C.c_void_p(_ptr(a)), C.c_void_p(_ptr(b)), C.c_void_p(_ptr(s_)), C.c_void_p(_ptr(w)), None, C.c_void_p(_ptr(out)),
+                                         C.c_int64(a.numel() // a.shape[-1]), C.c_int64(a.shape[-1]), C.c_float(eps), C.c_void_p(_stream(stream))))
+    return s_, out
+
+
 def silu_mul(g, u, stream=None):
     """silu(g) * u in one launch"""
     out = g.new_empty(g.shape)

@@ -429,6 +429,18 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             }
             if (j >= 0) { silu_of[j] = i; continue; }
         }
+        //   ADD(a, b) -> RMS_NORM -> MUL            (the residual add in front of a norm: ffn_inp / l_out; its sum is still written)
+        if (i + 2 < n_nodes && n->op == GGML_OP_ADD && supports_binary(n) && ggml_are_same_shape(n->src[0], n->src[1])) {
+            ggml_tensor * n1 = ggml_graph_node(g, i + 1), * n2 = ggml_graph_node(g, i + 2);
+            if (n1->op == GGML_OP_RMS_NORM && n1->src[0] == n && supports_rms_norm(n1) && n2->op == GGML_OP_MUL && n2->src[0] == n1 && supports_binary(n2) &&
+                ggml_nrows(n2->src[1]) == 1 && n1->data != n->data && n2->data != n->data) {   // the sum must survive: it is the next residual
+                float eps; memcpy(&eps, n1->op_params, sizeof(float));
+                if (pkv_add_rms_norm_mul_f32((const float *) n->src[0]->data, (const float *) n->src[1]->data, (float *) n->data, (const float *) n2->src[1]->data,
+                                             (float *) n1->data, (float *) n2->data, ggml_nrows(n), n->ne[0], eps, bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
+                i += 2;
+                continue;
+            }
+        }
         if (i + 1 < n_nodes) {
             ggml_tensor * nx = ggml_graph_node(g, i + 1);
             if (n->op == GGML_OP_RMS_NORM && nx->op == GGML_OP_MUL && nx->src[0] == n && supports_rms_norm(n) && supports_binary(nx) &&

@@ -441,7 +441,13 @@ int pkv_rms_norm_f32(const float * x, float * y, int64_t n_rows, int64_t ne0, fl
 int pkv_rms_norm_mul_f32(const float * x, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(x && w && y && n_rows >= 0 && ne0 > 0 && eps >= 0.0f, "pkv_rms_norm_mul_f32: bad arguments");
-    return launch_rms_norm_mul(x, w, y_norm, y, n_rows, ne0, eps, (hipStream_t) stream);
+    return launch_rms_norm_mul(x, nullptr, nullptr, w, y_norm, y, n_rows, ne0, eps, (hipStream_t) stream);
+}
+int pkv_add_rms_norm_mul_f32(const float * a, const float * b, float * sum, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps,
+                             void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(a && b && sum && w && y && n_rows >= 0 && ne0 > 0 && eps >= 0.0f, "pkv_add_rms_norm_mul_f32: bad arguments");
+    return launch_rms_norm_mul(a, b, sum, w, y_norm, y, n_rows, ne0, eps, (hipStream_t) stream);
 }
 int pkv_silu_mul_f32(const float * g, const float * u, float * y_silu, float * y, int64_t n, void * stream) {
     if (int rc = ensure_device()) return rc;

@@ -75,7 +75,8 @@ int launch_rows_io(void * pool, int type, int is_v, void * rows, const int32_t *
                    int n_head_kv, int D, int block_size, bool scatter, hipStream_t st, int64_t rs_tok = 0, int64_t rs_head = 0);
 // first slice of the rest of the decoder layer (pkv_layer_ops.hip)
 int launch_rms_norm(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st);
-int launch_rms_norm_mul(const float * x, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st);
+int launch_rms_norm_mul(const float * x, const float * res, float * x_out, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps,
+                        hipStream_t st);
 int launch_silu_mul(const float * g, const float * u, float * y_silu, float * y, int64_t n, hipStream_t st);
 int launch_binary(int op, const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, hipStream_t st);
 int launch_silu(const float * x, float * y, int64_t n, hipStream_t st);

@@ -22,7 +22,10 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 // y_norm may be NULL; w (one row of ne0 weights) may be NULL (plain rms_norm: y = the normalised row).
 // The weight row is requested together with x (it does not depend on the reduction), so its HBM latency is not a second trip.
 constexpr int RMS_MAX_V4 = 8;   // float4 per thread: rows of up to 256 * 4 * 8 = 8192 elements
-__global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, const float * w, float * y_norm, float * y, int64_t ne0, float eps) {
+// res / x_out (both or neither): the residual add in front of the norm, x_out = x + res is what gets normalised (ADD -> RMS_NORM -> MUL
+// of a llama layer, /ref/src/llama-model.cpp: ffn_inp = attn_out + inpL, then build_norm) — each thread adds, stores and keeps its own elements
+__global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, const float * res, float * x_out, const float * w, float * y_norm, float * y,
+                                                           int64_t ne0, float eps) {
     __shared__ float sred[4];
     const size_t ro = (size_t) blockIdx.x * ne0;
     const float * xr = x + ro;
@@ -37,12 +40,30 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
             v[j]  = i < n4 ? reinterpret_cast<const float4 *>(xr)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             wv[j] = (w && i < n4) ? reinterpret_cast<const float4 *>(w)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
         }
+        if (res) {
+            float4 rv[RMS_MAX_V4];
+#pragma unroll
+            for (int j = 0; j < RMS_MAX_V4; ++j) {
+                const int64_t i = threadIdx.x + 256 * j;
+                rv[j] = i < n4 ? reinterpret_cast<const float4 *>(res + ro)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < RMS_MAX_V4; ++j) {
+                const int64_t i = threadIdx.x + 256 * j;
+                v[j] = make_float4(v[j].x + rv[j].x, v[j].y + rv[j].y, v[j].z + rv[j].z, v[j].w + rv[j].w);
+                if (i < n4) reinterpret_cast<float4 *>(x_out + ro)[i] = v[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < RMS_MAX_V4; ++j) {   // same element order per thread as the scalar loop would not matter: the sum is re-associated by the tree anyway
             s = fmaf(v[j].x, v[j].x, s); s = fmaf(v[j].y, v[j].y, s); s = fmaf(v[j].z, v[j].z, s); s = fmaf(v[j].w, v[j].w, s);
         }
     } else {
-        for (int64_t i = threadIdx.x; i < ne0; i += 256) { const float t = xr[i]; s = fmaf(t, t, s); }
+        for (int64_t i = threadIdx.x; i < ne0; i += 256) {
+            float t = xr[i];
+            if (res) { t += res[ro + i]; x_out[ro + i] = t; }
+            s = fmaf(t, t, s);
+        }
     }
     s = wave_sum_f(s);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
@@ -61,8 +82,9 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
             }
         }
     } else {
+        const float * xs = res ? x_out + ro : xr;                 // the thread's own stores of the first pass
         for (int64_t i = threadIdx.x; i < ne0; i += 256) {
-            const float n = xr[i] * scale;
+            const float n = xs[i] * scale;
             if (y_norm) y_norm[ro + i] = n;
             if (y) y[ro + i] = w ? n * w[i] : n;
         }
@@ -328,13 +350,14 @@ int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int) (g < 1
 
 int launch_rms_norm(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st) {
     if (n_rows == 0) return PKV_OK;
-    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, (const float *) nullptr, (float *) nullptr, y, ne0, eps);
+    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, (const float *) nullptr, (float *) nullptr, (const float *) nullptr, (float *) nullptr, y, ne0, eps);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
-int launch_rms_norm_mul(const float * x, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st) {
+int launch_rms_norm_mul(const float * x, const float * res, float * x_out, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps,
+                        hipStream_t st) {
     if (n_rows == 0) return PKV_OK;
-    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, w, y_norm, y, ne0, eps);
+    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, res, x_out, w, y_norm, y, ne0, eps);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

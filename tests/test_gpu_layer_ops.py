@@ -31,6 +31,19 @@ def test_rms_norm_add_mul_silu(pkv):
     # the fused pairs are the two separate launches, bit for bit
     assert torch.equal(pkv.rms_norm_mul(dev(x), dev(w), 1e-5), pkv.mul(pkv.rms_norm(dev(x), 1e-5), dev(w)))
     assert torch.equal(pkv.silu_mul(dev(x), dev(r)), pkv.mul(pkv.silu(dev(x)), dev(r)))
+    # ... and so is the residual add in front of the norm (register path: rows of 2048; loop path: rows of 1030 and of 9216 elements)
+    for ne0, rows in ((2048, 37), (1030, 5), (9216, 3), (4096, 1)):
+        a = dev(rng.standard_normal((rows, ne0)).astype(np.float32) * 2)
+        b = dev(rng.standard_normal((rows, ne0)).astype(np.float32))
+        w2 = dev(rng.standard_normal(ne0).astype(np.float32))
+        want_sum = pkv.add(a, b)
+        want = pkv.mul(pkv.rms_norm(want_sum, 1e-5), w2)
+        assert torch.equal(pkv.rms_norm_mul(want_sum, w2, 1e-5), want)
+        got_sum, got = pkv.add_rms_norm_mul(a, b, w2, 1e-5)
+        assert torch.equal(got_sum, want_sum) and torch.equal(got, want)
+        a2 = a.clone()
+        got_sum, got = pkv.add_rms_norm_mul(a2, b, w2, 1e-5, in_place=True)
+        assert got_sum.data_ptr() == a2.data_ptr() and torch.equal(a2, want_sum) and torch.equal(got, want)
 
 
 @pytest.mark.parametrize("tname,M,K,N", [("f32", 64, 256, 1), ("f16", 300, 2048, 1), ("q8_0", 2048, 2048, 1), ("q8_0", 96, 5632, 3),
