@@ -97,6 +97,12 @@ int pkv_rope_f16_strided(const void * x, int64_t x_stride_tok, int64_t x_stride_
 /* GGML_OP_CPY f32 -> f16/q8_0/q4_0 into a CONTIGUOUS typed tensor in the reference's own byte format
  * (ggml_compute_forward_dup_f32, /ref/ggml/src/ggml-cpu/ggml-cpu.c:3742): x f32 [n_rows][ne0], ne0 % 64 == 0. */
 int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, void * stream);
+/* the same store for n_cells KV rows ([n_cells][n_head_kv][head_dim] f32) that ALSO lands in a paged pool with identity placement
+ * (cell c = block c / block_size, offset c % block_size; K or V layout by is_v): dst gets the reference's bytes for cells
+ * [cell0, cell0 + n_cells) — dst points at the first of them — and the pool gets the same quantized bits, in one launch.  What the
+ * ggml-backend plugin runs for the KV-store CPY of a step once a cache tensor has its paged mirror. */
+int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_cells, int n_head_kv, int head_dim,
+                          int block_size, void * stream);
 
 /* KV store: replaces ggml_cpy(k_cur -> k_cache_view) / (v_cur -> v_cache_view) in build_attn
  * (/ref/src/llama-graph.cpp:1367-1398), CPU kernel ggml_compute_forward_dup_f32 + from_float

@@ -318,6 +318,22 @@ def pool_gather_rows(pool, rows, *, type, is_v, slot_block, slot_off, n_head_kv,
     return rows
 
 
+def convert_f32(x, dst, type: int, stream=None):
+    """GGML_OP_CPY f32 -> f16 / q8_0 / q4_0 rows in the reference's byte format (x [n_rows][ne0] f32, dst device bytes)"""
+    check(lib().pkv_convert_f32(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(dst)), type, C.c_int64(x.numel() // x.shape[-1]), C.c_int64(x.shape[-1]),
+                                C.c_void_p(_stream(stream))))
+    return dst
+
+
+def convert_f32_paged(x, dst, type: int, pool, *, is_v, cell0: int, n_head_kv: int, head_dim: int, block_size: int, stream=None):
+    """pkv_convert_f32_paged: x [n_cells][n_head_kv][head_dim] f32 -> dst (reference bytes of those cells) AND the pool rows of cells
+    cell0.. (identity placement), one launch"""
+    n_cells = x.numel() // (n_head_kv * head_dim)
+    check(lib().pkv_convert_f32_paged(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(dst)), type, C.c_void_p(_ptr(pool)), int(is_v), C.c_int64(cell0),
+                                      C.c_int64(n_cells), n_head_kv, head_dim, block_size, C.c_void_p(_stream(stream))))
+    return dst
+
+
 # ---- first slice of the rest of the decoder layer (SURVEY §8(f) row 1) ----------------------------------------------------------
 def rms_norm(x, eps: float, out=None, stream=None):
     """ggml_rms_norm over the last dim of a contiguous f32 tensor"""

@@ -293,6 +293,26 @@ bool supports_cpy(const ggml_tensor * op) {
 ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     const ggml_tensor * s = op->src[0];
     ggml_tensor * d = op->src[1];
+    // the KV store of a step into a cache tensor that already has its paged mirror: flat bytes and mirror rows in ONE launch (same
+    // quantized bits), nothing left to re-scatter at the next attention call
+    {
+        const ggml_tensor * root = d;
+        size_t off = 0;
+        while (root->view_src) { off += root->view_offs; root = root->view_src; }
+        if (root != d && root->buffer && root->buffer->iface.free_buffer == buf_free) {
+            auto * c = (buffer_ctx *) root->buffer->context;
+            auto it = c->mirrors.find(root->data);
+            if (it != c->mirrors.end() && it->second.pool && it->second.type == (int) d->type) {
+                const kv_mirror & m = it->second;
+                const size_t row_cell = ggml_row_size(d->type, m.D) * m.n_head_kv;
+                const int64_t per_cell = (int64_t) m.n_head_kv * m.D, n_el = ggml_nelements(s);
+                if (off % row_cell == 0 && n_el % per_cell == 0 && s->ne[0] % m.D == 0 && (int64_t) (off / row_cell) + n_el / per_cell <= m.n_cells) {
+                    if (pkv_convert_f32_paged((const float *) s->data, d->data, d->type, m.pool, m.is_v, (int64_t) (off / row_cell), n_el / per_cell, m.n_head_kv, m.D,
+                                              BLOCK, bc->stream) == PKV_OK) return GGML_STATUS_SUCCESS;
+                }
+            }
+        }
+    }
     const int rc = pkv_convert_f32((const float *) s->data, d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
     if (rc) { MI355_LOG("cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
     note_write_all(d);                                      // the KV store of the step: the next attention re-scatters just these cells

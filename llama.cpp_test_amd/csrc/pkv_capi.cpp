@@ -132,6 +132,13 @@ int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64
     PKV_REQUIRE(x && dst && n_rows >= 0 && ne0 > 0 && kv_type_ok(type), "pkv_convert_f32: bad arguments");
     return launch_convert_rows(x, dst, type, n_rows, ne0, (hipStream_t) stream);
 }
+int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_cells, int n_head_kv, int head_dim,
+                          int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && dst && pool && kv_type_ok(type) && cell0 >= 0 && n_cells >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 32 == 0,
+                "pkv_convert_f32_paged: bad arguments");
+    return launch_convert_rows_mirror(x, dst, type, pool, is_v, cell0, n_cells * n_head_kv, n_head_kv, head_dim, block_size, (hipStream_t) stream);
+}
 
 int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
                  const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,

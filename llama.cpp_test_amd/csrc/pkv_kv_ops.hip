@@ -347,6 +347,44 @@ __global__ void __launch_bounds__(64) convert_rows_kernel(const float * x, char 
     ref_write<T>(dst + row * (int64_t) row_size(T, ne0) + (int64_t) ch * row_size(T, CH), lane, quantize<T>(v, lane), CH);
 }
 
+// the same conversion for KV rows of head_dim D that also land in a paged pool (identity placement: cell c = block c / BS, offset
+// c % BS): flat[g] and the pool row of (cell0 + g / n_head_kv, head g % n_head_kv) receive the SAME quantized bits, so a flat cache
+// tensor and its paged mirror are written by one launch.  grid = number of head rows.
+template <int T, bool IS_V, int D>
+__global__ void __launch_bounds__(64) convert_rows_mirror_kernel(const float * x, char * dst, char * pool, int64_t cell0, int n_head_kv, int BS) {
+    const int64_t g = blockIdx.x;
+    const int lane = threadIdx.x;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (2 * lane < D) v = *reinterpret_cast<const float2 *>(x + g * D + 2 * lane);
+    const Q2 q = quantize<T>(v, lane);
+    ref_write<T>(dst + g * (int64_t) row_size(T, D), lane, q, D);
+    const int64_t cell = cell0 + g / n_head_kv;
+    const int h = (int) (g % n_head_kv);
+    char * tile = pool + ((size_t) (cell / BS) * n_head_kv + h) * tile_bytes(T, BS, D);
+    tile_write<T, IS_V>(tile, (int) (cell % BS), lane, q, BS, D);
+}
+template <int T>
+static int convert_mirror_t(const float * x, void * dst, void * pool, int is_v, int64_t cell0, int64_t n_head_rows, int n_head_kv, int D, int BS, hipStream_t st) {
+    const dim3 grid((unsigned) n_head_rows);
+#define PKV_CM(V, DD) hipLaunchKernelGGL((convert_rows_mirror_kernel<T, V, DD>), grid, dim3(64), 0, st, x, (char *) dst, (char *) pool, cell0, n_head_kv, BS)
+    if (D == 128) { if (is_v) PKV_CM(true, 128); else PKV_CM(false, 128); }
+    else if (D == 64) { if (is_v) PKV_CM(true, 64); else PKV_CM(false, 64); }
+    else { set_error("convert + mirror: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+#undef PKV_CM
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+int launch_convert_rows_mirror(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_head_rows, int n_head_kv, int D, int BS,
+                               hipStream_t st) {
+    if (n_head_rows == 0) return PKV_OK;
+    switch (type) {
+        case PKV_TYPE_F16:  return convert_mirror_t<PKV_TYPE_F16>(x, dst, pool, is_v, cell0, n_head_rows, n_head_kv, D, BS, st);
+        case PKV_TYPE_Q8_0: return convert_mirror_t<PKV_TYPE_Q8_0>(x, dst, pool, is_v, cell0, n_head_rows, n_head_kv, D, BS, st);
+        case PKV_TYPE_Q4_0: return convert_mirror_t<PKV_TYPE_Q4_0>(x, dst, pool, is_v, cell0, n_head_rows, n_head_kv, D, BS, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
 int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st) {
     if (n_rows == 0) return PKV_OK;
     const int CH = ne0 % 128 == 0 ? 128 : 64;

@@ -1,0 +1,38 @@
+"""-m gpu: pkv_convert_f32_paged (the KV-store CPY of the ggml-backend plugin once a cache tensor has its paged mirror) ==
+pkv_convert_f32 into the flat tensor followed by pkv_pool_scatter_rows of those rows into the pool, bit for bit, for every KV type,
+K and V layouts, head_dim 64 / 128 and cell ranges that start inside a block and cross a block boundary."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tname", ["f16", "q8_0", "q4_0"])
+@pytest.mark.parametrize("is_v", [False, True])
+@pytest.mark.parametrize("D,HK,cell0,n_cells", [(128, 8, 4096 - 1, 1), (64, 4, 100, 60), (128, 2, 0, 130)])
+def test_convert_paged_matches_convert_then_scatter(pkv, tname, is_v, D, HK, cell0, n_cells):
+    t = pkv.TYPE_BY_NAME[tname]
+    BS = 128
+    nb = (cell0 + n_cells + BS - 1) // BS
+    rng = np.random.default_rng(D + HK + cell0 + n_cells)
+    x = dev(rng.standard_normal((n_cells, HK, D)).astype(np.float32))
+    row_cell = pkv.row_size(t, D) * HK
+    pool_bytes = pkv.pool_bytes(t, nb, HK, BS, D)
+    # the reference sequence: convert into the flat tensor, scatter those rows into the pool
+    flat_a = torch.zeros(n_cells * row_cell, dtype=torch.uint8, device="cuda")
+    pool_a = torch.zeros(pool_bytes, dtype=torch.uint8, device="cuda")
+    pkv.convert_f32(x.view(n_cells * HK, D), flat_a, t)
+    cells = torch.arange(cell0, cell0 + n_cells, dtype=torch.int32, device="cuda")
+    pkv.pool_scatter_rows(pool_a, flat_a, type=t, is_v=is_v, slot_block=(cells // BS).to(torch.int32), slot_off=(cells % BS).to(torch.int32),
+                          n_head_kv=HK, head_dim=D, block_size=BS)
+    # one launch
+    flat_b = torch.zeros_like(flat_a)
+    pool_b = torch.zeros_like(pool_a)
+    pkv.convert_f32_paged(x, flat_b, t, pool_b, is_v=is_v, cell0=cell0, n_head_kv=HK, head_dim=D, block_size=BS)
+    torch.cuda.synchronize()
+    assert torch.equal(flat_a, flat_b)
+    assert torch.equal(pool_a, pool_b)
+    assert int(pool_b.to(torch.int64).sum()) != 0
