@@ -104,6 +104,12 @@ int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64
 int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_cells, int n_head_kv, int head_dim,
                           int block_size, void * stream);
 
+/* ... and with the RoPE of the K rows in front: x = un-rotated k_cur, strided [tok][head][head_dim] (strides in elements, 0 = packed),
+ * roped (optional, packed f32) = what GGML_OP_ROPE writes, dst / pool = what the CPY of it stores (K layout).  ROPE -> CPY of
+ * build_attn (/ref/src/llama-graph.cpp:1375-1397) as one launch. */
+int pkv_rope_convert_f32_paged(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, const pkv_rope_params * rope, float * roped, void * dst,
+                               int type, void * pool, int64_t cell0, int64_t n_tok, int n_head_kv, int head_dim, int block_size, void * stream);
+
 /* KV store: replaces ggml_cpy(k_cur -> k_cache_view) / (v_cur -> v_cache_view) in build_attn
  * (/ref/src/llama-graph.cpp:1367-1398), CPU kernel ggml_compute_forward_dup_f32 + from_float
  * (/ref/ggml/src/ggml-cpu/ggml-cpu.c:3742, ggml-cpu-quants.c:738).

@@ -334,6 +334,15 @@ def convert_f32_paged(x, dst, type: int, pool, *, is_v, cell0: int, n_head_kv: i
     return dst
 
 
+def rope_convert_f32_paged(x, pos, rope: RopeParams, dst, type: int, pool, *, cell0: int, block_size: int, roped=None, stream=None):
+    """pkv_rope_convert_f32_paged: RoPE of k_cur x [n_tok][n_head_kv][head_dim] (packed), then what convert_f32_paged stores (K layout)"""
+    n_tok, n_head_kv, D = x.shape
+    check(lib().pkv_rope_convert_f32_paged(C.c_void_p(_ptr(x)), C.c_int64(0), C.c_int64(0), C.c_void_p(_ptr(pos)), C.byref(rope), C.c_void_p(_ptr(roped)),
+                                           C.c_void_p(_ptr(dst)), type, C.c_void_p(_ptr(pool)), C.c_int64(cell0), C.c_int64(n_tok), n_head_kv, D, block_size,
+                                           C.c_void_p(_stream(stream))))
+    return dst
+
+
 # ---- first slice of the rest of the decoder layer (SURVEY §8(f) row 1) ----------------------------------------------------------
 def rms_norm(x, eps: float, out=None, stream=None):
     """ggml_rms_norm over the last dim of a contiguous f32 tensor"""

@@ -290,28 +290,33 @@ bool supports_cpy(const ggml_tensor * op) {
     return s && d && s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) &&
            ggml_nelements(s) == ggml_nelements(d) && s->ne[0] % 64 == 0;
 }
+// the paged mirror a KV-store CPY can write directly: dst is a view into a cache tensor of this buffer type whose mirror exists, the
+// copy covers whole cells [*cell0, *cell0 + *n_cells) of it
+const kv_mirror * store_mirror(const ggml_tensor * cpy, int64_t * cell0, int64_t * n_cells) {
+    const ggml_tensor * s = cpy->src[0], * d = cpy->src[1], * root = d;
+    size_t off = 0;
+    while (root->view_src) { off += root->view_offs; root = root->view_src; }
+    if (root == d || !root->buffer || root->buffer->iface.free_buffer != buf_free) return nullptr;
+    auto * c = (buffer_ctx *) root->buffer->context;
+    auto it = c->mirrors.find(root->data);
+    if (it == c->mirrors.end() || !it->second.pool || it->second.type != (int) d->type) return nullptr;
+    const kv_mirror & m = it->second;
+    const size_t row_cell = ggml_row_size(d->type, m.D) * m.n_head_kv;
+    const int64_t per_cell = (int64_t) m.n_head_kv * m.D, n_el = ggml_nelements(s);
+    if (off % row_cell != 0 || n_el % per_cell != 0 || s->ne[0] % m.D != 0 || (int64_t) (off / row_cell) + n_el / per_cell > m.n_cells) return nullptr;
+    *cell0 = (int64_t) (off / row_cell);
+    *n_cells = n_el / per_cell;
+    return &m;
+}
 ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     const ggml_tensor * s = op->src[0];
     ggml_tensor * d = op->src[1];
     // the KV store of a step into a cache tensor that already has its paged mirror: flat bytes and mirror rows in ONE launch (same
     // quantized bits), nothing left to re-scatter at the next attention call
-    {
-        const ggml_tensor * root = d;
-        size_t off = 0;
-        while (root->view_src) { off += root->view_offs; root = root->view_src; }
-        if (root != d && root->buffer && root->buffer->iface.free_buffer == buf_free) {
-            auto * c = (buffer_ctx *) root->buffer->context;
-            auto it = c->mirrors.find(root->data);
-            if (it != c->mirrors.end() && it->second.pool && it->second.type == (int) d->type) {
-                const kv_mirror & m = it->second;
-                const size_t row_cell = ggml_row_size(d->type, m.D) * m.n_head_kv;
-                const int64_t per_cell = (int64_t) m.n_head_kv * m.D, n_el = ggml_nelements(s);
-                if (off % row_cell == 0 && n_el % per_cell == 0 && s->ne[0] % m.D == 0 && (int64_t) (off / row_cell) + n_el / per_cell <= m.n_cells) {
-                    if (pkv_convert_f32_paged((const float *) s->data, d->data, d->type, m.pool, m.is_v, (int64_t) (off / row_cell), n_el / per_cell, m.n_head_kv, m.D,
-                                              BLOCK, bc->stream) == PKV_OK) return GGML_STATUS_SUCCESS;
-                }
-            }
-        }
+    int64_t cell0, n_cells;
+    if (const kv_mirror * m = store_mirror(op, &cell0, &n_cells)) {
+        if (pkv_convert_f32_paged((const float *) s->data, d->data, d->type, m->pool, m->is_v, cell0, n_cells, m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK)
+            return GGML_STATUS_SUCCESS;
     }
     const int rc = pkv_convert_f32((const float *) s->data, d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
     if (rc) { MI355_LOG("cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
@@ -472,6 +477,29 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 continue;
             }
         }
+        //   ROPE(k_cur) ... CPY(roped -> cache view)   (build_attn's KV store): the CPY is pulled forward into the ROPE launch — its
+        //   destination, cells of the cache nobody reads before the attention of this layer, cannot alias anything in between
+        if (n->op == GGML_OP_ROPE && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32) {
+            for (int k = i + 1; k < n_nodes && k <= i + 8; ++k) {
+                ggml_tensor * nk = ggml_graph_node(g, k);
+                if (nk->op != GGML_OP_CPY || nk->src[0] != n || done[k] || !supports_cpy(nk)) continue;
+                int64_t cell0, n_cells;
+                const kv_mirror * m = store_mirror(nk, &cell0, &n_cells);
+                pkv_rope_params rp;
+                rope_params(n, &rp);
+                const ggml_tensor * x = n->src[0];
+                if (m && !m->is_v && x->ne[0] == m->D && x->ne[1] == m->n_head_kv && x->ne[2] == n_cells && x->ne[3] == 1 && ggml_is_contiguous(n) &&
+                    ((rp.mode & 2) == 0 || rp.n_dims == m->D) &&
+                    pkv_rope_convert_f32_paged((const float *) x->data, (int64_t) (x->nb[2] / sizeof(float)), (int64_t) (x->nb[1] / sizeof(float)),
+                                               (const int32_t *) n->src[1]->data, &rp, (float *) n->data, nk->src[1]->data, nk->src[1]->type, m->pool, cell0, n_cells,
+                                               m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK) {
+                    done[k] = 1;
+                    st = GGML_STATUS_SUCCESS;
+                    goto next_node;
+                }
+                break;
+            }
+        }
         switch (n->op) {
             case GGML_OP_NONE: case GGML_OP_VIEW: case GGML_OP_RESHAPE: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
             case GGML_OP_FLASH_ATTN_EXT: st = run_flash_attn(bc, n); break;
@@ -482,6 +510,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             default: MI355_LOG("op %s reached graph_compute but is not supported\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
         }
         if (st != GGML_STATUS_SUCCESS) return st;
+    next_node:;
     }
     (void) hipStreamSynchronize(bc->stream);
     return GGML_STATUS_SUCCESS;

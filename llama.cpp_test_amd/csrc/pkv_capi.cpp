@@ -140,6 +140,17 @@ int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, in
     return launch_convert_rows_mirror(x, dst, type, pool, is_v, cell0, n_cells * n_head_kv, n_head_kv, head_dim, block_size, (hipStream_t) stream);
 }
 
+int pkv_rope_convert_f32_paged(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, const pkv_rope_params * rope, float * roped, void * dst,
+                               int type, void * pool, int64_t cell0, int64_t n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && pos && rope && dst && pool && kv_type_ok(type) && cell0 >= 0 && n_tok >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 32 == 0 &&
+                xs_tok >= 0 && xs_head >= 0, "pkv_rope_convert_f32_paged: bad arguments");
+    PKV_REQUIRE((rope->mode & 2) == 0 || rope->n_dims == head_dim, "pkv_rope_convert_f32_paged: NEOX pairs need n_dims == head_dim");
+    RopeDev r;
+    if (int rc = make_rope(rope, head_dim, &r)) return rc;
+    return launch_rope_convert_mirror(x, xs_tok, xs_head, pos, roped, dst, type, pool, cell0, n_tok, n_head_kv, head_dim, block_size, r, (hipStream_t) stream);
+}
+
 int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
                  const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
                  const pkv_rope_params * rope, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {

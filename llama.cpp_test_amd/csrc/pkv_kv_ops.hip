@@ -363,6 +363,45 @@ __global__ void __launch_bounds__(64) convert_rows_mirror_kernel(const float * x
     char * tile = pool + ((size_t) (cell / BS) * n_head_kv + h) * tile_bytes(T, BS, D);
     tile_write<T, IS_V>(tile, (int) (cell % BS), lane, q, BS, D);
 }
+// ... with the RoPE of the K rows in front (ROPE -> CPY of build_attn, /ref/src/llama-graph.cpp:1375-1397): x is the un-rotated k_cur
+// (strided [tok][head][D]), `roped` (optional) receives what GGML_OP_ROPE would have written, flat + pool what the CPY of it stores
+template <int T, int D>
+__global__ void __launch_bounds__(64) rope_convert_mirror_kernel(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, float * roped, char * dst,
+                                                                 char * pool, int64_t cell0, int n_head_kv, int BS, const RopeDev r) {
+    const int64_t g = blockIdx.x, t = g / n_head_kv;
+    const int h = (int) (g % n_head_kv), lane = threadIdx.x;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (2 * lane < D) v = *reinterpret_cast<const float2 *>(x + t * xs_tok + h * xs_head + 2 * lane);
+    v = rope_row<D>(v, lane, pos[t], r, 1.0f);
+    if (roped && 2 * lane < D) *reinterpret_cast<float2 *>(roped + g * D + 2 * lane) = v;
+    const Q2 q = quantize<T>(v, lane);
+    ref_write<T>(dst + g * (int64_t) row_size(T, D), lane, q, D);
+    const int64_t cell = cell0 + t;
+    char * tile = pool + ((size_t) (cell / BS) * n_head_kv + h) * tile_bytes(T, BS, D);
+    tile_write<T, false>(tile, (int) (cell % BS), lane, q, BS, D);
+}
+template <int T>
+static int rope_convert_mirror_t(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, float * roped, void * dst, void * pool, int64_t cell0,
+                                 int64_t n_tok, int n_head_kv, int D, int BS, const RopeDev & r, hipStream_t st) {
+    const dim3 grid((unsigned) (n_tok * n_head_kv));
+    if (D == 128)     hipLaunchKernelGGL((rope_convert_mirror_kernel<T, 128>), grid, dim3(64), 0, st, x, xs_tok, xs_head, pos, roped, (char *) dst, (char *) pool, cell0, n_head_kv, BS, r);
+    else if (D == 64) hipLaunchKernelGGL((rope_convert_mirror_kernel<T, 64>), grid, dim3(64), 0, st, x, xs_tok, xs_head, pos, roped, (char *) dst, (char *) pool, cell0, n_head_kv, BS, r);
+    else { set_error("rope + convert + mirror: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+int launch_rope_convert_mirror(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, float * roped, void * dst, int type, void * pool,
+                               int64_t cell0, int64_t n_tok, int n_head_kv, int D, int BS, const RopeDev & r, hipStream_t st) {
+    if (n_tok == 0) return PKV_OK;
+    if (xs_tok == 0) { xs_tok = (int64_t) n_head_kv * D; xs_head = D; }
+    switch (type) {
+        case PKV_TYPE_F16:  return rope_convert_mirror_t<PKV_TYPE_F16>(x, xs_tok, xs_head, pos, roped, dst, pool, cell0, n_tok, n_head_kv, D, BS, r, st);
+        case PKV_TYPE_Q8_0: return rope_convert_mirror_t<PKV_TYPE_Q8_0>(x, xs_tok, xs_head, pos, roped, dst, pool, cell0, n_tok, n_head_kv, D, BS, r, st);
+        case PKV_TYPE_Q4_0: return rope_convert_mirror_t<PKV_TYPE_Q4_0>(x, xs_tok, xs_head, pos, roped, dst, pool, cell0, n_tok, n_head_kv, D, BS, r, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
 template <int T>
 static int convert_mirror_t(const float * x, void * dst, void * pool, int is_v, int64_t cell0, int64_t n_head_rows, int n_head_kv, int D, int BS, hipStream_t st) {
     const dim3 grid((unsigned) n_head_rows);

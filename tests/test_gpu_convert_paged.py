@@ -36,3 +36,26 @@ def test_convert_paged_matches_convert_then_scatter(pkv, tname, is_v, D, HK, cel
     assert torch.equal(flat_a, flat_b)
     assert torch.equal(pool_a, pool_b)
     assert int(pool_b.to(torch.int64).sum()) != 0
+
+
+@pytest.mark.parametrize("tname", ["f16", "q8_0", "q4_0"])
+@pytest.mark.parametrize("D,HK,cell0,n_tok,mode,n_dims", [(128, 8, 4095, 1, 0, 128), (64, 4, 120, 20, 0, 64), (128, 2, 3, 5, 2, 128), (128, 2, 0, 3, 0, 64)])
+def test_rope_convert_paged_matches_rope_then_convert(pkv, tname, D, HK, cell0, n_tok, mode, n_dims):
+    """pkv_rope_convert_f32_paged == pkv_rope_f32 followed by pkv_convert_f32_paged, bit for bit (roped f32 rows, flat bytes, pool)"""
+    t = pkv.TYPE_BY_NAME[tname]
+    BS = 128
+    nb = (cell0 + n_tok + BS - 1) // BS
+    rng = np.random.default_rng(D + HK + cell0 + n_tok + mode)
+    x = dev(rng.standard_normal((n_tok, HK, D)).astype(np.float32))
+    pos = dev(np.arange(cell0, cell0 + n_tok, dtype=np.int32) * 3 + 1)
+    rp = pkv.rope_params(n_dims=n_dims, mode=mode)
+    row_cell = pkv.row_size(t, D) * HK
+    flat_a = torch.zeros(n_tok * row_cell, dtype=torch.uint8, device="cuda")
+    pool_a = torch.zeros(pkv.pool_bytes(t, nb, HK, BS, D), dtype=torch.uint8, device="cuda")
+    roped_a = pkv.rope_f32(x, pos, rp)
+    pkv.convert_f32_paged(roped_a, flat_a, t, pool_a, is_v=False, cell0=cell0, n_head_kv=HK, head_dim=D, block_size=BS)
+    flat_b, pool_b, roped_b = torch.zeros_like(flat_a), torch.zeros_like(pool_a), torch.zeros_like(roped_a)
+    pkv.rope_convert_f32_paged(x, pos, rp, flat_b, t, pool_b, cell0=cell0, block_size=BS, roped=roped_b)
+    torch.cuda.synchronize()
+    assert torch.equal(roped_a, roped_b)
+    assert torch.equal(flat_a, flat_b) and torch.equal(pool_a, pool_b)
