@@ -58,6 +58,29 @@ struct backend_ctx {
     hipStream_t stream = nullptr;
     void *      scratch = nullptr;
     size_t      scratch_size = 0;
+    // results of products that were pulled forward although the graph's own output address was still occupied (Kcur / Vcur share
+    // Qcur's address, see be_graph_compute): tensor -> where its values really are, for the ROPE / CPY that consume them
+    void *      side = nullptr;
+    size_t      side_size = 0;
+    std::unordered_map<const ggml_tensor *, const char *> moved;
+    const void * src_data(const ggml_tensor * t) const {
+        if (moved.empty()) return t->data;
+        size_t off = 0;
+        const ggml_tensor * root = t;
+        while (root->view_src) { off += root->view_offs; root = root->view_src; }
+        auto it = moved.find(root);
+        return it == moved.end() ? t->data : (const void *) (it->second + off);
+    }
+    void * side_buf(size_t bytes) {
+        if (bytes > side_size) {
+            (void) hipStreamSynchronize(stream);
+            if (side) (void) hipFree(side);
+            side = nullptr; side_size = 0;
+            if (hipMalloc(&side, bytes * 2) != hipSuccess) return nullptr;
+            side_size = bytes * 2;
+        }
+        return side;
+    }
     void * arena(size_t bytes) {  // grow-only device scratch for the per-op pools / tables / workspace
         if (bytes > scratch_size) {
             (void) hipStreamSynchronize(stream);
@@ -274,9 +297,9 @@ ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
     rope_params(op, &rp);
     const int64_t es = (int64_t) ggml_type_size(x->type);
     const int rc = x->type == GGML_TYPE_F32
-        ? pkv_rope_f32_strided((const float *) x->data, (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data,
+        ? pkv_rope_f32_strided((const float *) bc->src_data(x), (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data,
                                (float *) op->data, (int) x->ne[2], (int) x->ne[1], (int) x->ne[0], &rp, back ? 1 : 0, bc->stream)
-        : pkv_rope_f16_strided(x->data, (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data, op->data,
+        : pkv_rope_f16_strided(bc->src_data(x), (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data, op->data,
                                (int) x->ne[2], (int) x->ne[1], (int) x->ne[0], &rp, back ? 1 : 0, bc->stream);
     if (rc) { MI355_LOG("rope failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
     note_write_all(op);                                     // in-place K-shift on the cache (/ref/src/llama-context.cpp:447-496)
@@ -315,10 +338,10 @@ ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     // quantized bits), nothing left to re-scatter at the next attention call
     int64_t cell0, n_cells;
     if (const kv_mirror * m = store_mirror(op, &cell0, &n_cells)) {
-        if (pkv_convert_f32_paged((const float *) s->data, d->data, d->type, m->pool, m->is_v, cell0, n_cells, m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK)
+        if (pkv_convert_f32_paged((const float *) bc->src_data(s), d->data, d->type, m->pool, m->is_v, cell0, n_cells, m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK)
             return GGML_STATUS_SUCCESS;
     }
-    const int rc = pkv_convert_f32((const float *) s->data, d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
+    const int rc = pkv_convert_f32((const float *) bc->src_data(s), d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
     if (rc) { MI355_LOG("cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
     note_write_all(d);                                      // the KV store of the step: the next attention re-scatters just these cells
     return GGML_STATUS_SUCCESS;
@@ -373,11 +396,34 @@ const char * be_name(ggml_backend_t) { return "MI355"; }
 void be_free(ggml_backend_t b) {
     auto * c = (backend_ctx *) b->context;
     if (c->scratch) (void) hipFree(c->scratch);
+    if (c->side) (void) hipFree(c->side);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     delete b;
 }
 void be_sync(ggml_backend_t b) { (void) hipStreamSynchronize(((backend_ctx *) b->context)->stream); }
+// every reader of t in the graph is (through RESHAPE / VIEW / PERMUTE / TRANSPOSE) the src[0] of an f32 ROPE or of a CPY: the ops that
+// resolve their source through backend_ctx::src_data
+bool consumers_take_moved(ggml_cgraph * g, const ggml_tensor * t, int depth = 0) {
+    if (depth > 3 || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    bool any = false;
+    for (int j = 0; j < ggml_graph_n_nodes(g); ++j) {
+        const ggml_tensor * nj = ggml_graph_node(g, j);
+        for (int s_ = 0; s_ < GGML_MAX_SRC; ++s_) {
+            if (nj->src[s_] != t) continue;
+            any = true;
+            if (s_ != 0) return false;
+            if ((nj->op == GGML_OP_ROPE && nj->type == GGML_TYPE_F32) || nj->op == GGML_OP_CPY) continue;
+            if (nj->op == GGML_OP_RESHAPE || nj->op == GGML_OP_VIEW || nj->op == GGML_OP_PERMUTE || nj->op == GGML_OP_TRANSPOSE) {
+                if (!consumers_take_moved(g, nj, depth + 1)) return false;
+                continue;
+            }
+            return false;
+        }
+        if (nj->view_src == t && nj->src[0] != t) return false;
+    }
+    return any;
+}
 ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     auto * bc = (backend_ctx *) b->context;
     (void) hipDeviceSynchronize();  // set_tensor uses the null stream
@@ -393,6 +439,8 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         MI355_LOG("node %3d %-14s %-24s data %p nbytes %zu src0 %s src1 %s\n", i, ggml_op_name(t->op), t->name, t->data, ggml_nbytes(t),
                   t->src[0] ? t->src[0]->name : "-", t->src[1] ? t->src[1]->name : "-");
     }
+    const bool fuse = getenv("GGML_MI355_NO_FUSE") == nullptr;   // GGML_MI355_NO_FUSE=1: one launch per graph node, in graph order (read per graph: tests flip it)
+    bc->moved.clear();
     std::vector<char> done(n_nodes, 0);      // MUL_MAT nodes already run together with an earlier product on the same activations
     for (int i = 0; i < n_nodes; ++i) {
         ggml_tensor * n = ggml_graph_node(g, i);
@@ -401,8 +449,9 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         // q4_K products that read the SAME activation tensor (wq / wk / wv of a layer, gate / up of its FFN) run as one launch: the later
         // ones are pulled forward to the first, when their output does not alias anything the nodes in between read or write
         // (ggml-alloc hands freed ranges to later nodes, ggml-alloc.c:470-560)
-        if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_Q4_K && supports_mul_mat(n)) {
+        if (fuse && n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_Q4_K && supports_mul_mat(n)) {
             int grp[PKV_MUL_MAT_MAX], ngp = 1;
+            bool redirect[PKV_MUL_MAT_MAX] = {false};
             grp[0] = i;
             for (int k = i + 1; k < n_nodes && k <= i + 16 && ngp < PKV_MUL_MAT_MAX; ++k) {
                 ggml_tensor * nk = ggml_graph_node(g, k);
@@ -413,13 +462,22 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                     if (overlaps(nk, nq)) safe = false;
                     for (int s_ = 0; s_ < GGML_MAX_SRC && safe; ++s_) if (nq->src[s_] && overlaps(nk, nq->src[s_])) safe = false;
                 }
+                // Kcur / Vcur: ggml-alloc gives them Qcur's address (each is dead after its out-of-place ROPE / CPY).  They can still be
+                // computed now, into a side buffer, when everything that reads them is a ROPE or CPY of this backend (through view
+                // ops): those take their source through backend_ctx::src_data
+                if (!safe && consumers_take_moved(g, nk)) { redirect[ngp] = true; safe = true; }
                 if (safe) grp[ngp++] = k;
             }
             if (ngp > 1) {
                 const void * wv[PKV_MUL_MAT_MAX]; float * yv[PKV_MUL_MAT_MAX]; int64_t mv[PKV_MUL_MAT_MAX];
+                size_t side_bytes = 0;
+                for (int q = 0; q < ngp; ++q) if (redirect[q]) side_bytes += (ggml_nbytes(ggml_graph_node(g, grp[q])) + 255) / 256 * 256;
+                char * side = side_bytes ? (char *) bc->side_buf(side_bytes) : nullptr;
+                if (side_bytes && !side) return GGML_STATUS_ALLOC_FAILED;
                 for (int q = 0; q < ngp; ++q) {
                     const ggml_tensor * nq = ggml_graph_node(g, grp[q]);
                     wv[q] = nq->src[0]->data; yv[q] = (float *) nq->data; mv[q] = nq->src[0]->ne[1];
+                    if (redirect[q]) { yv[q] = (float *) side; bc->moved[nq] = side; side += (ggml_nbytes(nq) + 255) / 256 * 256; }
                     done[grp[q]] = 1;
                 }
                 if (pkv_mul_mat_multi(ngp, wv, PKV_TYPE_Q4_K, (const float *) n->src[1]->data, yv, mv, n->src[0]->ne[0], n->src[1]->ne[1], bc->stream) != PKV_OK) {
@@ -441,7 +499,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                                  ggml_nelements(sn), bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
             continue;
         }
-        if (n->op == GGML_OP_UNARY && supports_silu(n)) {
+        if (fuse && n->op == GGML_OP_UNARY && supports_silu(n)) {
             int j = -1;
             for (int k = i + 1; k < n_nodes && k <= i + 3; ++k) {
                 ggml_tensor * nk = ggml_graph_node(g, k);
@@ -455,7 +513,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             if (j >= 0) { silu_of[j] = i; continue; }
         }
         //   ADD(a, b) -> RMS_NORM -> MUL            (the residual add in front of a norm: ffn_inp / l_out; its sum is still written)
-        if (i + 2 < n_nodes && n->op == GGML_OP_ADD && supports_binary(n) && ggml_are_same_shape(n->src[0], n->src[1])) {
+        if (fuse && i + 2 < n_nodes && n->op == GGML_OP_ADD && supports_binary(n) && ggml_are_same_shape(n->src[0], n->src[1])) {
             ggml_tensor * n1 = ggml_graph_node(g, i + 1), * n2 = ggml_graph_node(g, i + 2);
             if (n1->op == GGML_OP_RMS_NORM && n1->src[0] == n && supports_rms_norm(n1) && n2->op == GGML_OP_MUL && n2->src[0] == n1 && supports_binary(n2) &&
                 ggml_nrows(n2->src[1]) == 1 && n1->data != n->data && n2->data != n->data) {   // the sum must survive: it is the next residual
@@ -466,7 +524,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 continue;
             }
         }
-        if (i + 1 < n_nodes) {
+        if (fuse && i + 1 < n_nodes) {
             ggml_tensor * nx = ggml_graph_node(g, i + 1);
             if (n->op == GGML_OP_RMS_NORM && nx->op == GGML_OP_MUL && nx->src[0] == n && supports_rms_norm(n) && supports_binary(nx) &&
                 ggml_nrows(nx->src[1]) == 1) {
@@ -479,7 +537,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         }
         //   ROPE(k_cur) ... CPY(roped -> cache view)   (build_attn's KV store): the CPY is pulled forward into the ROPE launch — its
         //   destination, cells of the cache nobody reads before the attention of this layer, cannot alias anything in between
-        if (n->op == GGML_OP_ROPE && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32) {
+        if (fuse && n->op == GGML_OP_ROPE && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32) {
             for (int k = i + 1; k < n_nodes && k <= i + 8; ++k) {
                 ggml_tensor * nk = ggml_graph_node(g, k);
                 if (nk->op != GGML_OP_CPY || nk->src[0] != n || done[k] || !supports_cpy(nk)) continue;
@@ -490,7 +548,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 const ggml_tensor * x = n->src[0];
                 if (m && !m->is_v && x->ne[0] == m->D && x->ne[1] == m->n_head_kv && x->ne[2] == n_cells && x->ne[3] == 1 && ggml_is_contiguous(n) &&
                     ((rp.mode & 2) == 0 || rp.n_dims == m->D) &&
-                    pkv_rope_convert_f32_paged((const float *) x->data, (int64_t) (x->nb[2] / sizeof(float)), (int64_t) (x->nb[1] / sizeof(float)),
+                    pkv_rope_convert_f32_paged((const float *) bc->src_data(x), (int64_t) (x->nb[2] / sizeof(float)), (int64_t) (x->nb[1] / sizeof(float)),
                                                (const int32_t *) n->src[1]->data, &rp, (float *) n->data, nk->src[1]->data, nk->src[1]->type, m->pool, cell0, n_cells,
                                                m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK) {
                     done[k] = 1;

@@ -25,12 +25,16 @@ MODELS = {
     # head_dim 128, gqa 4, Q8_0 weights, RoPE base 5e5 + rope_freqs table (Llama-3.1-like)
     "llama3": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=78,
                    rope_freqs=True, wtype=8),
+    # the same geometry with Q4_K weights: the products of a layer go through the plugin's grouping rules (q / k / v in one launch with
+    # K and V in a side buffer, gate / up in one launch) at prefill widths and at decode
+    "llama3_q4k": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=79,
+                       rope_freqs=True, wtype=12),
 }
 
 
 @pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
 @pytest.mark.parametrize("tk", [1, 8])
-@pytest.mark.parametrize("model", ["tiny", "llama3"])
+@pytest.mark.parametrize("model", ["tiny", "llama3", "llama3_q4k"])
 def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
     from llama_cpp_test_amd import gguf_synth as G
     MODEL = MODELS[model]
@@ -64,12 +68,34 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
     cpu = run(0)
     R.load_backend(PLUGIN)
     gpu = run(99)
+    # the plugin's launch-merging rules (ADD->RMS_NORM->MUL, SILU..MUL, ROPE..CPY, products on shared activations pulled together, K / V
+    # products redirected to a side buffer) change WHICH launches run, never the arithmetic: one launch per graph node gives the same bits
+    os.environ["GGML_MI355_NO_FUSE"] = "1"
+    try:
+        plain = run(99)
+    finally:
+        del os.environ["GGML_MI355_NO_FUSE"]
     R.set_gpu_layers(0)
+    for (lg, logit_g), (lp, logit_p) in zip(gpu, plain):
+        assert np.array_equal(logit_g, logit_p)
+        assert all(np.array_equal(a, b) for a, b in zip(lg, lp))
     for ci, ((lc, logit_c), (lg, logit_g)) in enumerate(zip(cpu, gpu)):
         for il, (a, b) in enumerate(zip(lc, lg)):
             assert np.isfinite(b).all()
-            assert nmse(b, a) <= 5e-4, (ci, il)
+            if os.environ.get("PKV_PRINT_NMSE"):
+                print("call", ci, "layer", il, "kqv_out nmse %.3e" % nmse(b, a), flush=True)
+                continue
+            # Q4_K weights: the CPU backend quantizes activations to q8_K (blocks of 256), the device to int8 per 32.  The synthetic
+            # q4_K blocks (uniform random 6-bit scales and mins) give weights several times wider than N(0, 1/fan_in): peaky softmaxes that
+            # amplify that rounding difference — measured 2e-4 (layer 0) .. 3.4e-3 (layer 1) with f16 KV, up to 1.6e-2 with q8_0 KV, with
+            # or without the merged launches (bit-identical, checked above).  For this model the comparison with the CPU run is a sanity
+            # bound; the product itself is held to 1e-4 / exact int8 arithmetic in tests/test_gpu_layer_ops.py and to the harness bar.
+            assert nmse(b, a) <= (5e-2 if MODEL.get("wtype") == 12 else 5e-4), (ci, il)
         # Q8_0 weights: the CPU backend rounds the activations to q8_0 before every product (0.4 % of the block maximum per
         # element, 14 products deep), the device keeps them in f32: the runs differ by the CPU path's own quantization noise
-        bar = 2e-3 if MODEL.get("wtype") == 8 else (1e-4 if tk == 1 else 5e-4)
+        # (Q4_K weights: q8_K activations of 256 on the CPU, int8 per 32 on the device — same kind of difference)
+        bar = 2e-2 if MODEL.get("wtype") == 12 else (2e-3 if MODEL.get("wtype") == 8 else (1e-4 if tk == 1 else 5e-4))
+        if os.environ.get("PKV_PRINT_NMSE"):
+            print("call", ci, "logits nmse %.3e" % nmse(logit_g, logit_c), flush=True)
+            continue
         assert nmse(logit_g, logit_c) <= bar, (ci, bar)
