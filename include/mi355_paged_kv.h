@@ -110,6 +110,19 @@ int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, in
 int pkv_rope_convert_f32_paged(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, const pkv_rope_params * rope, float * roped, void * dst,
                                int type, void * pool, int64_t cell0, int64_t n_tok, int n_head_kv, int head_dim, int block_size, void * stream);
 
+/* ... and all three per-token ops that sit between the q / k / v products and the attention of a llama layer as ONE launch: RoPE(Q)
+ * out of place (q_out packed [tok][n_head][head_dim]), RoPE(K) + store, store(V) — K and V as in pkv_rope_convert_f32_paged /
+ * pkv_convert_f32_paged (dst = reference bytes of cells cell0.., pool = paged rows, identity placement).  Strides in elements,
+ * 0 = packed; v is packed [tok][n_head_kv][head_dim].  Q and K share pos and the rope parameters (build_attn's two ggml_rope_ext). */
+typedef struct pkv_qkv_store_args {
+    const float * q; int64_t q_stride_tok, q_stride_head; float * q_out;
+    const float * k; int64_t k_stride_tok, k_stride_head; void * k_dst; void * k_pool; int64_t k_cell0;
+    const float * v; void * v_dst; void * v_pool; int64_t v_cell0;
+    const int32_t * pos; const pkv_rope_params * rope;
+    int32_t type_k, type_v, n_tok, n_head, n_head_kv, head_dim, block_size;
+} pkv_qkv_store_args;
+int pkv_qkv_store_f32_paged(const pkv_qkv_store_args * a, void * stream);
+
 /* KV store: replaces ggml_cpy(k_cur -> k_cache_view) / (v_cur -> v_cache_view) in build_attn
  * (/ref/src/llama-graph.cpp:1367-1398), CPU kernel ggml_compute_forward_dup_f32 + from_float
  * (/ref/ggml/src/ggml-cpu/ggml-cpu.c:3742, ggml-cpu-quants.c:738).

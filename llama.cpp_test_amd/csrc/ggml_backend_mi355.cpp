@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -533,6 +534,52 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                                          ggml_nrows(n), n->ne[0], eps, bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
                 ++i;
                 continue;
+            }
+        }
+        //   ROPE(q) + [ROPE(k) -> CPY(k -> cache)] + CPY(v -> cache): everything between the q / k / v products and the attention of
+        //   a layer in ONE launch, when k and v are already computed (the products were pulled together above), ROPE(k) feeds
+        //   nothing but its CPY, and both cache tensors have their paged mirrors
+        if (fuse && n->op == GGML_OP_ROPE && n->type == GGML_TYPE_F32 && n->src[0]->type == GGML_TYPE_F32 && n->src[0]->ne[3] == 1 && ggml_is_contiguous(n)) {
+            auto ready = [&](const ggml_tensor * t) {      // t's producer has run: an earlier node, or one already pulled forward
+                while (t->view_src) t = t->view_src;
+                for (int q = std::max(0, i - 12); q < n_nodes && q <= i + 12; ++q) if (ggml_graph_node(g, q) == t) return q < i || done[q] != 0;
+                return false;
+            };
+            int ir = -1, ick = -1, icv = -1;
+            for (int k = i + 1; k < n_nodes && k <= i + 12; ++k) {
+                ggml_tensor * nk = ggml_graph_node(g, k);
+                if (done[k]) continue;
+                if (ir < 0 && nk->op == GGML_OP_ROPE && nk->type == GGML_TYPE_F32 && nk->src[0]->type == GGML_TYPE_F32 && nk->src[1] == n->src[1] &&
+                    nk->src[2] == n->src[2] && memcmp(nk->op_params, n->op_params, sizeof(n->op_params)) == 0) ir = k;
+                else if (ir >= 0 && ick < 0 && nk->op == GGML_OP_CPY && nk->src[0] == ggml_graph_node(g, ir) && supports_cpy(nk)) ick = k;
+                else if (icv < 0 && nk->op == GGML_OP_CPY && supports_cpy(nk) && (ir < 0 || nk->src[0] != ggml_graph_node(g, ir))) icv = k;
+            }
+            if (ir >= 0 && ick >= 0 && icv >= 0) {
+                ggml_tensor * r2 = ggml_graph_node(g, ir), * ck = ggml_graph_node(g, ick), * cv = ggml_graph_node(g, icv);
+                int users = 0;
+                for (int q = 0; q < n_nodes; ++q) for (int s_ = 0; s_ < GGML_MAX_SRC; ++s_) users += ggml_graph_node(g, q)->src[s_] == r2;
+                int64_t ck0, ckn, cv0, cvn;
+                const kv_mirror * mk = store_mirror(ck, &ck0, &ckn), * mv = store_mirror(cv, &cv0, &cvn);
+                const ggml_tensor * xq = n->src[0], * xk = r2->src[0], * xv = cv->src[0];
+                pkv_rope_params rp;
+                rope_params(n, &rp);
+                if (users == 1 && !(r2->flags & GGML_TENSOR_FLAG_OUTPUT) && mk && mv && !mk->is_v && mv->is_v && mk->D == mv->D && mk->n_head_kv == mv->n_head_kv &&
+                    xq->ne[0] == mk->D && xk->ne[0] == mk->D && xk->ne[1] == mk->n_head_kv && xk->ne[3] == 1 && xk->ne[2] == xq->ne[2] && ckn == xq->ne[2] &&
+                    cvn == xq->ne[2] && ((rp.mode & 2) == 0 || rp.n_dims == mk->D) && ready(xk) && ready(xv)) {
+                    pkv_qkv_store_args a = {};
+                    a.q = (const float *) bc->src_data(xq); a.q_stride_tok = (int64_t) (xq->nb[2] / sizeof(float)); a.q_stride_head = (int64_t) (xq->nb[1] / sizeof(float));
+                    a.q_out = (float *) n->data;
+                    a.k = (const float *) bc->src_data(xk); a.k_stride_tok = (int64_t) (xk->nb[2] / sizeof(float)); a.k_stride_head = (int64_t) (xk->nb[1] / sizeof(float));
+                    a.k_dst = ck->src[1]->data; a.k_pool = mk->pool; a.k_cell0 = ck0;
+                    a.v = (const float *) bc->src_data(xv); a.v_dst = cv->src[1]->data; a.v_pool = mv->pool; a.v_cell0 = cv0;
+                    a.pos = (const int32_t *) n->src[1]->data; a.rope = &rp;
+                    a.type_k = ck->src[1]->type; a.type_v = cv->src[1]->type; a.n_tok = (int32_t) xq->ne[2]; a.n_head = (int32_t) xq->ne[1];
+                    a.n_head_kv = mk->n_head_kv; a.head_dim = mk->D; a.block_size = BLOCK;
+                    if (pkv_qkv_store_f32_paged(&a, bc->stream) == PKV_OK) {
+                        done[ir] = done[ick] = done[icv] = 1;
+                        goto next_node;
+                    }
+                }
             }
         }
         //   ROPE(k_cur) ... CPY(roped -> cache view)   (build_attn's KV store): the CPY is pulled forward into the ROPE launch — its

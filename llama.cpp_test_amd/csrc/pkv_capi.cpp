@@ -151,6 +151,17 @@ int pkv_rope_convert_f32_paged(const float * x, int64_t xs_tok, int64_t xs_head,
     return launch_rope_convert_mirror(x, xs_tok, xs_head, pos, roped, dst, type, pool, cell0, n_tok, n_head_kv, head_dim, block_size, r, (hipStream_t) stream);
 }
 
+int pkv_qkv_store_f32_paged(const pkv_qkv_store_args * a, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(a && a->q && a->q_out && a->k && a->k_dst && a->k_pool && a->v && a->v_dst && a->v_pool && a->pos && a->rope, "pkv_qkv_store_f32_paged: null pointer");
+    PKV_REQUIRE(kv_type_ok(a->type_k) && kv_type_ok(a->type_v) && a->n_tok >= 0 && a->n_head > 0 && a->n_head_kv > 0 && a->k_cell0 >= 0 && a->v_cell0 >= 0 &&
+                a->block_size > 0 && a->block_size % 32 == 0, "pkv_qkv_store_f32_paged: bad arguments");
+    PKV_REQUIRE((a->rope->mode & 2) == 0 || a->rope->n_dims == a->head_dim, "pkv_qkv_store_f32_paged: NEOX pairs need n_dims == head_dim");
+    RopeDev r;
+    if (int rc = make_rope(a->rope, a->head_dim, &r)) return rc;
+    return launch_qkv_store_mirror(a, r, (hipStream_t) stream);
+}
+
 int pkv_kv_store(const float * k_cur, const float * v_cur, void * k_pool, void * v_pool, int type_k, int type_v,
                  const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
                  const pkv_rope_params * rope, int n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {

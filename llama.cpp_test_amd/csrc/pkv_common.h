@@ -84,6 +84,7 @@ int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64
 int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                          hipStream_t st);
 int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);
+int launch_qkv_store_mirror(const pkv_qkv_store_args * p, const RopeDev & r, hipStream_t st);
 int launch_rope_convert_mirror(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, float * roped, void * dst, int type, void * pool,
                                int64_t cell0, int64_t n_tok, int n_head_kv, int D, int BS, const RopeDev & r, hipStream_t st);
 int launch_convert_rows_mirror(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_head_rows, int n_head_kv, int D, int BS,

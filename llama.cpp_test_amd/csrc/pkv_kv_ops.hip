@@ -380,6 +380,80 @@ __global__ void __launch_bounds__(64) rope_convert_mirror_kernel(const float * x
     char * tile = pool + ((size_t) (cell / BS) * n_head_kv + h) * tile_bytes(T, BS, D);
     tile_write<T, false>(tile, (int) (cell % BS), lane, q, BS, D);
 }
+// the three per-token ops between the q / k / v products and the attention of a llama layer in ONE launch: RoPE(Q) out of place,
+// RoPE(K) + store (flat + pool), store V (flat + pool).  grid (max(n_head_q, n_head_kv), n_tok, 3): z = 0 K, 1 V, 2 Q.
+struct QkvStoreArgs {
+    const float * q; int64_t q_s_tok, q_s_head; float * q_out; int n_head_q;
+    const float * k; int64_t k_s_tok, k_s_head; char * k_dst; char * k_pool; int64_t k_cell0;
+    const float * v; char * v_dst; char * v_pool; int64_t v_cell0;
+    const int32_t * pos; RopeDev rope; int n_head_kv, BS;
+};
+template <int KT, int VT, int D>
+__global__ void __launch_bounds__(64) qkv_store_mirror_kernel(const QkvStoreArgs a) {
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const int64_t t = blockIdx.y;
+    if (blockIdx.z == 2) {
+        if (h >= a.n_head_q) return;
+        float2 x = make_float2(0.0f, 0.0f);
+        if (2 * lane < D) x = *reinterpret_cast<const float2 *>(a.q + t * a.q_s_tok + h * a.q_s_head + 2 * lane);
+        x = rope_row<D>(x, lane, a.pos[t], a.rope, 1.0f);
+        if (2 * lane < D) *reinterpret_cast<float2 *>(a.q_out + (t * a.n_head_q + h) * D + 2 * lane) = x;
+        return;
+    }
+    if (h >= a.n_head_kv) return;
+    const int64_t g = t * a.n_head_kv + h;
+    if (blockIdx.z == 0) {
+        float2 x = make_float2(0.0f, 0.0f);
+        if (2 * lane < D) x = *reinterpret_cast<const float2 *>(a.k + t * a.k_s_tok + h * a.k_s_head + 2 * lane);
+        x = rope_row<D>(x, lane, a.pos[t], a.rope, 1.0f);
+        const Q2 q = quantize<KT>(x, lane);
+        ref_write<KT>(a.k_dst + g * (int64_t) row_size(KT, D), lane, q, D);
+        const int64_t cell = a.k_cell0 + t;
+        tile_write<KT, false>(a.k_pool + ((size_t) (cell / a.BS) * a.n_head_kv + h) * tile_bytes(KT, a.BS, D), (int) (cell % a.BS), lane, q, a.BS, D);
+    } else {
+        float2 x = make_float2(0.0f, 0.0f);
+        if (2 * lane < D) x = *reinterpret_cast<const float2 *>(a.v + g * D + 2 * lane);
+        const Q2 q = quantize<VT>(x, lane);
+        ref_write<VT>(a.v_dst + g * (int64_t) row_size(VT, D), lane, q, D);
+        const int64_t cell = a.v_cell0 + t;
+        tile_write<VT, true>(a.v_pool + ((size_t) (cell / a.BS) * a.n_head_kv + h) * tile_bytes(VT, a.BS, D), (int) (cell % a.BS), lane, q, a.BS, D);
+    }
+}
+template <int KT, int VT>
+static int qkv_store_d(const QkvStoreArgs & a, int n_tok, int D, hipStream_t st) {
+    const dim3 grid(a.n_head_q > a.n_head_kv ? a.n_head_q : a.n_head_kv, n_tok, 3);
+    if (D == 128)     hipLaunchKernelGGL((qkv_store_mirror_kernel<KT, VT, 128>), grid, dim3(64), 0, st, a);
+    else if (D == 64) hipLaunchKernelGGL((qkv_store_mirror_kernel<KT, VT, 64>), grid, dim3(64), 0, st, a);
+    else { set_error("qkv store: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+template <int KT>
+static int qkv_store_v(const QkvStoreArgs & a, int type_v, int n_tok, int D, hipStream_t st) {
+    switch (type_v) {
+        case PKV_TYPE_F16:  return qkv_store_d<KT, PKV_TYPE_F16>(a, n_tok, D, st);
+        case PKV_TYPE_Q8_0: return qkv_store_d<KT, PKV_TYPE_Q8_0>(a, n_tok, D, st);
+        case PKV_TYPE_Q4_0: return qkv_store_d<KT, PKV_TYPE_Q4_0>(a, n_tok, D, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+int launch_qkv_store_mirror(const pkv_qkv_store_args * p, const RopeDev & r, hipStream_t st) {
+    if (p->n_tok == 0) return PKV_OK;
+    QkvStoreArgs a;
+    a.q = p->q; a.q_s_tok = p->q_stride_tok ? p->q_stride_tok : (int64_t) p->n_head * p->head_dim; a.q_s_head = p->q_stride_tok ? p->q_stride_head : p->head_dim;
+    a.q_out = p->q_out; a.n_head_q = p->n_head;
+    a.k = p->k; a.k_s_tok = p->k_stride_tok ? p->k_stride_tok : (int64_t) p->n_head_kv * p->head_dim; a.k_s_head = p->k_stride_tok ? p->k_stride_head : p->head_dim;
+    a.k_dst = (char *) p->k_dst; a.k_pool = (char *) p->k_pool; a.k_cell0 = p->k_cell0;
+    a.v = p->v; a.v_dst = (char *) p->v_dst; a.v_pool = (char *) p->v_pool; a.v_cell0 = p->v_cell0;
+    a.pos = p->pos; a.rope = r; a.n_head_kv = p->n_head_kv; a.BS = p->block_size;
+    switch (p->type_k) {
+        case PKV_TYPE_F16:  return qkv_store_v<PKV_TYPE_F16>(a, p->type_v, p->n_tok, p->head_dim, st);
+        case PKV_TYPE_Q8_0: return qkv_store_v<PKV_TYPE_Q8_0>(a, p->type_v, p->n_tok, p->head_dim, st);
+        case PKV_TYPE_Q4_0: return qkv_store_v<PKV_TYPE_Q4_0>(a, p->type_v, p->n_tok, p->head_dim, st);
+    }
+    return PKV_ERR_UNSUPPORTED;
+}
+
 template <int T>
 static int rope_convert_mirror_t(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, float * roped, void * dst, void * pool, int64_t cell0,
                                  int64_t n_tok, int n_head_kv, int D, int BS, const RopeDev & r, hipStream_t st) {
