@@ -54,6 +54,16 @@ class StepArgs(C.Structure):
                 ("rope_cache", C.c_void_p)]
 
 
+class QkvStoreArgs(C.Structure):
+    """pkv_qkv_store_args"""
+    _fields_ = [("q", C.c_void_p), ("q_stride_tok", C.c_int64), ("q_stride_head", C.c_int64), ("q_out", C.c_void_p),
+                ("k", C.c_void_p), ("k_stride_tok", C.c_int64), ("k_stride_head", C.c_int64), ("k_dst", C.c_void_p), ("k_pool", C.c_void_p), ("k_cell0", C.c_int64),
+                ("v", C.c_void_p), ("v_dst", C.c_void_p), ("v_pool", C.c_void_p), ("v_cell0", C.c_int64),
+                ("pos", C.c_void_p), ("rope", C.POINTER(RopeParams)),
+                ("type_k", C.c_int32), ("type_v", C.c_int32), ("n_tok", C.c_int32), ("n_head", C.c_int32), ("n_head_kv", C.c_int32), ("head_dim", C.c_int32),
+                ("block_size", C.c_int32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("q_stride_tok", C.c_int64), ("q_stride_head", C.c_int64), ("out", C.c_void_p),
                 ("k_pool", C.c_void_p), ("v_pool", C.c_void_p), ("block_table", C.c_void_p), ("seq_lens", C.c_void_p),
@@ -341,6 +351,16 @@ def rope_convert_f32_paged(x, pos, rope: RopeParams, dst, type: int, pool, *, ce
                                            C.c_void_p(_ptr(dst)), type, C.c_void_p(_ptr(pool)), C.c_int64(cell0), C.c_int64(n_tok), n_head_kv, D, block_size,
                                            C.c_void_p(_stream(stream))))
     return dst
+
+
+def qkv_store_f32_paged(q, k, v, pos, rope: RopeParams, *, q_out, k_dst, k_pool, v_dst, v_pool, type_k: int, type_v: int, cell0: int, block_size: int,
+                        stream=None):
+    """pkv_qkv_store_f32_paged: q [n_tok][n_head][D], k / v [n_tok][n_head_kv][D] packed f32; RoPE(q) -> q_out, RoPE(k) + store, store(v)"""
+    n_tok, n_head, D = q.shape
+    a = QkvStoreArgs(_ptr(q), 0, 0, _ptr(q_out), _ptr(k), 0, 0, _ptr(k_dst), _ptr(k_pool), cell0, _ptr(v), _ptr(v_dst), _ptr(v_pool), cell0,
+                     _ptr(pos), C.pointer(rope), type_k, type_v, n_tok, n_head, k.shape[1], D, block_size)
+    check(lib().pkv_qkv_store_f32_paged(C.byref(a), C.c_void_p(_stream(stream))))
+    return q_out
 
 
 # ---- first slice of the rest of the decoder layer (SURVEY §8(f) row 1) ----------------------------------------------------------

@@ -59,3 +59,33 @@ def test_rope_convert_paged_matches_rope_then_convert(pkv, tname, D, HK, cell0, 
     torch.cuda.synchronize()
     assert torch.equal(roped_a, roped_b)
     assert torch.equal(flat_a, flat_b) and torch.equal(pool_a, pool_b)
+
+
+@pytest.mark.parametrize("tk,tv", [("f16", "f16"), ("q8_0", "q4_0"), ("q4_0", "q8_0")])
+@pytest.mark.parametrize("D,H,HK,cell0,n_tok,mode", [(128, 32, 8, 4095, 1, 0), (64, 4, 4, 120, 20, 0), (128, 8, 2, 3, 5, 2)])
+def test_qkv_store_paged_matches_the_three_launches(pkv, tk, tv, D, H, HK, cell0, n_tok, mode):
+    """pkv_qkv_store_f32_paged == pkv_rope_f32(q), pkv_rope_convert_f32_paged(k), pkv_convert_f32_paged(v), bit for bit"""
+    TK, TV = pkv.TYPE_BY_NAME[tk], pkv.TYPE_BY_NAME[tv]
+    BS = 128
+    nb = (cell0 + n_tok + BS - 1) // BS
+    rng = np.random.default_rng(D + H + cell0 + n_tok + mode)
+    q = dev(rng.standard_normal((n_tok, H, D)).astype(np.float32))
+    k = dev(rng.standard_normal((n_tok, HK, D)).astype(np.float32))
+    v = dev(rng.standard_normal((n_tok, HK, D)).astype(np.float32))
+    pos = dev(np.arange(cell0, cell0 + n_tok, dtype=np.int32) * 2 + 5)
+    rp = pkv.rope_params(n_dims=D, mode=mode)
+
+    def bufs():
+        return (torch.zeros(n_tok * pkv.row_size(TK, D) * HK, dtype=torch.uint8, device="cuda"), torch.zeros(pkv.pool_bytes(TK, nb, HK, BS, D), dtype=torch.uint8, device="cuda"),
+                torch.zeros(n_tok * pkv.row_size(TV, D) * HK, dtype=torch.uint8, device="cuda"), torch.zeros(pkv.pool_bytes(TV, nb, HK, BS, D), dtype=torch.uint8, device="cuda"))
+    kf_a, kp_a, vf_a, vp_a = bufs()
+    q_a = pkv.rope_f32(q, pos, rp)
+    pkv.rope_convert_f32_paged(k, pos, rp, kf_a, TK, kp_a, cell0=cell0, block_size=BS)
+    pkv.convert_f32_paged(v, vf_a, TV, vp_a, is_v=True, cell0=cell0, n_head_kv=HK, head_dim=D, block_size=BS)
+    kf_b, kp_b, vf_b, vp_b = bufs()
+    q_b = torch.zeros_like(q_a)
+    pkv.qkv_store_f32_paged(q, k, v, pos, rp, q_out=q_b, k_dst=kf_b, k_pool=kp_b, v_dst=vf_b, v_pool=vp_b, type_k=TK, type_v=TV, cell0=cell0, block_size=BS)
+    torch.cuda.synchronize()
+    assert torch.equal(q_a, q_b)
+    assert torch.equal(kf_a, kf_b) and torch.equal(kp_a, kp_b)
+    assert torch.equal(vf_a, vf_b) and torch.equal(vp_a, vp_b)
