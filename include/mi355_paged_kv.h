@@ -337,8 +337,8 @@ int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int
 int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream);
 int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream);
 /* n (1..PKV_MUL_MAT_MAX) products that share x, K, n_cols and the weight type — wq / wk / wv of a layer, gate / up of its FFN
- * (/ref/src/llama-model.cpp build_attn inputs, build_ffn LLM_FFN_PAR) — results identical to n pkv_mul_mat calls; q4_K weights
- * run as ONE launch (at decode a product is mostly its launch-and-latency floor) */
+ * (/ref/src/llama-model.cpp build_attn inputs, build_ffn LLM_FFN_PAR) — results identical to n pkv_mul_mat calls; q4_K and q8_0
+ * weights run as ONE launch (at decode a product is mostly its launch-and-latency floor) */
 #define PKV_MUL_MAT_MAX 4
 int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                       void * stream);

@@ -450,13 +450,13 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         // q4_K products that read the SAME activation tensor (wq / wk / wv of a layer, gate / up of its FFN) run as one launch: the later
         // ones are pulled forward to the first, when their output does not alias anything the nodes in between read or write
         // (ggml-alloc hands freed ranges to later nodes, ggml-alloc.c:470-560)
-        if (fuse && n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_Q4_K && supports_mul_mat(n)) {
+        if (fuse && n->op == GGML_OP_MUL_MAT && (n->src[0]->type == GGML_TYPE_Q4_K || n->src[0]->type == GGML_TYPE_Q8_0) && supports_mul_mat(n)) {
             int grp[PKV_MUL_MAT_MAX], ngp = 1;
             bool redirect[PKV_MUL_MAT_MAX] = {false};
             grp[0] = i;
             for (int k = i + 1; k < n_nodes && k <= i + 16 && ngp < PKV_MUL_MAT_MAX; ++k) {
                 ggml_tensor * nk = ggml_graph_node(g, k);
-                if (nk->op != GGML_OP_MUL_MAT || nk->src[1] != n->src[1] || !nk->src[0] || nk->src[0]->type != GGML_TYPE_Q4_K || !supports_mul_mat(nk) || done[k]) continue;
+                if (nk->op != GGML_OP_MUL_MAT || nk->src[1] != n->src[1] || !nk->src[0] || nk->src[0]->type != n->src[0]->type || !supports_mul_mat(nk) || done[k]) continue;
                 bool safe = true;
                 for (int q = i; q < k && safe; ++q) {
                     const ggml_tensor * nq = ggml_graph_node(g, q);
@@ -481,7 +481,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                     if (redirect[q]) { yv[q] = (float *) side; bc->moved[nq] = side; side += (ggml_nbytes(nq) + 255) / 256 * 256; }
                     done[grp[q]] = 1;
                 }
-                if (pkv_mul_mat_multi(ngp, wv, PKV_TYPE_Q4_K, (const float *) n->src[1]->data, yv, mv, n->src[0]->ne[0], n->src[1]->ne[1], bc->stream) != PKV_OK) {
+                if (pkv_mul_mat_multi(ngp, wv, (int) n->src[0]->type, (const float *) n->src[1]->data, yv, mv, n->src[0]->ne[0], n->src[1]->ne[1], bc->stream) != PKV_OK) {
                     MI355_LOG("mul_mat_multi failed: %s\n", pkv_last_error());
                     return GGML_STATUS_FAILED;
                 }

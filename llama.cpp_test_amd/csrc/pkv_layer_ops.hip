@@ -228,23 +228,12 @@ __device__ __forceinline__ void q4k_rows(const char * w, const float * x, float 
         }
         }
 
-// up to PKV_MUL_MAT_MAX products that share the activation column(s) and K (the q / k / v projections of a layer, gate / up of its
-// FFN) in ONE launch: at decode each product is a ~5 us launch-and-latency floor plus its bytes, so three launches cost three floors
-struct MulMatMulti { const char * w[PKV_MUL_MAT_MAX]; float * y[PKV_MUL_MAT_MAX]; int64_t M[PKV_MUL_MAT_MAX]; int wg_end[PKV_MUL_MAT_MAX]; int n; };
-__global__ void __launch_bounds__(256) mul_mat_q4k_multi_kernel(MulMatMulti a, const float * x, int64_t K, int64_t n_cols, size_t w_row_bytes) {
-    int i = 0;
-    while (i + 1 < a.n && (int) blockIdx.x >= a.wg_end[i]) ++i;
-    q4k_rows(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, (int64_t) blockIdx.x - (i ? a.wg_end[i - 1] : 0));
-}
-
-template <int WT>
-__global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols,
-                                                      size_t w_row_bytes) {
+// block_q8_0 rows x f32 activation columns; `wg` = index of the group of 4 rows (one per wave) this workgroup owns
+__device__ __forceinline__ void q8_rows(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, size_t w_row_bytes, int64_t wg) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t m = (int64_t) blockIdx.x * 4 + wv;
+    const int64_t m = wg * 4 + wv;
     const char * wr = w + (size_t) min(m, M - 1) * w_row_bytes;            // surplus waves redo the last row and do not store
-    if constexpr (WT == PKV_TYPE_Q4_K) { q4k_rows(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
-    if constexpr (WT == PKV_TYPE_Q8_0) {
+
         // same scheme for block_q8_0 rows: a lane owns one 32-element block of a 2048-element chunk, the activation chunk is staged
         // once per workgroup in LDS, transposed (row stride 65)
         constexpr int KC = 2048;
@@ -274,8 +263,28 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
             const float v = wave_sum_f(acc);
             if (lane == 0 && m < M) y[(size_t) c * M + m] = v;
         }
-        return;
-    }
+        }
+
+// up to PKV_MUL_MAT_MAX products that share the activation column(s) and K (the q / k / v projections of a layer, gate / up of its
+// FFN) in ONE launch: at decode each product is a ~5 us launch-and-latency floor plus its bytes, so three launches cost three floors
+struct MulMatMulti { const char * w[PKV_MUL_MAT_MAX]; float * y[PKV_MUL_MAT_MAX]; int64_t M[PKV_MUL_MAT_MAX]; int wg_end[PKV_MUL_MAT_MAX]; int n; };
+template <int WT>
+__global__ void __launch_bounds__(256) mul_mat_multi_kernel(MulMatMulti a, const float * x, int64_t K, int64_t n_cols, size_t w_row_bytes) {
+    int i = 0;
+    while (i + 1 < a.n && (int) blockIdx.x >= a.wg_end[i]) ++i;
+    const int64_t wg = (int64_t) blockIdx.x - (i ? a.wg_end[i - 1] : 0);
+    if constexpr (WT == PKV_TYPE_Q4_K) q4k_rows(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, wg);
+    else                               q8_rows(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, wg);
+}
+
+template <int WT>
+__global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols,
+                                                      size_t w_row_bytes) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t m = (int64_t) blockIdx.x * 4 + wv;
+    const char * wr = w + (size_t) min(m, M - 1) * w_row_bytes;            // surplus waves redo the last row and do not store
+    if constexpr (WT == PKV_TYPE_Q4_K) { q4k_rows(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
+    if constexpr (WT == PKV_TYPE_Q8_0) { q8_rows(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
     for (int64_t c0 = 0; c0 < n_cols; c0 += MM_CT) {
         const int nc = (int) min((int64_t) MM_CT, n_cols - c0);
         float acc[MM_CT];
@@ -398,7 +407,7 @@ int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64
 
 int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                          hipStream_t st) {
-    if (type_w != PKV_TYPE_Q4_K) {                                 // one launch each for the other weight types
+    if (type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q8_0) {       // one launch each for the other weight types
         for (int i = 0; i < n; ++i) if (int rc = launch_mul_mat(w[i], type_w, x, y[i], M[i], K, n_cols, st)) return rc;
         return PKV_OK;
     }
@@ -408,11 +417,13 @@ int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float 
     for (int i = 0; i < n; ++i) {
         if (M[i] == 0) continue;
         a.w[a.n] = (const char *) w[i]; a.y[a.n] = y[i]; a.M[a.n] = M[i];
-        tot += (int) ((M[i] + 4 * Q4K_ROWS - 1) / (4 * Q4K_ROWS));
+        const int rows_wg = type_w == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
+        tot += (int) ((M[i] + rows_wg - 1) / rows_wg);
         a.wg_end[a.n++] = tot;
     }
     if (a.n == 0) return PKV_OK;
-    hipLaunchKernelGGL(mul_mat_q4k_multi_kernel, dim3((unsigned) tot), dim3(256), 0, st, a, x, K, n_cols, row_size(PKV_TYPE_Q4_K, K));
+    if (type_w == PKV_TYPE_Q4_K) hipLaunchKernelGGL(mul_mat_multi_kernel<PKV_TYPE_Q4_K>, dim3((unsigned) tot), dim3(256), 0, st, a, x, K, n_cols, row_size(PKV_TYPE_Q4_K, K));
+    else                         hipLaunchKernelGGL(mul_mat_multi_kernel<PKV_TYPE_Q8_0>, dim3((unsigned) tot), dim3(256), 0, st, a, x, K, n_cols, row_size(PKV_TYPE_Q8_0, K));
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
