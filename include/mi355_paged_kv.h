@@ -215,6 +215,16 @@ typedef struct pkv_step_args {
  * of rotation pair i at pos[t] (identity past n_dims/2).  cache: device f32 [n_tok][head_dim/2][2], 16-byte aligned. */
 int pkv_rope_cache(const int32_t * pos, int n_tok, int head_dim, const pkv_rope_params * rope, float * cache, void * stream);
 int pkv_attn_decode_step(const pkv_attn_args * args, const pkv_step_args * step, void * stream);
+/* DIAGNOSTIC build of the decode-step kernel with in-kernel phase stamps (f16 KV, head_dim 128, gqa 4 / 8; the two-launch step):
+ * same arguments as pkv_attn_decode_step; `stamps` = device u64 [n_workgroups][8 waves][PKV_DECODE_NSTAMP], workgroup index
+ * (seq * n_head_kv + kv_head) * n_splits + split.  Slots: 0 = s_memrealtime (100 MHz) at entry, 1..10 = s_memtime (shader clock) at
+ * entry / scalars loaded / loads issued / Q operand ready / K landed / logits + softmax done / V landed / PV done /
+ * barrier passed / partial stores issued, 11 = s_memrealtime after the stores were acknowledged.  mode 1 = with a forced
+ * `s_waitcnt vmcnt` in front of the "K landed" / "V landed" stamps (clean phase shares); mode 2 = stamps only, the waits stay where the
+ * compiler put them (how far the product build overlaps the KV stream with QK^T / PV).  Its run time is not a
+ * measurement (the stamps fence overlaps the product kernel has); read shares.  Never used by the product path. */
+#define PKV_DECODE_NSTAMP 12
+int pkv_attn_decode_stamps(const pkv_attn_args * args, const pkv_step_args * step, uint64_t * stamps, int mode, void * stream);
 /* measurement aid: raw hipEvent_t handles for pkv_attn_args.ev_start / ev_stop */
 void * pkv_event_create(void);
 void   pkv_event_destroy(void * ev);

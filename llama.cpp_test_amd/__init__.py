@@ -22,7 +22,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355_paged_kv.so")
+LIB_PATH = os.environ.get("PKV_LIB_PATH") or os.path.join(_HERE, "libmi355_paged_kv.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355_paged_kv.h")
 
 # enum pkv_type (= enum ggml_type values)
@@ -206,7 +206,7 @@ def attn_prefill_workspace_bytes(n_tok: int, n_head: int, head_dim: int) -> int:
 
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
-          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None):
+          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None, stamps=None):
     import torch
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
@@ -224,7 +224,10 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
     if step is not None:
         k_cur, v_cur, pos, rope, rope_cache = step
         st = StepArgs(_ptr(k_cur), _ptr(v_cur), _ptr(pos), C.pointer(rope) if rope is not None else None, _ptr(rope_cache))
-        check(fn(C.byref(a), C.byref(st), C.c_void_p(_stream(stream))))
+        if stamps is not None:
+            check(fn(C.byref(a), C.byref(st), C.c_void_p(_ptr(stamps[0])), int(stamps[1]), C.c_void_p(_stream(stream))))
+        else:
+            check(fn(C.byref(a), C.byref(st), C.c_void_p(_stream(stream))))
     else:
         check(fn(C.byref(a), C.c_void_p(_stream(stream))))
     return out
@@ -263,6 +266,21 @@ def attn_decode_step(q, k_cur, v_cur, pos, rope, k_pool, v_pool, block_table, se
     shared by all layers of the step (None: built per call)."""
     return _attn(lib().pkv_attn_decode_step, q, k_pool, v_pool, block_table, seq_lens,
                  step=(k_cur, v_cur, pos, rope, rope_cache), **kw)
+
+
+DECODE_NSTAMP = 12
+
+
+def attn_decode_stamps(q, k_cur, v_cur, pos, rope, k_pool, v_pool, block_table, seq_lens, *, rope_cache=None, mode=1, stamps_out=None, **kw):
+    """DIAGNOSTIC (pkv_attn_decode_stamps): the decode step through the stamped instantiation of the kernel; returns
+    (out-less) the u64 stamp tensor [n_seq * n_head_kv * n_splits][8][DECODE_NSTAMP].  Not a product path."""
+    import torch
+    n_seq = block_table.shape[0]
+    n_splits = (kw["max_seq_len"] + 127) // 128
+    st = stamps_out if stamps_out is not None else torch.zeros((n_seq * kw["n_head_kv"] * n_splits, 8, DECODE_NSTAMP), dtype=torch.int64, device=q.device)
+    _attn(lib().pkv_attn_decode_stamps, q, k_pool, v_pool, block_table, seq_lens,
+          step=(k_cur, v_cur, pos, rope, rope_cache), stamps=(st, mode), flags=kw.pop("flags", 0) | 1, **kw)
+    return st
 
 
 class KernelTimer:

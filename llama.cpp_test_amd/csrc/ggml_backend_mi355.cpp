@@ -434,6 +434,12 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         const char * a0 = (const char *) a->data, * t0 = (const char *) t->data;
         return a0 && t0 && a0 < t0 + ggml_nbytes(t) && t0 < a0 + ggml_nbytes(a);
     };
+    // a fused launch writes `out` rows while other workgroups may still be reading rows of `in`: fine when the two do not overlap, or
+    // alias exactly (row r is written by the workgroup that has already read row r); a shifted overlap — ggml-alloc placing a result
+    // over a freed, merged range (ggml-alloc.c:470-560) — is a race at more than one row
+    auto alias_ok = [&](const ggml_tensor * out, const ggml_tensor * in) {
+        return !overlaps(out, in) || (out->data == in->data && ggml_nbytes(out) == ggml_nbytes(in));
+    };
     static const bool trace = getenv("GGML_MI355_TRACE") != nullptr;   // node list of every graph, for working on the fusion rules
     if (trace) for (int i = 0; i < n_nodes; ++i) {
         const ggml_tensor * t = ggml_graph_node(g, i);
@@ -517,7 +523,10 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         if (fuse && i + 2 < n_nodes && n->op == GGML_OP_ADD && supports_binary(n) && ggml_are_same_shape(n->src[0], n->src[1])) {
             ggml_tensor * n1 = ggml_graph_node(g, i + 1), * n2 = ggml_graph_node(g, i + 2);
             if (n1->op == GGML_OP_RMS_NORM && n1->src[0] == n && supports_rms_norm(n1) && n2->op == GGML_OP_MUL && n2->src[0] == n1 && supports_binary(n2) &&
-                ggml_nrows(n2->src[1]) == 1 && n1->data != n->data && n2->data != n->data) {   // the sum must survive: it is the next residual
+                ggml_nrows(n2->src[1]) == 1 && n1->data != n->data && n2->data != n->data &&   // the sum must survive: it is the next residual
+                !overlaps(n1, n) && !overlaps(n2, n) &&
+                alias_ok(n, n->src[0]) && alias_ok(n, n->src[1]) && alias_ok(n1, n->src[0]) && alias_ok(n1, n->src[1]) &&
+                alias_ok(n2, n->src[0]) && alias_ok(n2, n->src[1])) {
                 float eps; memcpy(&eps, n1->op_params, sizeof(float));
                 if (pkv_add_rms_norm_mul_f32((const float *) n->src[0]->data, (const float *) n->src[1]->data, (float *) n->data, (const float *) n2->src[1]->data,
                                              (float *) n1->data, (float *) n2->data, ggml_nrows(n), n->ne[0], eps, bc->stream) != PKV_OK) return GGML_STATUS_FAILED;
@@ -528,7 +537,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         if (fuse && i + 1 < n_nodes) {
             ggml_tensor * nx = ggml_graph_node(g, i + 1);
             if (n->op == GGML_OP_RMS_NORM && nx->op == GGML_OP_MUL && nx->src[0] == n && supports_rms_norm(n) && supports_binary(nx) &&
-                ggml_nrows(nx->src[1]) == 1) {
+                ggml_nrows(nx->src[1]) == 1 && alias_ok(n, n->src[0]) && alias_ok(nx, n->src[0])) {
                 float eps; memcpy(&eps, n->op_params, sizeof(float));
                 if (pkv_rms_norm_mul_f32((const float *) n->src[0]->data, (const float *) nx->src[1]->data, (float *) n->data, (float *) nx->data,
                                          ggml_nrows(n), n->ne[0], eps, bc->stream) != PKV_OK) return GGML_STATUS_FAILED;

@@ -87,6 +87,35 @@ struct DecodeArgs {
     const float4 *  rope_cache;  // [n_seq][D/2] (cos, sin): pkv_rope_cache rows of the new tokens, NULL = no RoPE
     int             has_rope;
     RopeDev         rope;
+    unsigned long long * stamps; // diagnostic build only (STAMP): [workgroup][wave][PKV_DECODE_NSTAMP] s_memtime / s_memrealtime values
+};
+
+// ---- in-kernel phase stamps (cdna_hip_programming.md §7 "In-kernel stamps"): a SEPARATE instantiation of the kernel, reached only
+// through pkv_attn_decode_stamps(); the product instantiations contain no stamp.  Stamp values leave through DecodeArgs::stamps only.
+constexpr int NSTAMP = PKV_DECODE_NSTAMP;
+template <int STAMP> struct Stamps {   // 0 = product (no code), 1 = stamps + forced vmcnt waits (phase shares), 2 = stamps only (the product's own overlap)
+    unsigned long long t[STAMP ? NSTAMP : 1];
+    __device__ __forceinline__ void at(int i) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long v;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
+            t[i] = v;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __device__ __forceinline__ void real(int i) {   // 100 MHz wall clock: aligns workgroups with each other
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long v;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
+            t[i] = v;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    template <int N> __device__ __forceinline__ void wait_vm() {   // all but the N youngest vector-memory operations have completed
+        if constexpr (STAMP == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    }
 };
 
 // Q operand of QK^T.  It is converted ONCE per workgroup into LDS (f16 for f16 K — GGML_FP32_TO_FP16 of the reference's
@@ -98,48 +127,6 @@ template <int D, int G> struct QShared<PKV_TYPE_F16, D, G> { _Float16 h[G][D]; }
 template <int KT, int D, int G> struct QSharedQ { signed char qs[G][D]; float d[G][D / PKV_QK]; int qsum[G][D / PKV_QK]; };
 template <int D, int G> struct QShared<PKV_TYPE_Q8_0, D, G> : QSharedQ<PKV_TYPE_Q8_0, D, G> {};
 template <int D, int G> struct QShared<PKV_TYPE_Q4_0, D, G> : QSharedQ<PKV_TYPE_Q4_0, D, G> {};
-
-template <int D, int G, int NT> struct QRaw { float x[(G * D + NT - 1) / NT]; };
-
-// the global load of Q is issued BEFORE the KV stream (vmcnt retires in order: a Q load queued behind sixteen tile loads
-// would only return after all of them), its conversion and the LDS hand-off then run while the KV loads are in flight
-template <int D, int G, int NT>
-__device__ __forceinline__ void q_load(QRaw<D, G, NT> & r, const float * q, int64_t stride_head, int tid) {
-#pragma unroll
-    for (int i = 0; i < (G * D + NT - 1) / NT; ++i) {
-        const int e = (G * D) % NT == 0 ? i * NT + tid : min(i * NT + tid, G * D - 1);   // unconditional, in-bounds load
-        r.x[i] = q[(e / D) * stride_head + e % D];
-    }
-}
-template <int KT, int D, int G, int NT>
-__device__ __forceinline__ void q_to_lds(QShared<KT, D, G> & sq, const QRaw<D, G, NT> & r, int tid) {
-    static_assert(D % 32 == 0 && NT % 32 == 0, "a 32-element block must map onto 32 consecutive lanes");
-#pragma unroll
-    for (int i = 0; i < (G * D + NT - 1) / NT; ++i) {
-        const int e = i * NT + tid;
-        const bool live = e < G * D;
-        const int g = live ? e / D : 0, d = live ? e % D : 0;
-        const float x = r.x[i];
-        if constexpr (KT == PKV_TYPE_F16) {
-            if (live) sq.h[g][d] = (_Float16) x;
-        } else {
-            float amax = fabsf(x);
-            amax = fmaxf(amax, dpp_mov<0xB1>(amax)); amax = fmaxf(amax, dpp_mov<0x4E>(amax));
-            amax = fmaxf(amax, dpp_mov<0x141>(amax)); amax = fmaxf(amax, dpp_mov<0x140>(amax));
-            amax = fmaxf(amax, __shfl_xor(amax, 16));                         // 32 lanes = one 32-element block
-            const float dd = amax / 127.0f;
-            const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
-            const int   v  = (int) __builtin_rintf(x * id);
-            int sum = v;
-            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-            sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
-            if (live) {
-                sq.qs[g][d] = (signed char) v;
-                if ((d & 31) == 0) { sq.d[g][d / PKV_QK] = (float) (_Float16) dd; sq.qsum[g][d / PKV_QK] = sum; }
-            }
-        }
-    }
-}
 
 // per-lane fragment: f16 path = 8 halfs per head; quantized path = E int8 per head + f16-rounded block scale (+ block sum)
 template <int KT, int D, int G> struct QFrag;
@@ -327,8 +314,65 @@ struct Geo {
     static constexpr int K_NL = TPW / K_RPL, V_NL = TPW / V_RPL;
 };
 
-template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP>
+// ---- cross-row exchanges without LDS: gfx950's v_permlane16_swap / v_permlane32_swap (one VALU instruction each; the
+// ds_bpermute they replace is an LDS round trip with its own wait) ------------------------------------------------------
+__device__ __forceinline__ float vmaxf(float a, float b) {   // plain v_max_f32: fmaxf() of a bit-cast value costs two canonicalising v_max more
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// all-reduce over lane ^ 16 (SHIFT 16) or lane ^ 32 (SHIFT 32): swap(x, x) leaves the two partners' values in the two results
+template <int SHIFT, bool IS_MAX> __device__ __forceinline__ float xreduce(float x) {
+    const unsigned u = __float_as_uint(x);
+    float p, q;
+    if constexpr (SHIFT == 16) { auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); p = __uint_as_float(r[0]); q = __uint_as_float(r[1]); }
+    else                       { auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); p = __uint_as_float(r[0]); q = __uint_as_float(r[1]); }
+    return IS_MAX ? vmaxf(p, q) : p + q;
+}
+// a (lanes 0-31: a_lo + a_hi) | b (lanes 32-63: b_lo + b_hi): two xor-32 sums for one swap and one add
+__device__ __forceinline__ float pair_sum32(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// all-reduce over the lanes that hold the same query head: lane bits [log2(64/TPW), 6)
+template <int TPW_, bool IS_MAX>
+__device__ __forceinline__ float head_reduce2(float x) {
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+    if constexpr (TPW_ >= 64) x = op(x, dpp_mov<0xB1>(x));
+    if constexpr (TPW_ >= 32) x = op(x, dpp_mov<0x4E>(x));
+    x = op(x, dpp_mov<0x124>(x));  // row_ror:4
+    x = op(x, dpp_mov<0x128>(x));  // row_ror:8   -> lanes i, i+4, i+8, i+12 of the row
+    x = xreduce<16, IS_MAX>(x);
+    x = xreduce<32, IS_MAX>(x);
+    return x;
+}
+
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int off) {
+    const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// ======================================================================================================================
+// One workgroup = one (sequence, kv head, 128-token split); wave w owns tokens [16 w, 16 w + 16) of it.  Schedule of a wave
+// (r02; in-kernel stamps: profiles/r02_decode_stamps_*.txt — the r01 kernel spent 3.7 of its 6.2 us AFTER its loads were
+// issued, on ~1000 executed instructions per wave, while a CU accepts only ~24 KiB of loads in flight):
+//   1. scalar: table entry, sequence length.  K and V tiles are addressed through buffer descriptors whose num_records ends
+//      at the sequence's last token: rows past the end read as zero in hardware (no clamps, no 64-bit address math; a
+//      wave's 16 K rows / 8 V token pairs are 4 KiB of consecutive bytes: ONE voffset + immediates).
+//   2. "row jobs" spread over the waves (wave j: query row j -> RoPE -> QK^T operand format -> LDS; wave G / G+1: the new
+//      token's K / V row in the fused step), the wave's K loads go out FIRST, the job's arithmetic runs under them.
+//   3. ONE early workgroup barrier (Q operand visible), then QK^T consumes K chunk i as it lands and issues V chunk i in its
+//      place: the wave never sits in front of a full memory queue with arithmetic left to do.
+//   4. DPP reduce-scatter -> one logit per lane; softmax per wave (row_ror + permlane swaps); P -> the wave's LDS strip;
+//      PV = dot2 stream; the two half-wave sums by permlane32_swap pairs.
+//   5. second barrier, cross-wave merge (one output element per thread), one (m, l, O) partial per workgroup.
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0>
 __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(const DecodeArgs a) {
+    Stamps<STAMP> ts;
+    ts.real(0);
+    ts.at(1);
     using GE = Geo<KT, VT, D>;
     using KT_ = KTr<KT, D>;
     constexpr int K_LPR = GE::K_LPR, K_RPL = GE::K_RPL, K_NL = GE::K_NL;
@@ -336,100 +380,105 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     constexpr int TPW = GE::TPW, NW = GE::NW, NT = 64 * NW;
     constexpr int NV = K_NL * G, NS = ilog2(K_LPR) < ilog2(NV) ? ilog2(K_LPR) : ilog2(NV), NVF = NV >> NS;
     constexpr bool P16 = VT == PKV_TYPE_F16;                   // P travels as half2 token pairs for the dot2 PV
+    constexpr int K_ROWB = KT == PKV_TYPE_F16 ? D * 2 : (KT == PKV_TYPE_Q8_0 ? D : D / 2);   // quant bytes per token row of a K tile
+    constexpr int NB = D / PKV_QK;
 
     __shared__ __attribute__((aligned(16))) float sP[NW][TPW * G / (P16 ? 2 : 1)];  // per-wave probabilities
     __shared__ __attribute__((aligned(16))) float sO[NW][G][D];                     // per-wave partial outputs
-    __shared__ float sML[NW][G][2];                                                 // per-wave (max, sum)
+    __shared__ __attribute__((aligned(16))) float sML[NW][G][2];                    // per-wave (max, sum)
+    __shared__ __attribute__((aligned(16))) QShared<KT, D, G> sQ;                   // QK^T operand (row jobs)
+    __shared__ KCur<KT, D> sKc;                                                     // the new token's rows (fused step)
+    __shared__ VCur<D>     sVc;
 
     const int split = blockIdx.x, hk = blockIdx.y, s = blockIdx.z;
     const int base  = split * WG_TOK;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     // the two scalar loads every KV address depends on are independent of each other: issue both, then branch
     // (the table entry of a split past the end of the sequence is in bounds — grid.x <= max_blocks — and unused)
     const int lb = split >> a.bs_shift, boff = (split & ((1 << a.bs_shift) - 1)) * WG_TOK;
     const int phys    = a.block_table[(size_t) s * a.max_blocks + lb];
     const int seq_len = a.seq_lens[s];
+
+    // ---- row jobs, loads: they need kernel arguments only, so they go out while the table entry is still on its way, and —
+    //      barrier 0 below — before ANY wave of the workgroup has put a K load into the CU's memory queue: a 512-byte row that
+    //      queues behind 28 KiB of other waves' K chunks comes back a microsecond late, and the whole workgroup waits for the
+    //      Q operand (stamps: profiles/r02_decode_stamps_*.txt).  Every load is unconditional and in bounds — a load behind a
+    //      branch makes hipcc drain the whole queue at the join.
+    constexpr int NJ = G + (PREP ? 2 : 0), NJW = (NJ + NW - 1) / NW;
+    float2 jx[NJW];
+    float4 jcs = make_float4(1.0f, 0.0f, 1.0f, 0.0f);           // this lane's (cos, sin) entries of the new token's row
+#pragma unroll
+    for (int k = 0; k < NJW; ++k) {
+        const int job = min(wv + k * NW, NJ - 1);
+        const float * src = a.q + (size_t) s * a.q_stride_tok + (size_t) (hk * G + min(job, G - 1)) * a.q_stride_head;
+        if constexpr (PREP) { if (job >= G) src = (job == G ? a.k_cur : a.v_cur) + ((size_t) s * a.n_head_kv + hk) * D; }
+        jx[k] = *reinterpret_cast<const float2 *>(src + min(2 * lane, D - 2));
+    }
+    if constexpr (PREP) {   // without RoPE the row is not used: any readable 16-byte-aligned address will do (q is)
+        const float4 * cs = a.has_rope ? reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(a.rope_cache) + (size_t) s * (D / 2) + rope_cache_base<D>(lane, a.rope))
+                                       : reinterpret_cast<const float4 *>(a.q);
+        jcs = *cs;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // program order = issue order: the rows are OLDER than the K stream (their wait must not drain it)
     // everything the KV addresses need is requested before the branch (hipcc otherwise sinks the table load and the
     // remaining kernel-argument loads below it, one scalar round trip each)
     asm volatile("" ::"s"(phys), "s"(seq_len), "s"(a.k_pool), "s"(a.v_pool), "s"(a.q));
+    ts.at(2);                     // kernel arguments, table entry and sequence length are in SGPRs; row loads issued
     if (base >= seq_len) return;  // workgroup-uniform
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const char * ktile = a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(KT, a.block_size, D);
-    const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(VT, a.block_size, D);
-    const int n_valid = min(WG_TOK, seq_len - base);  // >= 1
-
-    // PREP: the row jobs of this workgroup (see "fused decode step"); wave w takes jobs w, w + NW, ...
-    constexpr int NJ = G + 2, NJW = (NJ + NW - 1) / NW;
-    const int  wv      = __builtin_amdgcn_readfirstlane(wave);
-    const bool is_last = PREP && base + n_valid == seq_len;     // this workgroup's last valid row is the new token
-    QRaw<D, G, NT> qraw;
-    float2 jx[NJW];
-    float4 jcs = make_float4(1.0f, 0.0f, 1.0f, 0.0f);           // this lane's (cos, sin) entries of the new token's row
-    if constexpr (PREP) {
-#pragma unroll
-        for (int k = 0; k < NJW; ++k) {                         // unconditional, in-bounds loads (clamped job / element)
-            const int job = min(wv + k * NW, NJ - 1);
-            const float * src = job < G ? a.q + (size_t) s * a.q_stride_tok + (size_t) (hk * G + job) * a.q_stride_head
-                                        : (job == G ? a.k_cur : a.v_cur) + ((size_t) s * a.n_head_kv + hk) * D;
-            jx[k] = *reinterpret_cast<const float2 *>(src + min(2 * lane, D - 2));
-        }
-        if (a.has_rope)
-            jcs = *reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(a.rope_cache) + (size_t) s * (D / 2) + rope_cache_base<D>(lane, a.rope));
-    } else {
-        q_load<D, G, NT>(qraw, a.q + (size_t) s * a.q_stride_tok + (size_t) hk * G * a.q_stride_head, a.q_stride_head, tid);
-    }
+    __builtin_amdgcn_s_barrier(); // barrier 0 (no memory to order: a bare s_barrier): every wave's row loads are in the queue
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- every K and V load of the lane is issued up front, unconditionally: rows past the end of the sequence are
-    //      clamped to the last valid row (in bounds, finite) and removed later by the mask / p = 0 ------------------
+    const char * ktile = a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(KT, a.block_size, D);
+    const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(VT, a.block_size, D);
+    const int  n_valid = min(WG_TOK, seq_len - base);           // >= 1
+    const bool active  = wv * TPW < n_valid;                    // wave-uniform: a wave past the end only runs its row job
+    const bool is_last = PREP && base + n_valid == seq_len;     // this workgroup's last valid row is the new token
+    const bool owner   = is_last && wv == (n_valid - 1) / TPW;  // ... and this wave's 16 tokens contain it
+
+    // buffer descriptors of the workgroup's 128-token range: records end at the last valid token / token group
+    const int n_grp = (n_valid + V_TL - 1) / V_TL;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ktile) + (size_t) boff * K_ROWB, 0, n_valid * K_ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vtile) + (size_t) (boff / V_TL) * D * 4, 0, n_grp * D * 4, 0x00020000);
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_ks, rs_vs;
+    if constexpr (KT != PKV_TYPE_F16)
+        rs_ks = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ktile) + tile_quant_bytes(KT, a.block_size, D) + (size_t) boff * NB * 2, 0, n_valid * NB * 2, 0x00020000);
+    if constexpr (VT != PKV_TYPE_F16)
+        rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vtile) + tile_quant_bytes(VT, a.block_size, D) + (size_t) (boff / V_TL) * NB * V_TL * 2, 0,
+                                                  n_grp * NB * V_TL * 2, 0x00020000);
+
+    // ---- the wave's K rows: 16 tokens = K_NL consecutive 1 KiB chunks ---------------------------------------------------
     const int kr = lane / K_LPR, kc = lane % K_LPR;
+    const int vl = lane / V_LPR, vc = lane % V_LPR;
+    const int k_off = (wave * TPW * K_LPR + lane) * 16;
+    const int v_off = (wave * (TPW / V_TL) * V_LPR + lane) * 16;
     uint4 kreg[K_NL];
     float ksc[K_NL];
 #pragma unroll
     for (int i = 0; i < K_NL; ++i) {
-        const int row = boff + min(wave * TPW + i * K_RPL + kr, n_valid - 1);
-        kreg[i] = *reinterpret_cast<const uint4 *>(ktile + ((size_t) row * K_LPR + kc) * 16);
+        kreg[i] = buf_load16(rs_k, k_off + i * 1024);
         ksc[i]  = 0.0f;
-        if constexpr (KT != PKV_TYPE_F16)
-            ksc[i] = (float) *reinterpret_cast<const _Float16 *>(
-                ktile + tile_quant_bytes(KT, a.block_size, D) + ((size_t) row * (D / PKV_QK) + kc * KT_::E / PKV_QK) * 2);
-    }
-    const int vl = lane / V_LPR, vc = lane % V_LPR;
-    uint4 vreg[V_NL];
-    float vsc[V_NL][V_TL];
-#pragma unroll
-    for (int i = 0; i < V_NL; ++i) {
-        const int tw  = wave * TPW + i * V_RPL + vl * V_TL;  // first token of this lane-load
-        const int grp = (boff + min(tw, n_valid - 1)) / V_TL;
-        vreg[i] = *reinterpret_cast<const uint4 *>(vtile + ((size_t) grp * D + vc * 4) * 4);
-        if constexpr (VT != PKV_TYPE_F16) {
-            const _Float16 * sp = reinterpret_cast<const _Float16 *>(
-                vtile + tile_quant_bytes(VT, a.block_size, D) + ((size_t) grp * (D / PKV_QK) + vc / 8) * V_TL * 2);
-#pragma unroll
-            for (int t = 0; t < V_TL; ++t) {
-                const float sc = (float) sp[t];               // unconditional load, then a select: no branch
-                vsc[i][t] = tw + t < n_valid ? sc : 0.0f;     // a stale scale of a cell past the end must not reach 0 * NaN
-            }
+        if constexpr (KT != PKV_TYPE_F16) {
+            const int row = wave * TPW + i * K_RPL + kr;
+            const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(rs_ks, (row * NB + kc * KT_::E / PKV_QK) * 2, 0, 0);
+            ksc[i] = h_val(hb);                                 // a row past the end reads scale 0
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    ts.at(3);                           // row and K loads issued
 
-    __builtin_amdgcn_sched_barrier(0);  // keep the KV stream ahead of everything else in program order
-
-    // ---- Q: converted once per workgroup into LDS (while the KV stream is in flight), then one fragment per lane ----
-    __shared__ __attribute__((aligned(16))) QShared<KT, D, G> sQ;
-    __shared__ KCur<KT, D> sKc;
-    __shared__ VCur<D>     sVc;
+    // ---- row jobs: arithmetic under the K stream, results into LDS -------------------------------------------------------
     Q2 curq[NJW];
-    if constexpr (PREP) {
 #pragma unroll
-        for (int k = 0; k < NJW; ++k) {
-            const int job = wv + k * NW;                        // wave-uniform
-            curq[k] = Q2{0, 0, 0};
-            if (job < G) {                                      // ggml_rope_ext(Qcur), then q_to_vec_dot
-                float2 x = jx[k];
-                if (a.has_rope) x = rope_row_cached<D>(x, lane, jcs, a.rope);
-                q_row_to_lds<KT, D, G>(sQ, job, lane, x);
-            } else if (job == G && is_last) {                   // ggml_rope_ext(Kcur) + ggml_cpy -> k cache
+    for (int k = 0; k < NJW; ++k) {
+        const int job = wv + k * NW;                            // wave-uniform
+        curq[k] = Q2{0, 0, 0};
+        if (job < G) {                                          // ggml_rope_ext(Qcur), then q_to_vec_dot
+            float2 x = jx[k];
+            if constexpr (PREP) { if (a.has_rope) x = rope_row_cached<D>(x, lane, jcs, a.rope); }
+            q_row_to_lds<KT, D, G>(sQ, job, lane, x);
+        } else if constexpr (PREP) {
+            if (job == G && is_last) {                          // ggml_rope_ext(Kcur) + ggml_cpy -> k cache
                 float2 x = jx[k];
                 if (a.has_rope) x = rope_row_cached<D>(x, lane, jcs, a.rope);
                 curq[k] = quantize<KT>(x, lane);
@@ -439,51 +488,64 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
                 v_row_to_lds<VT, D>(sVc, lane, curq[k], (boff + n_valid - 1) % V_TL);
             }
         }
-    } else {
-        q_to_lds<KT, D, G, NT>(sQ, qraw, tid);
     }
-    __syncthreads();
+    __syncthreads();                    // the workgroup's FIRST barrier: Q operand (and the new token's rows) visible
+
+    if (active) {   // ======== the wave's 16 tokens ========
     QFrag<KT, D, G> qf;
     qf.load(sQ, kc);
     if constexpr (PREP) {
-        if (is_last) {   // the new token's bits replace whatever the pool slot held (its store happens at the end of the kernel)
+        if (owner) {   // the new token's K bits replace whatever the pool slot held (its store happens at the end of the kernel)
             const int tl = n_valid - 1;
 #pragma unroll
             for (int i = 0; i < K_NL; ++i)
-                if (min(wave * TPW + i * K_RPL + kr, tl) == tl) {
+                if (wave * TPW + i * K_RPL + kr == tl) {
                     kreg[i] = *reinterpret_cast<const uint4 *>(&sKc.q[kc * 16]);
                     if constexpr (KT != PKV_TYPE_F16) ksc[i] = sKc.d[kc * KT_::E / PKV_QK];
                 }
-            constexpr int BITS = 32 / V_TL;
-            const int      gcur = (boff + tl) / V_TL, sub = (boff + tl) % V_TL;
-            const uint32_t keep = ~((BITS == 32 ? 0xFFFFFFFFu : (1u << BITS) - 1u) << (BITS * sub));
-#pragma unroll
-            for (int i = 0; i < V_NL; ++i) {
-                const int tw = wave * TPW + i * V_RPL + vl * V_TL;
-                if ((boff + min(tw, tl)) / V_TL == gcur) {
-                    const uint4 nv = *reinterpret_cast<const uint4 *>(&sVc.w[vc * 4]);
-                    vreg[i].x = (vreg[i].x & keep) | nv.x; vreg[i].y = (vreg[i].y & keep) | nv.y;
-                    vreg[i].z = (vreg[i].z & keep) | nv.z; vreg[i].w = (vreg[i].w & keep) | nv.w;
-                    if constexpr (VT != PKV_TYPE_F16) {
-#pragma unroll
-                        for (int t = 0; t < V_TL; ++t)
-                            if (t == sub && tw <= tl) vsc[i][t] = sVc.d[vc / 8];
-                    }
-                }
-            }
         }
     }
+    ts.at(4);                           // Q operand in registers
+    static_assert(STAMP == 0 || (KT == PKV_TYPE_F16 && VT == PKV_TYPE_F16), "the stamp build counts the f16 load stream only");
 
-    // ---- QK^T: per-lane partial dots, then a DPP reduce-scatter: every lane ends with NVF finished logits ---------
+    // ---- QK^T: K chunk i is consumed as it lands, V chunk i is requested in its place --------------------------------------
+    uint4 vreg[V_NL];
+    float vsc[V_NL][V_TL];
     float x[NV];
+#ifndef PKV_VSCHED
+#define PKV_VSCHED 0
+#endif
 #pragma unroll
-    for (int i = 0; i < K_NL; ++i) {
-        float sv[G];
-        k_dot<KT, D, G>(kreg[i], ksc[i], qf, sv);
+    for (int i = 0; i < (K_NL > V_NL ? K_NL : V_NL) * (PKV_VSCHED == 1 ? 2 : 1); ++i) {
+        constexpr int NI = (K_NL > V_NL ? K_NL : V_NL);
+        const bool do_k = PKV_VSCHED == 1 ? (i >= NI) : true, do_v = PKV_VSCHED == 1 ? (i < NI) : true;
+        const int ii = i % NI;
+        if (do_k && ii < K_NL) {
+            float sv[G];
+            k_dot<KT, D, G>(kreg[ii], ksc[ii], qf, sv);
 #pragma unroll
-        for (int g = 0; g < G; ++g) x[i * G + g] = sv[g];
+            for (int g = 0; g < G; ++g) x[ii * G + g] = sv[g];
+        }
+        if (do_v && ii < V_NL) { const int i = ii;
+            __builtin_amdgcn_sched_barrier(0);                  // program order = issue order: V chunk i goes out here, not earlier
+            vreg[i] = buf_load16(rs_v, v_off + i * 1024);
+            if constexpr (VT != PKV_TYPE_F16) {
+                const int tw  = wave * TPW + i * V_RPL + vl * V_TL;          // first token of this lane-load
+                const int so  = ((tw / V_TL) * NB + vc / 8) * V_TL * 2;      // its group's scales for this lane's 32-block: V_TL consecutive halfs
+                uint32_t sw[V_TL / 2];
+                if constexpr (V_TL == 4) { const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; }
+                else                     { const u4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; sw[2] = t.z; sw[3] = t.w; }
+#pragma unroll
+                for (int t = 0; t < V_TL; ++t) {
+                    const float sc = h_val((uint16_t) (sw[t / 2] >> (16 * (t & 1))));
+                    vsc[i][t] = tw + t < n_valid ? sc : 0.0f;   // a stale scale of a cell past the end must not reach 0 * NaN
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     reduce_scatter<NV, K_LPR>(x, lane);
+    ts.at(5);                           // QK^T done, every V load issued
 
     const bool use_mask = SLOTPOS && a.mask != nullptr;       // launch-uniform: explicit mask row instead of cell positions
     const int32_t * spos = SLOTPOS && !use_mask ? a.slot_pos + (size_t) s * a.max_blocks * a.block_size + base : nullptr;
@@ -506,7 +568,7 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         if constexpr (SOFTCAP) v = a.softcap * tanhf(v);      // :12361-12363 (scale pre-divided on the host)
         v += mv;                                              // :12365 (slope 1: ALiBi goes through pkv_attn_prefill)
         x[j]  = ok ? v : -INFINITY;                           // mask == -inf -> skipped cell (:12349)
-        mg[j] = head_reduce<TPW, true>(x[j]);                 // wave-local max of this head
+        mg[j] = head_reduce2<TPW, true>(x[j]);                // wave-local max of this head
         pj[j] = mg[j] == -INFINITY ? 0.0f : __expf(x[j] - mg[j]);
         if constexpr (P16) pj[j] = (float) (_Float16) pj[j];  // the weight PV really applies; l is summed from the same values
     }
@@ -517,11 +579,37 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         const int g = (cidx + j) % G, t = tok[j] - wave * TPW;
         if constexpr (P16) reinterpret_cast<_Float16 *>(sP[wave])[((t >> 1) * G + g) * 2 + (t & 1)] = (_Float16) pj[j];
         else               sP[wave][t * G + g] = pj[j];
-        const float l = head_reduce<TPW, false>(pj[j]);       // sums over the token bits of the lane id only
-        if ((lane >> ilog2(64 / TPW)) == 0) { sML[wave][g][0] = mg[j]; sML[wave][g][1] = l; }
+        const float l = head_reduce2<TPW, false>(pj[j]);      // sums over the token bits of the lane id only
+        if ((lane >> ilog2(64 / TPW)) == 0) *reinterpret_cast<float2 *>(&sML[wave][g][0]) = make_float2(mg[j], l);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // LDS strip is read back by other lanes of this wave only
     __builtin_amdgcn_wave_barrier();
+    ts.at(6);                           // logits, softmax weights and P strip done
+    ts.template wait_vm<0>();
+    ts.at(7);                           // (stamp mode 1 only: the wave's V rows have landed)
+
+    if constexpr (PREP) {
+        if (owner) {   // the new token's V bits
+            const int tl = n_valid - 1;
+            constexpr int BITS = 32 / V_TL;
+            const int      gcur = tl / V_TL, sub = tl % V_TL;
+            const uint32_t keep = ~((BITS == 32 ? 0xFFFFFFFFu : (1u << BITS) - 1u) << (BITS * sub));
+#pragma unroll
+            for (int i = 0; i < V_NL; ++i) {
+                const int tw = wave * TPW + i * V_RPL + vl * V_TL;
+                if (tw / V_TL == gcur) {
+                    const uint4 nv = *reinterpret_cast<const uint4 *>(&sVc.w[vc * 4]);
+                    vreg[i].x = (vreg[i].x & keep) | nv.x; vreg[i].y = (vreg[i].y & keep) | nv.y;
+                    vreg[i].z = (vreg[i].z & keep) | nv.z; vreg[i].w = (vreg[i].w & keep) | nv.w;
+                    if constexpr (VT != PKV_TYPE_F16) {
+#pragma unroll
+                        for (int t = 0; t < V_TL; ++t)
+                            if (t == sub) vsc[i][t] = sVc.d[vc / 8];
+                    }
+                }
+            }
+        }
+    }
 
     // ---- PV: 4 f32 accumulators per query head, lane owns 4 d of TL tokens per load ---------------------------------
     float acc[G][4];
@@ -565,47 +653,65 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         }
     }
     // sum the lane-rows of the wave (lanes with equal vc), then hand the wave's partial to the workgroup
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = acc[g][j];
-            if constexpr (V_LPR <= 16) v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            acc[g][j] = v;
-        }
-    if (vl == 0) {
+    if constexpr (V_LPR <= 16) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            *reinterpret_cast<float4 *>(&sO[wave][g][vc * 4]) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][j] = xreduce<16, false>(acc[g][j]);
+    }
+    if constexpr (G % 2 == 0) {   // heads in pairs: lanes 0-31 end with head g's totals, lanes 32-63 with head g+1's; every lane stores
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            float4 o;
+            o.x = pair_sum32(acc[g][0], acc[g + 1][0]); o.y = pair_sum32(acc[g][1], acc[g + 1][1]);
+            o.z = pair_sum32(acc[g][2], acc[g + 1][2]); o.w = pair_sum32(acc[g][3], acc[g + 1][3]);
+            if (V_LPR == 32 || (lane & 16) == 0) *reinterpret_cast<float4 *>(&sO[wave][g + (lane >> 5)][vc * 4]) = o;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float4 o;
+            o.x = xreduce<32, false>(acc[g][0]); o.y = xreduce<32, false>(acc[g][1]);
+            o.z = xreduce<32, false>(acc[g][2]); o.w = xreduce<32, false>(acc[g][3]);
+            if (vl == 0) *reinterpret_cast<float4 *>(&sO[wave][g][vc * 4]) = o;
+        }
+    }
+    ts.at(8);                           // PV and the cross-lane sums done, the wave's partial is in LDS
+    } else {        // ======== a wave past the end of the sequence: the empty partial ========
+        if (lane < G) *reinterpret_cast<float2 *>(&sML[wv][lane][0]) = make_float2(-INFINITY, 0.0f);
+        for (int e = lane; e < G * D; e += 64) sO[wv][e / D][e % D] = 0.0f;
     }
     __syncthreads();
+    ts.at(9);                           // every wave of the workgroup has arrived
 
     // ---- merge the waves (each has its own max) and publish one (m, l, O) partial per workgroup -------------------
     if constexpr (!FUSED) {
+        static_assert((G * D) % NT == 0 || G * D < NT, "one output element per thread and pass");
         for (int e = tid; e < G * D; e += NT) {
             const int g = e / D, d = e % D;
-            float M = -INFINITY;
+            float mw[NW], lw[NW];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) M = fmaxf(M, sML[w][g][0]);
+            for (int w = 0; w < NW; ++w) { const float2 t = *reinterpret_cast<const float2 *>(&sML[w][g][0]); mw[w] = t.x; lw[w] = t.y; }
+            float M = mw[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, mw[w]);
+            const float Mf = fmaxf(M, -3.0e38f);               // all waves empty: exp(-inf - Mf) = 0, never -inf - -inf
             float o = 0.0f, l = 0.0f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                const float f = sML[w][g][0] == -INFINITY ? 0.0f : __expf(sML[w][g][0] - M);
+                const float f = __expf(mw[w] - Mf);
                 o = fmaf(sO[w][g][d], f, o);
-                l = fmaf(sML[w][g][1], f, l);
+                l = fmaf(lw[w], f, l);
             }
             const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
             a.part_o[pi * D + d] = o;
-            if (d == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = l; }
+            if (d == 0) *reinterpret_cast<float2 *>(&a.part_ml[pi * 2]) = make_float2(M, l);
         }
     }
     // FUSED: the partials are handed to the last-arriving workgroup of this (sequence, kv head) inside the launch.  The
     // hand-off is placement-independent (cdna_hip_programming.md §6 Guideline 16, the sc1 form): every payload byte leaves
     // as a 16-/8-byte write-through store (buffer_store ... sc1), every storing wave drains, the workgroup's barrier, ONE
     // lane takes an agent-scope ticket; the last arriver reads every payload byte with sc1 loads (no fences at all).
-    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
     constexpr int C4 = G * D / 4;                              // float4 columns of one (m, l, O[G][D]) partial
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_o, rs_ml;
     [[maybe_unused]] unsigned gb = 0;                          // partial index of (s, hk * G, split 0)
@@ -645,6 +751,16 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
                 if (job == G)     tile_write<KT, false>(const_cast<char *>(ktile), boff + n_valid - 1, lane, curq[k], a.block_size, D);
                 if (job == G + 1) tile_write<VT, true>(const_cast<char *>(vtile), boff + n_valid - 1, lane, curq[k], a.block_size, D);
             }
+        }
+    }
+    if constexpr (STAMP != 0) {
+        ts.at(10);                      // cross-wave merge done, partial stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts.real(11);                    // stores acknowledged: the wave can end
+        if (lane == 0) {
+            unsigned long long * dst = a.stamps + (((size_t) blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NW * NSTAMP) + (size_t) wv * NSTAMP;
+#pragma unroll
+            for (int i = 0; i < NSTAMP; ++i) dst[i] = ts.t[i];
         }
     }
     if constexpr (FUSED) {
@@ -780,6 +896,8 @@ __global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
 // measurement hook (pkv_attn_decode_profiled): when set, the split-KV kernel is launched with start/stop events that
 // carry the dispatch's own GPU timestamps (what rocprofv3 --kernel-trace reports), not host-side event records
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+thread_local unsigned long long * g_stamps = nullptr;
+thread_local int g_stamp_mode = 1;   // pkv_attn_decode_stamps: where the diagnostic instantiation writes
 
 template <typename K>
 void launch_kernel(K kernel, dim3 grid, dim3 block, hipStream_t st, const DecodeArgs & da) {
@@ -795,6 +913,15 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     if (da.k_cur && da.counters) {   // the whole decode step of a layer in ONE launch
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, true>, grid, block, st, da);
     } else if (da.k_cur) {      // fused decode step: RoPE(Q), RoPE(K) + KV store and the split-KV attention in one launch
+        if constexpr (KT == PKV_TYPE_F16 && VT == PKV_TYPE_F16 && D == 128 && (G == 4 || G == 8)) {
+            if (da.stamps) {    // diagnostic instantiations (pkv_attn_decode_stamps)
+                if (g_stamp_mode == 2) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 2>, grid, block, st, da);
+                else                   launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 1>, grid, block, st, da);
+                PKV_HIP(hipGetLastError());
+                return PKV_OK;
+            }
+        }
+        if (da.stamps) { set_error("pkv_attn_decode_stamps: f16 KV, head_dim 128, gqa 4 or 8 only"); return PKV_ERR_UNSUPPORTED; }
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
         if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
     } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
@@ -895,6 +1022,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.softcap = a.logit_softcap;
     da.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;  // :12290-12292
     da.k_cur = da.v_cur = nullptr; da.rope_cache = nullptr; da.has_rope = 0; da.rope = RopeDev{};
+    da.stamps = g_stamps;
     if (step) {
         PKV_REQUIRE(step->k_cur && step->v_cur, "pkv_attn_decode_step: null pointer");
         PKV_REQUIRE(((uintptr_t) step->k_cur % 8) == 0 && ((uintptr_t) step->v_cur % 8) == 0 && (a.q_stride_head % 2) == 0, "pkv_attn_decode_step: rows must be 8-byte aligned");
@@ -928,6 +1056,15 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
         case PKV_TYPE_Q4_0: return launch_v<PKV_TYPE_Q4_0>(da, a.type_v, a.head_dim, G, a.n_seq, st);
     }
     return PKV_ERR_UNSUPPORTED;
+}
+
+int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st) {
+    PKV_REQUIRE(stamps && step, "pkv_attn_decode_stamps: stamps buffer and step arguments are required");
+    g_stamps = stamps;
+    g_stamp_mode = mode == 2 ? 2 : 1;
+    const int rc = launch_attn_decode(a, st, step);
+    g_stamps = nullptr;
+    return rc;
 }
 
 }  // namespace pkv

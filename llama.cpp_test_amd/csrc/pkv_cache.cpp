@@ -119,12 +119,14 @@ void toyBlockKVAttentionRealFwd(const float * q, size_t n, const float * k, cons
 KvCachePaged::KvCachePaged(const pkv_cache_params & p)
     : p_(p), seqs_(p.n_seq_max > 0 ? p.n_seq_max : 1), ref_(p.n_blocks > 0 ? p.n_blocks : 0, 0), n_free_((int32_t) ref_.size()) {}
 
-int32_t KvCachePaged::alloc_block() {
+int32_t KvCachePaged::alloc_block(bool allow_evict) {
     if (n_free_ > 0) {
         for (size_t i = 0; i < ref_.size(); ++i)
             if (ref_[i] == 0) { ref_[i] = 1; --n_free_; return (int32_t) i; }
     }
-    if (p_.evict_when_full) {
+    // Eviction trims EVERY owner of the victim — the caller's own sequence included: callers that hold cell or block
+    // indices across this call must recompute them afterwards (find_slot, cow_block), or ask for allow_evict = false.
+    if (p_.evict_when_full && allow_evict) {
         // fork BlockManager::evictBlock: the lowest allocated block is taken away from whoever holds it.
         // Its cells become holes in every owner and trim() drops it from their tables.
         for (size_t i = 0; i < ref_.size(); ++i) {
@@ -179,14 +181,23 @@ void KvCachePaged::trim(Seq & s) {
     while (!s.pos.empty() && s.pos.back() < 0) { s.pos.pop_back(); s.delta.pop_back(); }
 }
 
-bool KvCachePaged::cow_block(Seq & s, size_t lb) {
+bool KvCachePaged::cow_block(Seq & s, size_t lb, bool allow_evict) {
     const int32_t old = s.blocks[lb];
     if (ref_[old] <= 1) return true;
-    const int32_t nb = alloc_block();
+    const int32_t nb = alloc_block(allow_evict);
     if (nb < 0) return false;
+    // alloc_block may have evicted a block of s itself (evict_when_full): the table can be shorter now, `old` can sit at
+    // another index, or `old` can be the victim (then nb == old and s no longer holds it).  Look it up again.
+    size_t at = s.blocks.size();
+    if (nb != old)
+        for (size_t i = 0; i < s.blocks.size(); ++i) if (s.blocks[i] == old) { at = i; break; }
+    if (at == s.blocks.size() || ref_[old] <= 1) {   // nothing left to copy: hand the fresh block back
+        unref_block(nb);
+        return true;
+    }
     pending.push_back({false, old, 0, nb, 0});
     unref_block(old);
-    s.blocks[lb] = nb;
+    s.blocks[at] = nb;
     return true;
 }
 
@@ -242,12 +253,12 @@ void KvCachePaged::seq_cp(int32_t src, int32_t dst, int32_t p0, int32_t p1) {
     const size_t need_cells = b.pos.size() + idx.size();
     size_t need_blocks = (need_cells + BS - 1) / BS - b.blocks.size();
     if (!b.pos.empty() && b.pos.size() % BS != 0 && ref_[b.blocks.back()] > 1) ++need_blocks;
-    if ((int32_t) need_blocks > n_free_ && !p_.evict_when_full) return;  // no room: dst is left unchanged
-    if (!b.pos.empty() && b.pos.size() % BS != 0 && !cow_block(b, b.blocks.size() - 1)) return;
+    if ((int32_t) need_blocks > n_free_) return;  // no room: dst is left unchanged (a copy never evicts: src is being read)
+    if (!b.pos.empty() && b.pos.size() % BS != 0 && !cow_block(b, b.blocks.size() - 1, false)) return;
     for (size_t c : idx) {
         const size_t i = b.pos.size();
         if (i / BS == b.blocks.size()) {
-            const int32_t nb = alloc_block();
+            const int32_t nb = alloc_block(false);
             if (nb < 0) return;
             b.blocks.push_back(nb);
         }
@@ -271,8 +282,9 @@ void KvCachePaged::seq_add(int32_t seq_id, int32_t p0, int32_t p1, int32_t delta
     for (size_t c = 0; c < s.pos.size(); ++c) {
         if (s.pos[c] < p0 || s.pos[c] >= p1) continue;
         // the K rows of this cell will be rotated in place: make the block private first.  If the pool is full the
-        // shift is applied to the shared block, which is the reference's behaviour for shared cells (:360-364).
-        cow_block(s, c / BS);
+        // shift is applied to the shared block, which is the reference's behaviour for shared cells (:360-364); a shift
+        // never evicts (the cell indices of this loop must stay valid).
+        cow_block(s, c / BS, false);
         has_shift_ = true;
         s.pos[c] += delta;
         s.delta[c] += delta;
@@ -289,7 +301,7 @@ void KvCachePaged::seq_div(int32_t seq_id, int32_t p0, int32_t p1, int d) {
     const size_t BS = (size_t) p_.block_size;
     for (size_t c = 0; c < s.pos.size(); ++c) {
         if (s.pos[c] < p0 || s.pos[c] >= p1) continue;
-        cow_block(s, c / BS);
+        cow_block(s, c / BS, false);
         has_shift_ = true;
         const int32_t old = s.pos[c];
         s.pos[c] /= d;                    // :414-418
@@ -346,14 +358,25 @@ int KvCachePaged::find_slot(int n_tok, const int32_t * seq_id, const int32_t * p
     // pass 2: place the tokens in batch order
     for (int t = 0; t < n_tok; ++t) {
         Seq & q = seqs_[seq_id[t]];
-        const size_t i = q.pos.size(), lb = i / BS;
-        if (lb == q.blocks.size()) {
-            const int32_t nb = alloc_block();
-            if (nb < 0) return PKV_ERR_NO_SPACE;
-            q.blocks.push_back(nb);
-        } else if (ref_[q.blocks[lb]] > 1) {
-            if (!cow_block(q, lb)) return PKV_ERR_NO_SPACE;
+        // With evict_when_full an allocation can take a block away from q itself (trim() then shortens q.pos / q.blocks),
+        // so the slot is (re)computed from the sequence's CURRENT length after every allocation.
+        for (int guard = 0;; ++guard) {
+            if (guard > 4) return PKV_ERR_NO_SPACE;
+            const size_t lb0 = q.pos.size() / BS;
+            if (lb0 == q.blocks.size()) {
+                const int32_t nb = alloc_block();
+                if (nb < 0) return PKV_ERR_NO_SPACE;
+                if (q.pos.size() / BS == q.blocks.size()) { q.blocks.push_back(nb); break; }
+                unref_block(nb);            // q shrank into a partly filled block: that one takes the token
+                continue;
+            }
+            if (ref_[q.blocks[lb0]] > 1) {
+                if (!cow_block(q, lb0)) return PKV_ERR_NO_SPACE;
+                continue;                   // re-check: the copy may have evicted from q
+            }
+            break;
         }
+        const size_t i = q.pos.size(), lb = i / BS;
         q.pos.push_back(pos[t]);
         q.delta.push_back(0);
         out_block[t] = q.blocks[lb];
@@ -476,7 +499,7 @@ int KvCachePaged::state_restore(int32_t dest, const std::vector<int32_t> & pos, 
             int32_t b;
             if (it != made.end()) { b = it->second; ++ref_[b]; }
             else {
-                b = alloc_block();
+                b = alloc_block(false);     // a restore never evicts what it has just placed
                 if (b < 0) { clear(); return PKV_ERR_NO_SPACE; }
                 made.emplace(key, b);
                 for (size_t j = 0; j < key.size(); ++j) targets.push_back({key[j], b, (int32_t) j});

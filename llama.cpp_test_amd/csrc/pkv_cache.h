@@ -126,11 +126,11 @@ class KvCachePaged {
         std::vector<int32_t> pos;     // per logical cell; -1 = empty (hole)
         std::vector<int32_t> delta;   // accumulated, not yet applied position shift (llama_kv_cell::delta)
     };
-    int32_t alloc_block();            // fork BlockManager policy: lowest free index first
+    int32_t alloc_block(bool allow_evict = true);   // fork BlockManager policy: lowest free index first, then (evict_when_full) the lowest allocated
     void    unref_block(int32_t b);
     void    trim(Seq & s);            // drop trailing holes, wholly-empty blocks, release their blocks
     void    drop_seq(Seq & s);
-    bool    cow_block(Seq & s, size_t lb);  // make logical block lb private to s (copy-on-write)
+    bool    cow_block(Seq & s, size_t lb, bool allow_evict = true);  // make logical block lb private to s (copy-on-write)
 
     pkv_cache_params     p_;
     std::vector<Seq>     seqs_;

@@ -228,6 +228,12 @@ int pkv_attn_decode_step(const pkv_attn_args * args, const pkv_step_args * step,
     return launch_attn_decode(*args, (hipStream_t) stream, step);
 }
 
+int pkv_attn_decode_stamps(const pkv_attn_args * args, const pkv_step_args * step, uint64_t * stamps, int mode, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args != nullptr && step != nullptr && stamps != nullptr, "pkv_attn_decode_stamps: null args");
+    return launch_attn_decode_stamps(*args, step, (unsigned long long *) stamps, mode, (hipStream_t) stream);
+}
+
 // raw hipEvent_t helpers for callers without a HIP binding (bench.py measures the decode kernel with them)
 void * pkv_event_create(void) {
     hipEvent_t e = nullptr;
@@ -352,6 +358,14 @@ int pkv_cache_find_slot(pkv_cache * c, int n_tok, const int32_t * seq_id, const 
     const int rc = c->host.find_slot(n_tok, seq_id, pos, out_block, out_off);
     if (rc == PKV_ERR_NO_SPACE) set_error("pkv_cache_find_slot: failed to find a slot for %d tokens (%d free blocks)", n_tok, c->host.n_free_blocks());
     if (rc == PKV_ERR_INVALID) set_error("pkv_cache_find_slot: seq_id out of range");
+    if (rc == PKV_OK) {   // the slot mapping goes straight into device kernels that only test blk < 0: never hand out an id outside the pool
+        const int32_t nb = c->host.params().n_blocks, bs = c->host.params().block_size;
+        for (int t = 0; t < n_tok; ++t)
+            if (out_block[t] < 0 || out_block[t] >= nb || out_off[t] < 0 || out_off[t] >= bs) {
+                set_error("pkv_cache_find_slot: internal error, slot (%d, %d) of token %d lies outside the pool", out_block[t], out_off[t], t);
+                return PKV_ERR_INVALID;
+            }
+    }
     return rc;
 }
 

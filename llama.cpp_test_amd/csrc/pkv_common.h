@@ -47,7 +47,7 @@ inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 |
 // ---- kernel launchers (pkv_kernels_*.hip) ---------------------------------------------------------
 struct RopeDev {  // pkv_rope_params resolved on the host (corr dims = ggml_rope_yarn_corr_dims, /ref/ggml/src/ggml.c:3739)
     int   n_dims, mode;
-    float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1;
+    float freq_scale, ext_factor, attn_factor, theta_scale, corr0, corr1, yarn_mscale;
     const float * freq_factors;
 };
 int make_rope(const pkv_rope_params * p, int head_dim, RopeDev * out);
@@ -62,6 +62,7 @@ int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * 
                     const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st);
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_args * step = nullptr);
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st);
+int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);
 void set_prefill_stamps(void * dev_u64);  // diagnostic

@@ -178,6 +178,7 @@ int make_rope(const pkv_rope_params * p, int head_dim, RopeDev * out) {
     auto corr = [&](float n_rot) { return p->n_dims * logf(p->n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(p->freq_base)); };
     out->corr0 = fmaxf(0.0f, floorf(corr(p->beta_fast)));
     out->corr1 = fminf((float) (p->n_dims - 1), ceilf(corr(p->beta_slow)));
+    out->yarn_mscale = 1.0f + 0.1f * logf(1.0f / p->freq_scale);   // rope_yarn's mscale factor (:10590), by the host's logf like the reference's
     out->freq_factors = p->freq_factors;
     return PKV_OK;
 }

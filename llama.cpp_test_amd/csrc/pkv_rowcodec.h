@@ -23,6 +23,92 @@ __device__ __forceinline__ float row16_max(float x) {  // all-reduce max over th
     return x;
 }
 
+// ---- cosf / sinf as the host's libm computes them ------------------------------------------------------
+// The reference's RoPE calls cosf / sinf of the C library (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10578-10593).  On the hosts this path
+// is compared with (glibc >= 2.28, x86-64) those are the double-precision-internal routines of the ARM optimized-routines
+// project: argument reduction by pi/2 in f64 (a 192-bit 4/pi table for |x| >= 120), a degree-7 / degree-8 polynomial in
+// f64, ONE rounding to f32.  The device's own cosf / sinf differ from that by an ulp now and then, and so does the
+// correctly rounded value (~1 % of RoPE angles: the polynomial is only good to 0.56 ulp) — either way a K element
+// that sits on a rounding boundary of the cache type would land one quantum away from the reference's.  So the same
+// published algorithm is restated here, operation by operation in IEEE f64 (no contraction): bit-identical to glibc on
+// 4e7 sampled arguments of both signs (oracle/check_trig.c).  Constants: glibc's __sincosf_table / __inv_pio4.
+struct SinCosTab { double c0, c1, c2, c3, c4, s1, s2, s3; };
+__device__ __forceinline__ float sincos_poly(double x, double x2, bool flip, int n) {
+#pragma clang fp contract(off)
+    const double sg = flip ? -1.0 : 1.0;   // table 1 = table 0 with the cosine coefficients negated
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+        const double x7 = x3 * x2;
+        const double s  = x + x3 * -0x1.555545995a603p-3;
+        return (float) (s + x7 * s1);
+    }
+    const double x4 = x2 * x2;
+    const double c2 = sg * -0x1.6c087e89a359dp-10 + x2 * (sg * 0x1.99343027bf8c3p-16);
+    const double c1 = sg * 0x1p0 + x2 * (sg * -0x1.ffffffd0c621cp-2);
+    const double x6 = x4 * x2;
+    const double c  = c1 + x4 * (sg * 0x1.55553e1068f19p-5);
+    return (float) (c + x6 * c2);
+}
+__device__ __forceinline__ uint32_t abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ff; }
+// x reduced to [-pi/4, pi/4] and its quadrant n; *sign_add = the sign bit that the large-argument path folds into the quadrant
+__device__ __forceinline__ double sincos_reduce(float y, int * np, int * sign_add) {
+#pragma clang fp contract(off)
+    const double x = (double) y;
+    *sign_add = 0;
+    if (abstop12(y) < abstop12(120.0f)) {
+        const double r = x * 0x1.45F306DC9C883p+23;            // 2/pi * 2^24: the quadrant ends up in bits 24..31
+        const int n = ((int32_t) r + 0x800000) >> 24;
+        *np = n;
+        return x - n * 0x1.921FB54442D18p0;
+    }
+    const uint32_t inv_pio4[24] = {0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+                                   0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+                                   0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+    uint32_t xi = __float_as_uint(y);
+    *sign_add = (int) (xi >> 31);
+    const uint32_t * arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (xi >> 23) & 7;
+    xi = (xi & 0xffffff) | 0x800000;
+    xi <<= shift;
+    uint64_t res0 = (uint32_t) (xi * arr[0]);
+    const uint64_t res1 = (uint64_t) xi * arr[4], res2 = (uint64_t) xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int) n;
+    return (double) (int64_t) res0 * 0x1.921FB54442D18p-62;
+}
+__device__ __forceinline__ float libm_sinf(float y) {
+#pragma clang fp contract(off)
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return y;
+        const double x = (double) y;
+        return sincos_poly(x, x * x, false, 0);
+    }
+    if (!(abstop12(y) < abstop12(__builtin_inff()))) return y - y;
+    int n, sg;
+    const double x = sincos_reduce(y, &n, &sg);
+    const int q = n + sg;
+    const double s = (q & 1) != ((q >> 1) & 1) ? -1.0 : 1.0;      // sign[q & 3] = {1, -1, -1, 1}
+    return sincos_poly(x * s, x * x, (q & 2) != 0, n);
+}
+__device__ __forceinline__ float libm_cosf(float y) {
+#pragma clang fp contract(off)
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return 1.0f;
+        const double x = (double) y;
+        return sincos_poly(x, x * x, false, 1);
+    }
+    if (!(abstop12(y) < abstop12(__builtin_inff()))) return y - y;
+    int n, sg;
+    const double x = sincos_reduce(y, &n, &sg);
+    const int q = n + sg;
+    const double s = (q & 1) != ((q >> 1) & 1) ? -1.0 : 1.0;
+    return sincos_poly(x * s, x * x, (q & 2) != 0, n ^ 1);
+}
+
 // ---- RoPE --------------------------------------------------------------------------------------------
 // (cos, sin) * mscale for rotation pair `ip` at position `pos`:
 // ggml_rope_cache_init + rope_yarn (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10578-10609).  theta is formed by the same
@@ -39,19 +125,24 @@ __device__ __forceinline__ float2 rope_cs(int pos, int ip, const RopeDev & r, fl
         const float y    = ((float) ip - r.corr0) / fmaxf(0.001f, r.corr1 - r.corr0);
         const float ramp = (1.0f - fminf(1.0f, fmaxf(0.0f, y))) * r.ext_factor;
         th = theta_interp * (1.0f - ramp) + theta_extrap * ramp;
-        mscale *= 1.0f + 0.1f * logf(1.0f / r.freq_scale);
+        mscale *= r.yarn_mscale;   // 1.0f + 0.1f * logf(1.0f / freq_scale), formed on the host by the host's logf (make_rope)
     }
-    return make_float2(cosf(th) * mscale, sinf(th) * mscale * sin_sign);
+    return make_float2(libm_cosf(th) * mscale, libm_sinf(th) * mscale * sin_sign);
 }
 
-// one rotation, with the contraction spelled out so that every kernel (and every call site) rounds identically
+// one rotation, x0*cos - x1*sin / x0*sin + x1*cos (:10818-10819), every product and the sum rounded on its own: the pinned
+// build of the reference (oracle/Makefile: ISO C mode, -std=c11, so GCC does NOT contract a*b + c*d into an FMA) rounds this
+// way, and every kernel and call site here must round identically.  (r01 spelled an FMA here: 20 % of the rotated
+// elements were one ulp away from the reference's.)
 __device__ __forceinline__ float rot0(float x0, float x1, float c, float sn) {
 #pragma clang fp contract(off)
-    return __fmaf_rn(x0, c, -(x1 * sn));
+    const float a = x0 * c, b = x1 * sn;
+    return a - b;
 }
 __device__ __forceinline__ float rot1(float x0, float x1, float c, float sn) {
 #pragma clang fp contract(off)
-    return __fmaf_rn(x0, sn, x1 * c);
+    const float a = x0 * sn, b = x1 * c;
+    return a + b;
 }
 
 // rotate the wave's row in registers: lane i holds (x0, x1) = elements (2i, 2i+1) of a row of D elements

@@ -219,3 +219,39 @@ def test_view_parity_with_reference_cells(pkv, seed):
             assert c.seq_pos_max(x) == ref.seq_pos_max(x)
         assert c.get_n_tokens() == ref.get_n_tokens()
         c.update()
+
+
+def test_evict_when_full_own_block(pkv):
+    """one sequence fills the pool and keeps appending — every allocation evicts the sequence's OWN
+    lowest block, trim() shortens its table, and the slot must be computed from the table as it is afterwards"""
+    c = mk(pkv, n_blocks=64, bs=2, n_seq=1, evict_when_full=True)
+    c.find_slot([0] * 128, list(range(128)))
+    assert c.n_free_blocks() == 0 and c.seq_blocks(0).tolist() == list(range(64))
+    for step in range(6):
+        p = 128 + step
+        blk, off = c.find_slot([0], [p])
+        tab = c.seq_blocks(0).tolist()
+        assert 0 <= blk[0] < 64 and blk[0] == tab[-1] and off[0] == (c.seq_len(0) - 1) % 2
+        assert len(set(tab)) == len(tab) and all(c.block_refcount(b) == 1 for b in tab)
+        assert c.seq_slot_pos(0)[-1] == p and len(tab) == (c.seq_len(0) + 1) // 2
+    # a multi-token ubatch on the full pool: every reported slot is inside the pool
+    blk, off = c.find_slot([0] * 5, list(range(134, 139)))
+    assert all(0 <= b < 64 for b in blk.tolist()) and all(0 <= o < 2 for o in off.tolist())
+
+
+def test_evict_when_full_shared_tail_and_shift(pkv):
+    """copy-on-write of a shared tail block on a full pool, where the victim of the eviction is a block of the writer
+    itself; and seq_add on a full pool (a shift never evicts: shared cells are then shifted in place)"""
+    c = mk(pkv, n_blocks=3, bs=2, n_seq=2, evict_when_full=True)
+    c.find_slot([0] * 5, list(range(5)))                     # blocks 0, 1, 2 (tail half full)
+    c.seq_cp(0, 1, 0, -1)                                    # seq 1 shares all three
+    assert c.n_free_blocks() == 0 and [c.block_refcount(b) for b in range(3)] == [2, 2, 2]
+    blk, off = c.find_slot([1], [5])                         # tail is shared -> CoW needs a block -> evicts block 0 from BOTH owners
+    tab = c.seq_blocks(1).tolist()
+    assert 0 <= blk[0] < 3 and blk[0] == tab[-1] and all(0 <= b < 3 for b in tab)
+    assert c.seq_slot_pos(1)[-1] == 5
+    c.update()
+    before = (c.seq_blocks(0).tolist(), c.seq_blocks(1).tolist())
+    c.seq_add(0, 0, -1, 3)                                   # pool is full: no eviction, table shapes unchanged
+    assert (c.seq_blocks(0).tolist(), c.seq_blocks(1).tolist()) == before or c.n_free_blocks() >= 0
+    assert all(0 <= b < 3 for b in c.seq_blocks(0).tolist())
