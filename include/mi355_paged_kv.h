@@ -48,7 +48,8 @@ extern "C" {
 
 /* values follow enum ggml_type (/ref/ggml/include/ggml.h:351-360) */
 enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8,
-                PKV_TYPE_Q4_K = 12 /* weights of pkv_mul_mat only (block_q4_K, /ref/ggml/src/ggml-common.h:279-290); not a KV type */ };
+                PKV_TYPE_Q4_K = 12, /* weights of pkv_mul_mat / pkv_gemv_q only (block_q4_K, /ref/ggml/src/ggml-common.h:279-290); not a KV type */
+                PKV_TYPE_Q6_K = 14  /* weights of pkv_gemv_q / pkv_get_rows only (block_q6_K, :309-319): what a Q4_K_M file mixes in          */ };
 
 enum pkv_status {
     PKV_OK              =  0,
@@ -352,6 +353,35 @@ int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t 
 #define PKV_MUL_MAT_MAX 4
 int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                       void * stream);
+
+/* ---- decode-step weight products (one activation column) for K-quant weights: csrc/pkv_gemv.hip ------------------------------
+ * The activation column is quantized once to int8 per 32 elements (the reference's CPU backend quantizes it to q8_K per 256 before a
+ * q4_K / q6_K product, /ref/ggml/src/ggml-cpu/ggml-cpu.c:7467-7640) into an "activation image" of pkv_act_image_bytes(K) bytes:
+ * by pkv_quantize_act, or by pkv_rms_norm_mul_q (rms_norm(x [+ res]) * w straight into the image: build_norm feeding a product).
+ * pkv_gemv_q then streams the rows of up to three matrices that share the column in ONE launch (wq + wk + wv; gate + up), with the
+ * epilogues a llama layer needs: y = residual + W x (attn_out / ffn_down onto the residual stream, :4120,:4160) or
+ * y = silu(W0 x) * (W1 x) (LLM_FFN_SILU + LLM_FFN_PAR of build_ffn).  Rows are block_q4_K / block_q6_K in the reference's format
+ * (per matrix: a Q4_K_M file keeps attn_v / ffn_down / output in q6_K), K % 256 == 0, M even. */
+#define PKV_GEMV_MAX 3
+typedef struct pkv_gemv {
+    int32_t       n;                   /* products that share the activation image (1..PKV_GEMV_MAX)                          */
+    int32_t       silu_mul;            /* 1: n == 2, M[0] == M[1]: y[0][m] = silu(W0 x)[m] * (W1 x)[m]; y[1] is not written    */
+    int32_t       type_w[PKV_GEMV_MAX];
+    const void *  w[PKV_GEMV_MAX];     /* device rows, reference format                                                       */
+    float *       y[PKV_GEMV_MAX];     /* device f32 [M[i]]                                                                   */
+    int64_t       M[PKV_GEMV_MAX];
+    int64_t       K;
+    const void *  xq;                  /* activation image                                                                    */
+    const float * residual;            /* optional (n == 1): y[0][m] = residual[m] + (W x)[m]; may alias y[0]                 */
+} pkv_gemv;
+size_t pkv_act_image_bytes(int64_t K);
+int pkv_quantize_act(const float * x, void * image, int64_t K, void * stream);
+/* x_out = x + res (res, x_out both or neither; x_out may alias x), image = quantize(rms_norm(x_out) * w); y (optional) = the f32 row */
+int pkv_rms_norm_mul_q(const float * x, const float * res, float * x_out, const float * w, float * y, void * image, int64_t ne0, float eps, void * stream);
+int pkv_gemv_q(const pkv_gemv * g, void * stream);
+/* ggml_get_rows (/ref/src/llama-model.cpp:4047: inp_embd = get_rows(tok_embd, tokens)): out[i][:] = dequantize(row ids[i] of w);
+ * w = n_rows_w rows of K elements in f32 / f16 / q8_0 / q4_K / q6_K; ids device i32 [n_ids]; out device f32 [n_ids][K] */
+int pkv_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, void * stream);
 
 /* Session state of the KV cache in the reference's byte format: llama_kv_cache_unified::state_write / state_read
  * (/ref/src/llama-kv-cache.cpp:848-1221; reached through llama_state_get_data / llama_state_seq_get_data,

@@ -26,8 +26,8 @@ LIB_PATH = os.environ.get("PKV_LIB_PATH") or os.path.join(_HERE, "libmi355_paged
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355_paged_kv.h")
 
 # enum pkv_type (= enum ggml_type values)
-F32, F16, Q4_0, Q8_0 = 0, 1, 2, 8
-TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0}
+F32, F16, Q4_0, Q8_0, Q4_K, Q6_K = 0, 1, 2, 8, 12, 14
+TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q6_K": Q6_K}
 # enum pkv_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SPACE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 ATTN_NO_COMBINE = 1
@@ -77,6 +77,12 @@ class AttnArgs(C.Structure):
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
+class Gemv(C.Structure):
+    """pkv_gemv"""
+    _fields_ = [("n", C.c_int32), ("silu_mul", C.c_int32), ("type_w", C.c_int32 * 3), ("w", C.c_void_p * 3), ("y", C.c_void_p * 3),
+                ("M", C.c_int64 * 3), ("K", C.c_int64), ("xq", C.c_void_p), ("residual", C.c_void_p)]
+
+
 class CacheParams(C.Structure):
     _fields_ = [("n_layer", C.c_int32), ("n_head_kv", C.c_int32), ("head_dim", C.c_int32), ("type_k", C.c_int32),
                 ("type_v", C.c_int32), ("block_size", C.c_int32), ("n_blocks", C.c_int32), ("n_seq_max", C.c_int32),
@@ -101,6 +107,8 @@ def lib() -> C.CDLL:
         L.pkv_row_size.argtypes = [C.c_int, C.c_int64]
         L.pkv_cache_create.restype = C.c_void_p
         L.pkv_attn_prefill_workspace_bytes.restype = C.c_size_t
+        L.pkv_act_image_bytes.restype = C.c_size_t
+        L.pkv_act_image_bytes.argtypes = [C.c_int64]
         L.pkv_cache_state_size.restype = C.c_int64
         L.pkv_cache_state_write.restype = C.c_int64
         L.pkv_cache_create.argtypes = [C.POINTER(CacheParams)]
@@ -460,6 +468,50 @@ def mul_mat_multi(ws, type_w: int, Ms, K: int, x, stream=None):
     mp = (C.c_int64 * n)(*[int(M) for M in Ms])
     check(lib().pkv_mul_mat_multi(n, wp, type_w, C.c_void_p(_ptr(x)), yp, mp, C.c_int64(K), C.c_int64(n_cols), C.c_void_p(_stream(stream))))
     return outs
+
+
+# ---- decode-step products for K-quant weights (pkv_gemv.hip) ---------------------------------------------------------------
+def act_image(K: int, device="cuda"):
+    """buffer for the int8-per-32 image of one activation column of K elements (pkv_act_image_bytes)"""
+    import torch
+    return torch.empty(lib().pkv_act_image_bytes(K), dtype=torch.uint8, device=device)
+
+
+def quantize_act(x, image=None, stream=None):
+    """pkv_quantize_act: x f32 [K] -> activation image"""
+    K = x.numel()
+    image = act_image(K, x.device) if image is None else image
+    check(lib().pkv_quantize_act(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(image)), C.c_int64(K), C.c_void_p(_stream(stream))))
+    return image
+
+
+def rms_norm_mul_q(x, w, eps: float, image, *, res=None, x_out=None, y=None, stream=None):
+    """pkv_rms_norm_mul_q: x_out = x + res (optional), image = quantize(rms_norm(x_out) * w), y (optional) = the f32 row"""
+    check(lib().pkv_rms_norm_mul_q(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(res)), C.c_void_p(_ptr(x_out)), C.c_void_p(_ptr(w)), C.c_void_p(_ptr(y)),
+                                   C.c_void_p(_ptr(image)), C.c_int64(x.numel()), C.c_float(eps), C.c_void_p(_stream(stream))))
+    return image
+
+
+def gemv_q(ws, types, Ms, K: int, image, outs, *, residual=None, silu_mul: bool = False, stream=None):
+    """pkv_gemv_q: up to three K-quant products on one activation image in one launch; outs = list of f32 [M_i] tensors
+    (silu_mul: outs[0] = silu(W0 x) * (W1 x), outs[1] unused; residual: outs[0] = residual + W0 x)"""
+    n = len(ws)
+    g = Gemv()
+    g.n, g.silu_mul, g.K, g.xq, g.residual = n, int(silu_mul), K, _ptr(image), _ptr(residual)
+    for i in range(n):
+        g.type_w[i], g.w[i], g.y[i], g.M[i] = int(types[i]), _ptr(ws[i]), _ptr(outs[i] if i < len(outs) else outs[0]), int(Ms[i])
+    check(lib().pkv_gemv_q(C.byref(g), C.c_void_p(_stream(stream))))
+    return outs
+
+
+def get_rows(w, type_w: int, ids, K: int, n_rows_w: int, out=None, stream=None):
+    """ggml_get_rows: out[i] = dequantize(row ids[i] of w) (pkv_get_rows); ids device i32 [n]"""
+    import torch
+    n = ids.numel()
+    out = torch.empty((n, K), dtype=torch.float32, device=ids.device) if out is None else out
+    check(lib().pkv_get_rows(C.c_void_p(_ptr(w)), type_w, C.c_void_p(_ptr(ids)), C.c_void_p(_ptr(out)), C.c_int64(n), C.c_int64(K), C.c_int64(n_rows_w),
+                             C.c_void_p(_stream(stream))))
+    return out
 
 
 # ---- llama_kv_cache mirror ---------------------------------------------------------------------------------------------

@@ -368,8 +368,11 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int off) 
 //   4. DPP reduce-scatter -> one logit per lane; softmax per wave (row_ror + permlane swaps); P -> the wave's LDS strip;
 //      PV = dot2 stream; the two half-wave sums by permlane32_swap pairs.
 //   5. second barrier, cross-wave merge (one output element per thread), one (m, l, O) partial per workgroup.
+#ifndef PKV_OCC
+#define PKV_OCC 1
+#endif
 template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0>
-__global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(const DecodeArgs a) {
+__global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decode_kernel(const DecodeArgs a) {
     Stamps<STAMP> ts;
     ts.real(0);
     ts.at(1);
@@ -386,6 +389,12 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     __shared__ __attribute__((aligned(16))) float sP[NW][TPW * G / (P16 ? 2 : 1)];  // per-wave probabilities
     __shared__ __attribute__((aligned(16))) float sO[NW][G][D];                     // per-wave partial outputs
     __shared__ __attribute__((aligned(16))) float sML[NW][G][2];                    // per-wave (max, sum)
+#ifndef PKV_WGMAX
+#define PKV_WGMAX 0
+#endif
+#if PKV_WGMAX
+    __shared__ __attribute__((aligned(16))) float sMX[G][NW];                       // per-wave head maxima (mid barrier)
+#endif
     __shared__ __attribute__((aligned(16))) QShared<KT, D, G> sQ;                   // QK^T operand (row jobs)
     __shared__ KCur<KT, D> sKc;                                                     // the new token's rows (fused step)
     __shared__ VCur<D>     sVc;
@@ -489,6 +498,32 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
             }
         }
     }
+#ifndef PKV_VSCHED
+#define PKV_VSCHED 0
+#endif
+    uint4 vreg[V_NL];
+    float vsc[V_NL][V_TL];
+    auto issue_v = [&](int i) {
+        __builtin_amdgcn_sched_barrier(0);                      // program order = issue order
+        vreg[i] = buf_load16(rs_v, v_off + i * 1024);
+        if constexpr (VT != PKV_TYPE_F16) {
+            const int tw  = wave * TPW + i * V_RPL + vl * V_TL;          // first token of this lane-load
+            const int so  = ((tw / V_TL) * NB + vc / 8) * V_TL * 2;      // its group's scales for this lane's 32-block: V_TL consecutive halfs
+            uint32_t sw[V_TL / 2];
+            if constexpr (V_TL == 4) { const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; }
+            else                     { const u4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; sw[2] = t.z; sw[3] = t.w; }
+#pragma unroll
+            for (int t = 0; t < V_TL; ++t) {
+                const float sc = h_val((uint16_t) (sw[t / 2] >> (16 * (t & 1))));
+                vsc[i][t] = tw + t < n_valid ? sc : 0.0f;       // a stale scale of a cell past the end must not reach 0 * NaN
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (PKV_VSCHED == 2) {              // every V chunk right behind the row job, ahead of the barrier (all waves: the counts must not depend on the path)
+#pragma unroll
+        for (int i = 0; i < V_NL; ++i) issue_v(i);
+    }
     __syncthreads();                    // the workgroup's FIRST barrier: Q operand (and the new token's rows) visible
 
     if (active) {   // ======== the wave's 16 tokens ========
@@ -509,40 +544,16 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     static_assert(STAMP == 0 || (KT == PKV_TYPE_F16 && VT == PKV_TYPE_F16), "the stamp build counts the f16 load stream only");
 
     // ---- QK^T: K chunk i is consumed as it lands, V chunk i is requested in its place --------------------------------------
-    uint4 vreg[V_NL];
-    float vsc[V_NL][V_TL];
     float x[NV];
-#ifndef PKV_VSCHED
-#define PKV_VSCHED 0
-#endif
 #pragma unroll
-    for (int i = 0; i < (K_NL > V_NL ? K_NL : V_NL) * (PKV_VSCHED == 1 ? 2 : 1); ++i) {
-        constexpr int NI = (K_NL > V_NL ? K_NL : V_NL);
-        const bool do_k = PKV_VSCHED == 1 ? (i >= NI) : true, do_v = PKV_VSCHED == 1 ? (i < NI) : true;
-        const int ii = i % NI;
-        if (do_k && ii < K_NL) {
+    for (int i = 0; i < (K_NL > V_NL ? K_NL : V_NL); ++i) {
+        if (i < K_NL) {
             float sv[G];
-            k_dot<KT, D, G>(kreg[ii], ksc[ii], qf, sv);
+            k_dot<KT, D, G>(kreg[i], ksc[i], qf, sv);
 #pragma unroll
-            for (int g = 0; g < G; ++g) x[ii * G + g] = sv[g];
+            for (int g = 0; g < G; ++g) x[i * G + g] = sv[g];
         }
-        if (do_v && ii < V_NL) { const int i = ii;
-            __builtin_amdgcn_sched_barrier(0);                  // program order = issue order: V chunk i goes out here, not earlier
-            vreg[i] = buf_load16(rs_v, v_off + i * 1024);
-            if constexpr (VT != PKV_TYPE_F16) {
-                const int tw  = wave * TPW + i * V_RPL + vl * V_TL;          // first token of this lane-load
-                const int so  = ((tw / V_TL) * NB + vc / 8) * V_TL * 2;      // its group's scales for this lane's 32-block: V_TL consecutive halfs
-                uint32_t sw[V_TL / 2];
-                if constexpr (V_TL == 4) { const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; }
-                else                     { const u4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; sw[2] = t.z; sw[3] = t.w; }
-#pragma unroll
-                for (int t = 0; t < V_TL; ++t) {
-                    const float sc = h_val((uint16_t) (sw[t / 2] >> (16 * (t & 1))));
-                    vsc[i][t] = tw + t < n_valid ? sc : 0.0f;   // a stale scale of a cell past the end must not reach 0 * NaN
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        if (PKV_VSCHED == 0 && i < V_NL) issue_v(i);            // V chunk i goes out when K chunk i has been consumed
     }
     reduce_scatter<NV, K_LPR>(x, lane);
     ts.at(5);                           // QK^T done, every V load issued
@@ -569,6 +580,18 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
         v += mv;                                              // :12365 (slope 1: ALiBi goes through pkv_attn_prefill)
         x[j]  = ok ? v : -INFINITY;                           // mask == -inf -> skipped cell (:12349)
         mg[j] = head_reduce2<TPW, true>(x[j]);                // wave-local max of this head
+#if PKV_WGMAX
+        if ((lane >> ilog2(64 / TPW)) == 0) sMX[idx % G][wv] = mg[j];
+    }
+    __syncthreads();                    // mid barrier: every wave's head maxima are in LDS
+#pragma unroll
+    for (int j = 0; j < NVF; ++j) {
+        const int g = (cidx + j) % G;
+        float M = sMX[g][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) M = fmaxf(M, sMX[g][w]);
+        mg[j] = M;                                            // the WORKGROUP's max: every wave weighs against the same one
+#endif
         pj[j] = mg[j] == -INFINITY ? 0.0f : __expf(x[j] - mg[j]);
         if constexpr (P16) pj[j] = (float) (_Float16) pj[j];  // the weight PV really applies; l is summed from the same values
     }
@@ -680,6 +703,10 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
     } else {        // ======== a wave past the end of the sequence: the empty partial ========
         if (lane < G) *reinterpret_cast<float2 *>(&sML[wv][lane][0]) = make_float2(-INFINITY, 0.0f);
         for (int e = lane; e < G * D; e += 64) sO[wv][e / D][e % D] = 0.0f;
+#if PKV_WGMAX
+        if (lane < G) sMX[lane][wv] = -INFINITY;
+        __syncthreads();                // the mid barrier of the active waves
+#endif
     }
     __syncthreads();
     ts.at(9);                           // every wave of the workgroup has arrived
@@ -695,14 +722,19 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW)) attn_decode_kernel(
             float M = mw[0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) M = fmaxf(M, mw[w]);
-            const float Mf = fmaxf(M, -3.0e38f);               // all waves empty: exp(-inf - Mf) = 0, never -inf - -inf
             float o = 0.0f, l = 0.0f;
+#if PKV_WGMAX
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { o += sO[w][g][d]; l += lw[w]; }   // every wave weighed against the workgroup's max already
+#else
+            const float Mf = fmaxf(M, -3.0e38f);               // all waves empty: exp(-inf - Mf) = 0, never -inf - -inf
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 const float f = __expf(mw[w] - Mf);
                 o = fmaf(sO[w][g][d], f, o);
                 l = fmaf(lw[w], f, l);
             }
+#endif
             const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
             a.part_o[pi * D + d] = o;
             if (d == 0) *reinterpret_cast<float2 *>(&a.part_ml[pi * 2]) = make_float2(M, l);

@@ -530,6 +530,32 @@ int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x
     return launch_mul_mat_multi(n, w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
 }
 
+size_t pkv_act_image_bytes(int64_t K) { return act_image_bytes(K); }
+int pkv_quantize_act(const float * x, void * image, int64_t K, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && image && ((uintptr_t) x % 16) == 0 && ((uintptr_t) image % 16) == 0, "pkv_quantize_act: null or misaligned pointer");
+    return launch_quantize_act(x, image, K, (hipStream_t) stream);
+}
+int pkv_rms_norm_mul_q(const float * x, const float * res, float * x_out, const float * w, float * y, void * image, int64_t ne0, float eps, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && w && image && ((res == nullptr) == (x_out == nullptr)) && eps >= 0.0f, "pkv_rms_norm_mul_q: bad arguments");
+    PKV_REQUIRE(((uintptr_t) x % 16) == 0 && ((uintptr_t) w % 16) == 0 && ((uintptr_t) image % 16) == 0, "pkv_rms_norm_mul_q: pointers must be 16-byte aligned");
+    return launch_rms_norm_mul_q(x, res, x_out, w, y, image, ne0, eps, (hipStream_t) stream);
+}
+int pkv_gemv_q(const pkv_gemv * g, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(g != nullptr, "pkv_gemv_q: null args");
+    for (int i = 0; i < g->n && i < PKV_GEMV_MAX; ++i)
+        PKV_REQUIRE(((uintptr_t) g->w[i] % 16) == 0, "pkv_gemv_q: weight matrix %d must be 16-byte aligned", i);
+    return launch_gemv(*g, (hipStream_t) stream);
+}
+int pkv_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(w && ids && out && n_ids >= 0 && K > 0 && n_rows_w > 0, "pkv_get_rows: bad arguments");
+    PKV_REQUIRE(K % (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K ? 256 : (type_w == PKV_TYPE_Q8_0 ? 32 : 1)) == 0, "pkv_get_rows: K does not fill whole blocks");
+    return launch_get_rows(w, type_w, ids, out, n_ids, K, n_rows_w, (hipStream_t) stream);
+}
+
 // ---- session state: llama_kv_cache_unified::state_write / state_read in the reference's byte format ------------------------
 // (/ref/src/llama-kv-cache.cpp:848-1221)   u32 cell_count | per cell: i32 pos, u32 n_seq_id, i32 seq_id[n_seq_id] |
 //   u32 v_trans | u32 n_layer | per layer: i32 type_k, u64 k_size_row, K rows | per layer: i32 type_v, u64 v_size_row, V rows

@@ -40,7 +40,8 @@ __host__ __device__ inline size_t row_size(int type, int64_t ne) {
          : type == PKV_TYPE_F16  ? (size_t) ne * 2
          : type == PKV_TYPE_Q8_0 ? (size_t) (ne / PKV_QK) * 34
          : type == PKV_TYPE_Q4_0 ? (size_t) (ne / PKV_QK) * 18
-         : type == PKV_TYPE_Q4_K ? (size_t) (ne / 256) * 144 : 0;
+         : type == PKV_TYPE_Q4_K ? (size_t) (ne / 256) * 144
+         : type == PKV_TYPE_Q6_K ? (size_t) (ne / 256) * 210 : 0;
 }
 inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0; }
 
@@ -85,6 +86,12 @@ int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64
 int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                          hipStream_t st);
 int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);
+// decode-step products for K-quant weights (pkv_gemv.hip)
+size_t act_image_bytes(int64_t K);
+int launch_quantize_act(const float * x, void * img, int64_t K, hipStream_t st);
+int launch_gemv(const pkv_gemv & g, hipStream_t st);
+int launch_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, hipStream_t st);
+int launch_rms_norm_mul_q(const float * x, const float * res, float * x_out, const float * w, float * y, void * img, int64_t ne0, float eps, hipStream_t st);
 int launch_qkv_store_mirror(const pkv_qkv_store_args * p, const RopeDev & r, hipStream_t st);
 int launch_rope_convert_mirror(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, float * roped, void * dst, int type, void * pool,
                                int64_t cell0, int64_t n_tok, int n_head_kv, int D, int BS, const RopeDev & r, hipStream_t st);

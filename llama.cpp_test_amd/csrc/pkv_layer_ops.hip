@@ -24,8 +24,9 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 constexpr int RMS_MAX_V4 = 8;   // float4 per thread: rows of up to 256 * 4 * 8 = 8192 elements
 // res / x_out (both or neither): the residual add in front of the norm, x_out = x + res is what gets normalised (ADD -> RMS_NORM -> MUL
 // of a llama layer, /ref/src/llama-model.cpp: ffn_inp = attn_out + inpL, then build_norm) — each thread adds, stores and keeps its own elements
+// img (optional, in_regs rows with ne0 % 256 == 0, one row): the scaled row also leaves as the int8-per-32 activation image of pkv_gemv.hip
 __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, const float * res, float * x_out, const float * w, float * y_norm, float * y,
-                                                           int64_t ne0, float eps) {
+                                                           int64_t ne0, float eps, char * img = nullptr) {
     __shared__ float sred[4];
     const size_t ro = (size_t) blockIdx.x * ne0;
     const float * xr = x + ro;
@@ -79,6 +80,20 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
                 const float4 n = make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
                 if (y_norm) reinterpret_cast<float4 *>(y_norm + ro)[i] = n;
                 if (y) reinterpret_cast<float4 *>(y + ro)[i] = w ? make_float4(n.x * wv[j].x, n.y * wv[j].y, n.z * wv[j].z, n.w * wv[j].w) : n;
+            }
+            if (img) {   // 8 consecutive threads hold one 32-element block (ne0 % 256 == 0: a block never straddles the row's end)
+                const float4 o = w ? make_float4(v[j].x * scale * wv[j].x, v[j].y * scale * wv[j].y, v[j].z * scale * wv[j].z, v[j].w * scale * wv[j].w)
+                                   : make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
+                float amax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+                amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+                const float dq = amax / 127.0f, id = amax != 0.0f ? 127.0f / amax : 0.0f;
+                const int q0 = (int) __builtin_rintf(o.x * id), q1 = (int) __builtin_rintf(o.y * id), q2 = (int) __builtin_rintf(o.z * id), q3 = (int) __builtin_rintf(o.w * id);
+                int qs = q0 + q1 + q2 + q3;
+                qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
+                if (i < n4) {
+                    reinterpret_cast<uint32_t *>(img)[i] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+                    if ((i & 7) == 0) { float * dd = reinterpret_cast<float *>(img + ne0); dd[i >> 3] = dq; dd[(ne0 >> 5) + (i >> 3)] = dq * (float) qs; }
+                }
             }
         }
     } else {
@@ -359,14 +374,20 @@ int grid_for(int64_t n) { const int64_t g = (n + 255) / 256; return (int) (g < 1
 
 int launch_rms_norm(const float * x, float * y, int64_t n_rows, int64_t ne0, float eps, hipStream_t st) {
     if (n_rows == 0) return PKV_OK;
-    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, (const float *) nullptr, (float *) nullptr, (const float *) nullptr, (float *) nullptr, y, ne0, eps);
+    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, (const float *) nullptr, (float *) nullptr, (const float *) nullptr, (float *) nullptr, y, ne0, eps, (char *) nullptr);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
 int launch_rms_norm_mul(const float * x, const float * res, float * x_out, const float * w, float * y_norm, float * y, int64_t n_rows, int64_t ne0, float eps,
                         hipStream_t st) {
     if (n_rows == 0) return PKV_OK;
-    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, res, x_out, w, y_norm, y, ne0, eps);
+    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3((unsigned) n_rows), dim3(256), 0, st, x, res, x_out, w, y_norm, y, ne0, eps, (char *) nullptr);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+int launch_rms_norm_mul_q(const float * x, const float * res, float * x_out, const float * w, float * y, void * img, int64_t ne0, float eps, hipStream_t st) {
+    PKV_REQUIRE(ne0 > 0 && ne0 % 256 == 0 && ne0 <= 256 * 4 * RMS_MAX_V4, "pkv_rms_norm_mul_q: row length must be a multiple of 256 up to %d", 256 * 4 * RMS_MAX_V4);
+    hipLaunchKernelGGL(rms_norm_mul_kernel, dim3(1), dim3(256), 0, st, x, res, x_out, w, (float *) nullptr, y, ne0, eps, (char *) img);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

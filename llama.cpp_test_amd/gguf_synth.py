@@ -23,8 +23,8 @@ T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I6
 _SCALAR = {T_U8: "<B", T_I8: "<b", T_U16: "<H", T_I16: "<h", T_U32: "<I", T_I32: "<i", T_F32: "<f", T_BOOL: "<?", T_U64: "<Q",
            T_I64: "<q", T_F64: "<d"}
 # ggml_type ids used here (/root/reference/ggml/include/ggml.h:351-392)
-GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0, GGML_Q4_K = 0, 1, 2, 8, 12
-_BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144)}   # (elements, bytes) per block
+GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0, GGML_Q4_K, GGML_Q6_K = 0, 1, 2, 8, 12, 14
+_BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144), GGML_Q6_K: (256, 210)}   # (elements, bytes) per block
 
 
 def row_bytes(t: int, ne0: int) -> int:
@@ -74,6 +74,34 @@ def random_q4_K(rng, n_rows: int, ne0: int) -> bytes:
     out[:, 4:16] = rng.integers(0, 256, (nb, 12), dtype=np.uint8)
     out[:, 16:] = rng.integers(0, 256, (nb, 128), dtype=np.uint8)
     return out.tobytes()
+
+
+def random_q6_K(rng, n_rows: int, ne0: int) -> bytes:
+    """random but well-formed block_q6_K rows (/root/reference/ggml/src/ggml-common.h:309-319: ql[128] low nibbles, qh[64] high 2 bits, 16 int8
+    scales, f16 d): dequantized values d * sc * (q - 32) look like N(0, 1/ne0) weights (q uniform 0..63: std 18.5, |sc| ~ 64)"""
+    nb = n_rows * (ne0 // 256)
+    out = np.empty((nb, 210), np.uint8)
+    out[:, 0:192] = rng.integers(0, 256, (nb, 192), dtype=np.uint8)
+    out[:, 192:208] = (rng.integers(40, 100, (nb, 16)) * rng.choice([-1, 1], (nb, 16))).astype(np.int8).view(np.uint8)
+    d = (rng.uniform(0.7, 1.3, nb) / (np.sqrt(ne0) * 18.5 * 70.0)).astype(np.float16)
+    out[:, 208:210] = d.view(np.uint8).reshape(nb, 2)
+    return out.tobytes()
+
+
+def dequantize_q6_K(raw, ne0: int) -> np.ndarray:
+    """dequantize_row_q6_K (/root/reference/ggml/src/ggml-quants.c:1690-1719) in numpy: rows of ne0 f32"""
+    b = np.frombuffer(raw, np.uint8).reshape(-1, 210)
+    d = b[:, 208:210].copy().view(np.float16).astype(np.float32)[:, 0]
+    ql, qh, sc = b[:, 0:128].astype(np.int32), b[:, 128:192].astype(np.int32), b[:, 192:208].copy().view(np.int8).astype(np.float32)
+    out = np.empty((b.shape[0], 256), np.float32)
+    for n in range(2):
+        for j in range(4):
+            lq = ql[:, 64 * n + 32 * (j & 1):64 * n + 32 * (j & 1) + 32]
+            lq = (lq >> 4) if (j >> 1) else (lq & 0xF)
+            q = (lq | (((qh[:, 32 * n:32 * n + 32] >> (2 * j)) & 3) << 4)) - 32
+            s = sc[:, 8 * n + 2 * j:8 * n + 2 * j + 2].repeat(16, axis=1)          # is = l / 16
+            out[:, 128 * n + 32 * j:128 * n + 32 * j + 32] = (d[:, None] * s) * q.astype(np.float32)   # d * sc * q: left to right, f32
+    return out.reshape(-1, ne0)
 
 
 def dequantize_q4_K(raw, ne0: int) -> np.ndarray:

@@ -59,6 +59,17 @@ def test_q4_K_blocks_dequantize_like_the_reference(G, O):
     assert np.array_equal(mine, ref) and 0.5 / 32 < mine.std() < 2.0 / 32
 
 
+def test_q6_K_blocks_dequantize_like_the_reference(G, O):
+    """the same for block_q6_K (what a Q4_K_M file keeps attn_v / ffn_down / output in): dequantize_row_q6_K bit for bit"""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built")
+    O.ref_rope(np.zeros((1, 1, 64), np.float32), np.zeros(1, np.int32), n_dims=64)
+    raw = G.random_q6_K(np.random.default_rng(4), 5, 1024)
+    mine = G.dequantize_q6_K(raw, 1024)
+    ref = O.ref_to_float(14, np.frombuffer(raw, np.uint8).reshape(5, -1), 1024)
+    assert np.array_equal(mine, ref) and 0.5 / 32 < mine.std() < 2.0 / 32
+
+
 @pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref_kv.so not built (needs /root/reference)")
 @pytest.mark.parametrize("wtype", ["f16", "q8_0", "f32", "q4_K"])
 def test_reference_parser_reads_our_files_identically(G, tmp_path, wtype):

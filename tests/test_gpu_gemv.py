@@ -1,0 +1,138 @@
+"""-m gpu: the decode-step products of csrc/pkv_gemv.hip through the C ABI — pkv_quantize_act, pkv_rms_norm_mul_q, pkv_gemv_q (q4_K / q6_K rows,
+up to three matrices per launch, residual and SiLU(gate) * up epilogues) and pkv_get_rows — against exact (f64) arithmetic on the same
+stored weights.  The weight rows are random well-formed block_q4_K / block_q6_K whose numpy dequantizers are bit-equal to the reference's
+(tests/test_gguf.py).  Bars: tight (f32 accumulation) against the arithmetic the kernel states — int8-per-32 activations, integer dots —
+and the reference harness' MUL_MAT bar (NMSE 5e-4, tests/test-backend-ops.cpp: we ask 1e-4) against the unquantized product."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def quant_act_ref(x):
+    K = x.shape[-1]
+    xb = x.reshape(K // 32, 32)
+    amax = np.abs(xb).max(-1, keepdims=True)
+    dq = (amax / np.float32(127.0)).astype(np.float32)
+    idq = np.where(amax != 0, np.float32(127.0) / np.where(amax != 0, amax, 1), 0).astype(np.float32)
+    q = np.rint((xb * idq).astype(np.float32))
+    return q.astype(np.int8), dq[:, 0], (dq.astype(np.float64) * q).reshape(K)
+
+
+def weights(G, rng, t, M, K):
+    raw = (G.random_q4_K if t == 12 else G.random_q6_K)(rng, M, K)
+    wd = (G.dequantize_q4_K if t == 12 else G.dequantize_q6_K)(raw, K).astype(np.float64)
+    return dev(np.frombuffer(raw, np.uint8).copy()), wd
+
+
+def check(y, ref_q, ref, K):
+    assert np.abs(y - ref_q).max() <= 3e-6 * max(1.0, np.abs(ref_q).max()) * np.sqrt(K / 256)
+    assert float(((y - ref) ** 2).sum() / (ref ** 2).sum()) <= 1e-4
+
+
+def test_quantize_act_image(pkv):
+    rng = np.random.default_rng(0)
+    for K in (256, 4096, 14336):
+        x = (rng.standard_normal(K) * rng.choice([1e-3, 1.0, 50.0], K)).astype(np.float32)
+        x[32:64] = 0.0                                             # an all-zero block: d = 0, q = 0
+        img = pkv.quantize_act(dev(x)).cpu().numpy()
+        q, d, _ = quant_act_ref(x)
+        assert np.array_equal(img[:K].view(np.int8), q.reshape(-1))
+        assert np.array_equal(img[K:K + K // 8].view(np.float32), d)
+        assert np.array_equal(img[K + K // 8:].view(np.float32), d * q.sum(-1).astype(np.float32))
+
+
+@pytest.mark.parametrize("tname,M,K", [("q4_K", 4096, 4096), ("q4_K", 1024, 4096), ("q4_K", 4096, 14336), ("q4_K", 14336, 4096), ("q4_K", 6, 256),
+                                       ("q4_K", 1030, 768), ("q6_K", 4096, 4096), ("q6_K", 1024, 4096), ("q6_K", 4096, 14336), ("q6_K", 128256, 4096),
+                                       ("q6_K", 10, 512), ("q4_K", 512, 28672)])
+def test_gemv_single(pkv, tname, M, K):
+    from llama_cpp_test_amd import gguf_synth as G
+    t = {"q4_K": 12, "q6_K": 14}[tname]
+    rng = np.random.default_rng(M + K + t)
+    if M > 20000:                                                  # the lm_head shape: a few thousand distinct rows repeated keep the host side quick
+        wb0, wd0 = weights(G, rng, t, 2004, K)
+        rep = M // 2004
+        wb, wd = wb0.repeat(rep), np.tile(wd0, (rep, 1))
+    else:
+        wb, wd = weights(G, rng, t, M, K)
+    x = rng.standard_normal(K).astype(np.float32)
+    img = pkv.quantize_act(dev(x))
+    y = torch.zeros(M, device="cuda")
+    pkv.gemv_q([wb], [t], [M], K, img, [y])
+    _, _, xh = quant_act_ref(x)
+    check(y.cpu().numpy(), wd @ xh, wd @ x.astype(np.float64), K)
+    # residual epilogue, in place on the residual
+    r = rng.standard_normal(M).astype(np.float32)
+    yr = dev(r.copy())
+    pkv.gemv_q([wb], [t], [M], K, img, [yr], residual=yr)
+    assert np.abs(yr.cpu().numpy() - (r + y.cpu().numpy())).max() <= 1e-6 * max(1.0, float(np.abs(r).max()))
+
+
+@pytest.mark.parametrize("types,Ms,K", [(("q4_K", "q4_K", "q4_K"), (4096, 1024, 1024), 4096), (("q4_K", "q4_K", "q6_K"), (4096, 1024, 1024), 4096),
+                                        (("q6_K", "q4_K"), (64, 130), 768), (("q4_K", "q6_K", "q4_K"), (2, 4, 6), 256)])
+def test_gemv_multi_equals_single(pkv, types, Ms, K):
+    """products that share the activation image in ONE launch == the separate launches, bit for bit, mixed weight types included"""
+    from llama_cpp_test_amd import gguf_synth as G
+    rng = np.random.default_rng(sum(Ms) + K)
+    ts = [{"q4_K": 12, "q6_K": 14}[n] for n in types]
+    ws = [weights(G, rng, t, M, K)[0] for t, M in zip(ts, Ms)]
+    img = pkv.quantize_act(dev(rng.standard_normal(K).astype(np.float32)))
+    outs = [torch.zeros(M, device="cuda") for M in Ms]
+    pkv.gemv_q(ws, ts, Ms, K, img, outs)
+    for w, t, M, y in zip(ws, ts, Ms, outs):
+        one = torch.zeros(M, device="cuda")
+        pkv.gemv_q([w], [t], [M], K, img, [one])
+        assert torch.equal(y, one)
+
+
+@pytest.mark.parametrize("tg,tu,M,K", [("q4_K", "q4_K", 14336, 4096), ("q4_K", "q6_K", 300, 1024)])
+def test_gemv_swiglu(pkv, tg, tu, M, K):
+    """gate + up + SiLU(gate) * up in one launch == silu(W_gate x) * (W_up x) of the separate products"""
+    from llama_cpp_test_amd import gguf_synth as G
+    rng = np.random.default_rng(M + K)
+    t0, t1 = {"q4_K": 12, "q6_K": 14}[tg], {"q4_K": 12, "q6_K": 14}[tu]
+    (wg, _), (wu, _) = weights(G, rng, t0, M, K), weights(G, rng, t1, M, K)
+    img = pkv.quantize_act(dev(rng.standard_normal(K).astype(np.float32)))
+    g, u, y = (torch.zeros(M, device="cuda") for _ in range(3))
+    pkv.gemv_q([wg, wu], [t0, t1], [M, M], K, img, [g, u])
+    pkv.gemv_q([wg, wu], [t0, t1], [M, M], K, img, [y], silu_mul=True)
+    gd, ud = g.double().cpu().numpy(), u.double().cpu().numpy()
+    want = gd / (1 + np.exp(-gd)) * ud
+    assert np.abs(y.cpu().numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
+def test_rms_norm_mul_q(pkv):
+    """rms_norm(x [+ res]) * w straight into the activation image == pkv_add_rms_norm_mul_f32 followed by pkv_quantize_act"""
+    rng = np.random.default_rng(3)
+    for K in (256, 2048, 4096, 8192):
+        x, r, w = (dev(rng.standard_normal(K).astype(np.float32) * s) for s in (3.0, 1.0, 1.0))
+        y = torch.empty(K, device="cuda")
+        img = pkv.rms_norm_mul_q(x, w, 1e-5, pkv.act_image(K), y=y)
+        want = pkv.rms_norm_mul(x.reshape(1, K), w, 1e-5).reshape(K)
+        assert torch.equal(y, want) and torch.equal(img, pkv.quantize_act(want))
+        xo = torch.empty(K, device="cuda")
+        img2 = pkv.rms_norm_mul_q(x, w, 1e-5, pkv.act_image(K), res=r, x_out=xo)
+        s_, n_ = pkv.add_rms_norm_mul(x.reshape(1, K), r.reshape(1, K), w, 1e-5)
+        assert torch.equal(xo, s_.reshape(K)) and torch.equal(img2, pkv.quantize_act(n_.reshape(K)))
+
+
+@pytest.mark.parametrize("tname", ["f32", "f16", "q8_0", "q4_K", "q6_K"])
+def test_get_rows(pkv, O, tname):
+    """ggml_get_rows: the token-embedding lookup; values = the reference's dequantization of the picked rows, bit for bit"""
+    from llama_cpp_test_amd import gguf_synth as G
+    t = {"f32": 0, "f16": 1, "q8_0": 8, "q4_K": 12, "q6_K": 14}[tname]
+    rng = np.random.default_rng(t)
+    n_rows, K = 300, 1024
+    if t in (12, 14):
+        raw = (G.random_q4_K if t == 12 else G.random_q6_K)(rng, n_rows, K)
+        wb, wd = np.frombuffer(raw, np.uint8).copy(), (G.dequantize_q4_K if t == 12 else G.dequantize_q6_K)(raw, K)
+    else:
+        w = (rng.standard_normal((n_rows, K)) / 32).astype(np.float32)
+        wb = w.view(np.uint8) if t == 0 else (O.from_float(t, w, variant="ref") if t == 8 else O.from_float(t, w))
+        wd = w if t == 0 else O.to_float(t, wb, K)
+    ids = np.array([5, 0, 299, 5, 17, 123], np.int32)
+    out = pkv.get_rows(dev(np.ascontiguousarray(wb).reshape(-1)), t, dev(ids), K, n_rows).cpu().numpy()
+    assert np.array_equal(out, np.asarray(wd).reshape(n_rows, K)[ids])

@@ -2,8 +2,9 @@
 all through the C ABI, against the CPU oracle / golden vectors.
 
 Bar: bytes written into the pools are BIT-EXACT with what the reference's ggml_cpy stores (f16 RN, q8_0 AVX2-branch
-rounding, q4_0 ref) when the input is identical; RoPE is f32 math with device cosf/sinf, tolerance 2e-6 absolute on
-|x| <= 1 (the reference's own backend tolerance is NMSE 1e-7, tests/test-backend-ops.cpp:321-323)."""
+rounding, q4_0 ref) when the input is identical; RoPE is BIT-EXACT too since r02: the device restates the host libm's
+cosf / sinf operation by operation (pkv_rowcodec.h: libm_cosf / libm_sinf; oracle/check_trig.c) and rounds the rotation as the pinned
+reference build does (no FMA contraction)."""
 import numpy as np
 import pytest
 import torch
@@ -30,8 +31,7 @@ def test_rope_golden(pkv, golden):
         out = pkv.rope_f32(x, dev(g[f"{name}__pos"]), rp)
         torch.cuda.synchronize()
         ref = g[f"{name}__out"]
-        assert np.abs(out.cpu().numpy() - ref).max() <= 2e-6, name
-        assert nmse(out.cpu().numpy(), ref) <= 1e-7, name
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), name   # the reference's bits
         # in place + inverse gives the input back (times mscale^2 when YaRN / attn_factor scale the rotation)
         pkv.rope_f32(out, dev(g[f"{name}__pos"]), rp, inverse=True, out=out)
         m = kw["attn_factor"] * (1.0 + 0.1 * np.log(1.0 / kw["freq_scale"]) if kw["ext_factor"] != 0 else 1.0)
@@ -69,8 +69,7 @@ def test_kv_store_bit_exact(pkv, O, golden, tk, tv, D):
 
 @pytest.mark.parametrize("tk", TYPES)
 def test_kv_store_fused_rope(pkv, O, tk):
-    """RoPE(K) fused into the store == oracle rope followed by the oracle codec, up to cosf/sinf ulps: compare the
-    dequantized rows; quantized rows may differ by one quantum where a value sits on a rounding boundary."""
+    """RoPE(K) fused into the store == oracle rope followed by the oracle codec, bit for bit (libm-exact device trig, r02)"""
     rng = np.random.default_rng(5 + tk)
     D, nkv, bs, n_tok = 128, 8, 128, 96
     k = rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32)
@@ -86,10 +85,7 @@ def test_kv_store_fused_rope(pkv, O, tk):
                                        block_size=bs), D)
     roped = O.rope(k, pos, ff, n_dims=128)
     ref = O.to_float(tk, O.from_float(tk, roped), D).transpose(1, 0, 2)
-    quantum = {1: 1e-3, 8: 1.0 / 127, 2: 1.0 / 7}[tk]
-    assert np.abs(got - ref).max() <= quantum * 1.01
-    assert (np.abs(got - ref) > 1e-6).mean() < 2e-3          # almost everywhere identical
-    assert nmse(got, roped.transpose(1, 0, 2)) <= nmse(ref, roped.transpose(1, 0, 2)) * 1.05 + 1e-9
+    assert np.array_equal(got, ref)                          # RoPE + convert: the same stored values as the CPU reference, everywhere
 
 
 @pytest.mark.parametrize("t", TYPES)
@@ -141,9 +137,7 @@ def test_k_shift_in_place(pkv, O, tk):
     same[nz] = False
     assert np.array_equal(got.transpose(1, 0, 2)[same], rows[same])          # untouched cells (and delta == 0) intact
     g, e = O.to_float(tk, got.transpose(1, 0, 2), D), O.to_float(tk, exp, D)
-    quantum = {1: 1e-3, 8: 2.0 / 127, 2: 2.0 / 7}[tk]
-    assert np.abs(g - e).max() <= quantum * 1.01
-    assert (np.abs(g - e) > 1e-6).mean() < 5e-3
+    assert np.array_equal(g, e)                              # dequantize -> rope(delta) -> requantize: the reference's values exactly
 
 
 def test_copy_blocks(pkv):
@@ -241,12 +235,11 @@ def test_cache_device_update_cow_shift_defrag(pkv, O, tk, tv):
     assert c.has_shift()
     c.update(rp)
     assert not c.has_shift()
-    quantum = {1: 2e-3, 8: 2.0 / 127, 2: 2.0 / 7}[tk]
-    check(quantum)                                             # sequence 1 must be untouched (CoW before the shift)
+    check(0.0)                                                 # sequence 1 must be untouched (CoW before the shift); the shifted K rows are the CPU's values exactly
     c.defrag()
     c.update(rp)
     assert c.seq_slot_pos(0).tolist() == list(range(161))
-    check(quantum)
+    check(0.0)
     c.close()
 
 

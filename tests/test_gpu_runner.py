@@ -44,9 +44,8 @@ def test_runner_matches_dense_model(pkv, O, tk):
                 kc = np.stack(model[s]["k"][il][:upto]).transpose(1, 0, 2)
                 vc = np.stack(model[s]["v"][il][:upto]).transpose(1, 0, 2)
                 ref = O.flash_attn_ext(qr[t][:, None, :], kc, vc, None, type_k=tk, type_v=tk, scale=D ** -0.5)[0]
-                # RoPE runs with device cosf/sinf: a K element that lands on a q8_0 rounding boundary may be stored one quantum
-                # (|x|max/127) away from the CPU's, which moves a few-cell softmax by a few 1e-3
-                assert np.abs(got[t] - ref).max() <= (2.5e-3 if tk == 1 else 8e-3), (il, t, s)
+                # the cache holds the CPU's bits (RoPE is libm-exact on the device): north_star's 1e-3 on the attention output
+                assert np.abs(got[t] - ref).max() <= 1e-3, (il, t, s)
                 assert nmse(got[t], ref) <= 5e-4
 
     # three prompts in ONE ubatch (prefill kernel, ragged)
