@@ -203,6 +203,110 @@ def cpu_baseline(w: Workload, pkv, budget_s: float = 20.0):
                       f"median {t_layer * 1e3:.2f} ms/layer, extrapolated to {g['n_layer']} layers; KV store + RoPE excluded"}
 
 
+LLAMA3_8B = dict(n_layer=32, n_embd=4096, n_head=32, n_head_kv=8, n_ff=14336, n_vocab=128256, n_ctx=8192, rope_freq_base=500000.0)
+
+
+def e2e_record(pkv, torch, *, ctx: int, steps: int, warmup: int, cpu: bool):
+    """The metric's other half: a FULL decode step of Llama-3-8B geometry (Q4_K_M tensor-type mix: q4_K with q6_K output / attn_v / ffn_down
+    of the use_more_bits layers; synthetic, seeded, well-formed blocks), ONE sequence at `ctx`, run by the repo's own host loop
+    (llama.cpp_test_amd/decoder.py: own GGUF loader -> pkv_get_rows / pkv_rms_norm_mul_q / pkv_gemv_q / pkv_attn_decode_step through the C ABI),
+    captured as ONE hipGraph per token and replayed: no reference code in the timed region.  roofline = (weight bytes one step reads +
+    algorithmic KV bytes) / time / 8 TB/s.  cpu_baseline = the reference's own llama_decode on its CPU backend (oracle/_ref, CHECKER ONLY) on
+    the same file at the same depth, context restored from a session blob in the reference's format."""
+    import shutil
+    import tempfile
+    from llama_cpp_test_amd import gguf_synth as G
+    from llama_cpp_test_amd.decoder import LlamaDecoder
+    tmp = tempfile.mkdtemp(dir="/tmp", prefix="pkv_e2e_")
+    path = os.path.join(tmp, "llama3-8b-synth-q4km.gguf")
+    rec = {}
+    try:
+        t0 = time.time()
+        G.synth_llama(path, wtype=G.GGML_Q4_K, k_mix=True, seed=8, **LLAMA3_8B)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        dec = LlamaDecoder(path, n_ctx=ctx, type_k=pkv.F16, type_v=pkv.F16)
+        dec.fill_kv_synthetic(ctx - 1, seed=3)
+        dec._place(12345 % LLAMA3_8B["n_vocab"], ctx - 1)            # the token that makes the sequence `ctx` long: every replay decodes it again
+        t_load = time.time() - t0
+        side = torch.cuda.Stream()
+        g = dec.capture(side)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        wb = dec.weight_bytes()
+        kvb = LLAMA3_8B["n_layer"] * algorithmic_bytes(ctx, pkv.F16, pkv.F16, pkv, GEOM)
+        finite = bool(torch.isfinite(dec.logits).all().item())
+        n_types = {}
+        for name, (t, ty, ne) in dec.w.items():
+            n_types[ty] = n_types.get(ty, 0) + t.numel()
+        rec = {"value": round(1.0 / dt, 2), "unit": "tok/s", "ms_per_token": round(dt * 1e3, 4), "steps": steps, "warmup": warmup,
+               "workload": f"Llama-3-8B geometry, Q4_K_M tensor mix (synthetic GGUF {os.path.getsize(path) / 2**30:.2f} GiB: "
+                           + ", ".join(f"{ {0: 'f32', 12: 'q4_K', 14: 'q6_K'}.get(k, k)} {v / 2**20:.0f} MiB" for k, v in sorted(n_types.items()))
+                           + f"), f16 KV, 1 sequence at ctx {ctx}, single-token decode incl. lm_head",
+               "host_loop": "llama.cpp_test_amd/decoder.py through the C ABI, one hipGraph per token (own GGUF loader; no reference code)",
+               "logits_finite": finite, "weight_bytes": wb, "kv_bytes": kvb, "setup_s": {"synth_gguf": round(t_gen, 1), "load_fill_capture": round(t_load, 1)},
+               "roofline": {"bound": "hbm", "achieved": round((wb + kvb) / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round((wb + kvb) / dt / 1e9 / HBM_PEAK_GBS, 4)}}
+        dec.close()
+        del dec
+        torch.cuda.empty_cache()
+        if cpu:
+            rec["cpu_baseline"] = e2e_cpu_baseline(path, ctx)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return rec
+
+
+def e2e_cpu_baseline(path: str, ctx: int, steps: int = 6):
+    """CHECKER ONLY (oracle/_ref = the reference compiled in place): the reference's llama_decode on its CPU backend, same GGUF, same depth;
+    the ctx - 1 cells of context are restored with llama_state_seq_set_data from a session blob in the reference's own format"""
+    import ctypes as C
+    import struct
+    from oracle import ref_model as R
+    if not R.available():
+        return None
+    NL, HK, D = LLAMA3_8B["n_layer"], LLAMA3_8B["n_head_kv"], 128
+    n_cells = ctx - 1
+    rng = np.random.default_rng(1)
+    row = HK * D * 2
+    parts = [struct.pack("<I", n_cells)] + [struct.pack("<iI", p, 0) for p in range(n_cells)] + [struct.pack("<II", 0, NL)]
+    for kv in range(2):
+        for il in range(NL):
+            parts.append(struct.pack("<iQ", 1, row))
+            parts.append((rng.standard_normal(n_cells * HK * D, dtype=np.float32) * (0.5 if kv else 1.0)).astype(np.float16).tobytes())
+    blob = b"".join(parts)
+    L = R._lib()
+    L.refmodel_detach_capture.restype = None
+    L.refmodel_state_seq_set.restype = C.c_size_t
+    cores = min(os.cpu_count() or 1, 32)
+    h = C.c_void_p(L.refmodel_load(path.encode(), ctx + 64, 512, 1, 1, 1, 1, cores))
+    if not h:
+        return None
+    L.refmodel_detach_capture(h)
+    if L.refmodel_state_seq_set(h, blob, C.c_size_t(len(blob)), 0) != len(blob):
+        L.refmodel_free(h)
+        return None
+
+    def step(tok, pos):
+        a, p, s = np.array([tok], np.int32), np.array([pos], np.int32), np.zeros(1, np.int32)
+        return L.refmodel_decode(h, a.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), 1)
+    step(1, n_cells)
+    t0 = time.time()
+    for i in range(steps):
+        step(int(i * 13 % 32000), n_cells + 1 + i)
+    dt = (time.time() - t0) / steps
+    L.refmodel_free(h)
+    return {"value": round(1.0 / dt, 2), "unit": "tok/s", "cores": cores, "kind": "reference",
+            "sample": f"{steps} llama_decode steps of the reference's CPU backend ({cores} threads) on the same GGUF at ctx {ctx} (context restored from a session blob), {dt * 1e3:.1f} ms/token"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +324,8 @@ def main():
     ap.add_argument("--two-call", action="store_true",
                     help="pkv_qkv_prepare + pkv_attn_decode (three launches per layer) instead of the fused pkv_attn_decode_step")
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end record (full Llama-3-8B Q4_K_M decode step through the own host loop)")
+    ap.add_argument("--e2e-steps", type=int, default=30)
     args = ap.parse_args()
 
     import torch
@@ -323,6 +429,13 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, pkv)
+    if rank == 0 and world == 1 and not args.no_e2e and args.model == "8b" and args.n_seq == 1 and args.kv_type == "f16":
+        del w                                                         # the attention-path pools make room for the model
+        torch.cuda.empty_cache()
+        try:
+            line["e2e"] = e2e_record(pkv, torch, ctx=args.ctx, steps=args.e2e_steps, warmup=3, cpu=not args.no_cpu_baseline)
+        except Exception as e:                                        # the headline record must not be lost to a failure of the extra one
+            line["e2e"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

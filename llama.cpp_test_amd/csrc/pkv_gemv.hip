@@ -3,8 +3,8 @@
 // the mat-vec half of a llama decoder layer (/ref/src/llama-model.cpp:4070-4160: wq / wk / wv, wo, ffn gate / up /
 // down; lm_head :4186).  The reference's CPU backend quantizes the activation column to q8_K and runs integer dots
 // (ggml_compute_forward_mul_mat, /ref/ggml/src/ggml-cpu/ggml-cpu.c:7467-7640, vec_dot_q4_K_q8_K / vec_dot_q6_K_q8_K); here the column is
-// quantized ONCE per product group to int8 per 32 elements (finer than q8_K's 256) by pkv_quantize_act — or by the kernel that produced
-// it — and every workgroup copies the 1 byte / element image into LDS, then STREAMS its rows:
+// quantized ONCE per product group to the same q8_K integers by pkv_quantize_act — or by the kernel that produced it — and every
+// workgroup copies the 1 byte / element image into LDS, then STREAMS its rows:
 //   * block_q4_K (144 B / 256 elements, /ref/ggml/src/ggml-common.h:279-290) and block_q6_K (210 B, :309-319) rows, read exactly once;
 //   * a lane owns 64 elements (q4_K: one 64-element group = 32 bytes of nibbles; q6_K: four runs of 16 with their own scales) of one of
 //     the TWO rows a wave works on at a time, so the 64 lanes cover 2 x K / 64 groups in passes of 64 whatever K is;
@@ -24,25 +24,38 @@ __device__ __forceinline__ float wsum(float x) {
 }
 __device__ __forceinline__ float h2f(uint16_t b) { return (float) *reinterpret_cast<const _Float16 *>(&b); }
 
-// ---- activation column -> int8 per 32 elements ------------------------------------------------------------------------------
-// image: [K int8][K/32 f32 d][K/32 f32 d * sum(q)]  (d = amax / 127, q = rint(x / d): quantize_row_q8_0's rule with an f32 scale)
-__global__ void __launch_bounds__(256) quant_act_kernel(const float * x, char * img, int64_t K) {
-    const int64_t i4 = (int64_t) blockIdx.x * 256 + threadIdx.x;            // float4 index: 8 threads per 32-element block
-    const bool in = i4 * 4 < K;
-    const float4 v = in ? reinterpret_cast<const float4 *>(x)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
-    const float d = amax / 127.0f, id = amax != 0.0f ? 127.0f / amax : 0.0f;
-    const int q0 = (int) __builtin_rintf(v.x * id), q1 = (int) __builtin_rintf(v.y * id), q2 = (int) __builtin_rintf(v.z * id), q3 = (int) __builtin_rintf(v.w * id);
+// ---- activation column -> q8_K, the reference's own operand of a q4_K / q6_K product ---------------------------------------------
+// quantize_row_q8_K_ref (/ref/ggml/src/ggml-quants.c:2479-2516; the x86 CPU backend runs exactly this, ggml-cpu-quants.c:1746): per 256
+// elements iscale = -127 / max (max = the signed value of largest magnitude), q = nearest_int(iscale * x), d = 1 / iscale, plus the sums of
+// the quants.  Image: [K int8 q][K/256 f32 d][K/32 i32 sum of q per 32].  The integer dots of pkv_gemv_q then see the reference's integers:
+// a product differs from the CPU backend's only by the order of a handful of f32 additions.  (Which of two elements of equal magnitude
+// and opposite sign supplies `max` only flips the sign of d and of every q together: the products q * d are the same bits.)
+// One wave per 256-element block, 4 elements per lane.
+__device__ __forceinline__ void quant_block_q8k(const float4 v, int lane, uint32_t & packed, float & d, int & bsum32) {
+    float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    float mx = fabsf(v.x) == am ? v.x : (fabsf(v.y) == am ? v.y : (fabsf(v.z) == am ? v.z : v.w));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float oa = __shfl_xor(am, o), om = __shfl_xor(mx, o);
+        if (oa > am || (oa == am && (lane & o))) { am = oa; mx = om; }     // equal magnitudes: every lane settles on the lower lane's value
+    }
+    const float iscale = am != 0.0f ? -127.0f / mx : 0.0f;
+    const int q0 = (int) __builtin_rintf(iscale * v.x), q1 = (int) __builtin_rintf(iscale * v.y), q2 = (int) __builtin_rintf(iscale * v.z),
+              q3 = (int) __builtin_rintf(iscale * v.w);
     int qs = q0 + q1 + q2 + q3;
     qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
-    if (!in) return;
-    reinterpret_cast<uint32_t *>(img)[i4] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
-    if ((i4 & 7) == 0) {
-        float * dd = reinterpret_cast<float *>(img + K);
-        dd[i4 >> 3] = d;
-        dd[(K >> 5) + (i4 >> 3)] = d * (float) qs;
-    }
+    packed = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+    d = am != 0.0f ? 1.0f / iscale : 0.0f;
+    bsum32 = qs;
+}
+__global__ void __launch_bounds__(256) quant_act_kernel(const float * x, char * img, int64_t K) {
+    const int64_t i4 = (int64_t) blockIdx.x * 256 + threadIdx.x;            // float4 index; K % 256 == 0: a wave never straddles the end
+    if (i4 * 4 >= K) return;
+    uint32_t packed; float d; int bs;
+    quant_block_q8k(reinterpret_cast<const float4 *>(x)[i4], threadIdx.x & 63, packed, d, bs);
+    reinterpret_cast<uint32_t *>(img)[i4] = packed;
+    if ((i4 & 63) == 0) reinterpret_cast<float *>(img + K)[i4 >> 6] = d;
+    if ((i4 & 7) == 0) reinterpret_cast<int *>(img + K + (K >> 8) * 4)[i4 >> 3] = bs;
 }
 
 struct GemvArgs {
@@ -66,8 +79,9 @@ __device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, co
     uint32_t xq[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) xq[i] = sq[i * gs + g];
-    const float dx0 = sd[g], dx1 = sd[gs + g], sx0 = ss[g], sx1 = ss[gs + g];
-    const float d = h2f((uint16_t) (hdr.x & 0xFFFF)), dmin = h2f((uint16_t) (hdr.x >> 16));
+    const float dx = sd[g];                                                     // the column's scale for this 256-block
+    const int   b0 = reinterpret_cast<const int *>(ss)[g], b1 = reinterpret_cast<const int *>(ss)[gs + g];   // sums of its quants, per 32
+    const float d = h2f((uint16_t) (hdr.x & 0xFFFF)) * dx, dmin = h2f((uint16_t) (hdr.x >> 16)) * dx;       // as ggml_vec_dot_q4_K_q8_K forms them
     auto sc = [&](int k) -> int { const uint32_t wd_ = k < 4 ? hdr.y : (k < 8 ? hdr.z : hdr.w); return (int) ((wd_ >> (8 * (k & 3))) & 0xFF); };
     auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
         if (j < 4) { s_ = sc(j) & 63; m_ = sc(j + 4) & 63; }
@@ -83,8 +97,8 @@ __device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, co
         ilo = __builtin_amdgcn_sdot4((int) (qw[w4] & 0x0F0F0F0Fu), (int) xq[w4], ilo, false);
         ihi = __builtin_amdgcn_sdot4((int) ((qw[w4] >> 4) & 0x0F0F0F0Fu), (int) xq[8 + w4], ihi, false);
     }
-    // sum (d*sc*q - dmin*m) x  with x ~ dx * xq :  d*sc*dx*sum(q xq) - dmin*m*dx*sum(xq)
-    return (d * (float) s1 * dx0 * (float) ilo - dmin * (float) m1 * sx0) + (d * (float) s2 * dx1 * (float) ihi - dmin * (float) m2 * sx1);
+    // the reference's integers (ggml-cpu-quants.c:6511: sum_j scale_j * (q4 . q8)_j and sum_j min_j * bsum_j), then ONE pair of f32 products
+    return d * (float) (s1 * ilo + s2 * ihi) - dmin * (float) (m1 * b0 + m2 * b1);
 }
 
 // block_q6_K (210 bytes, 2-byte aligned): quarter `qt` = (n, is) of block -> elements n*128 + 32 j + 16 is + [0, 16), j = 0..3, scale index
@@ -103,10 +117,10 @@ __device__ __forceinline__ float dot_q6k(const unsigned char * blk, int qt, cons
     uint32_t la[4], lb[4], hh[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) { la[w] = ld_u32_b2(ql + 4 * w); lb[w] = ld_u32_b2(ql + 32 + 4 * w); hh[w] = ld_u32_b2(qh + 4 * w); }
-    float acc = 0.0f;
+    int acc = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        // the run's activations: elements n*128 + 32 j + 16 is + [0, 16) = 64-group (2 n + j / 2), dwords 8 (j & 1) + 4 is + [0, 4); their scale: 32-block 4 n + j
+        // the run's activations: elements n*128 + 32 j + 16 is + [0, 16) = 64-group (2 n + j / 2), dwords 8 (j & 1) + 4 is + [0, 4)
         const int g = g64 + (j >> 1), wi0 = 8 * (j & 1) + 4 * is;
         int idot = 0;
 #pragma unroll
@@ -116,9 +130,9 @@ __device__ __forceinline__ float dot_q6k(const unsigned char * blk, int qt, cons
             const uint32_t v  = ((u | 0x80808080u) - 0x20202020u) ^ 0x80808080u;                     // per byte: q - 32 as int8
             idot = __builtin_amdgcn_sdot4((int) v, (int) sq[(wi0 + w) * gs + g], idot, false);
         }
-        acc += d * (float) (int) sc[2 * j] * sd[(j & 1) * gs + g] * (float) idot;
+        acc += (int) sc[2 * j] * idot;
     }
-    return acc;
+    return d * sd[g64] * (float) acc;                           // ggml_vec_dot_q6_K_q8_K: d = x.d * y.d, sum_is scale * (q6 . q8)
 }
 
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
@@ -130,7 +144,9 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     // stage the column image: K / 4 dwords of int8, K / 32 scales and scaled sums
     for (int i = threadIdx.x; i < (int) (a.K >> 2); i += 256) sq[(i & 15) * gs + (i >> 4)] = reinterpret_cast<const uint32_t *>(a.img)[i];
     const float * dd = reinterpret_cast<const float *>(a.img + a.K);
-    for (int b = threadIdx.x; b < (int) (a.K >> 5); b += 256) { sd[(b & 1) * gs + (b >> 1)] = dd[b]; ss[(b & 1) * gs + (b >> 1)] = dd[(a.K >> 5) + b]; }
+    const int *   bb = reinterpret_cast<const int *>(a.img + a.K + (a.K >> 8) * 4);
+    for (int g = threadIdx.x; g < gpr; g += 256) sd[g] = dd[g >> 2];                                  // the 256-block's scale, once per 64-group
+    for (int b = threadIdx.x; b < (int) (a.K >> 5); b += 256) reinterpret_cast<int *>(ss)[(b & 1) * gs + (b >> 1)] = bb[b];
     __syncthreads();
 
     const int total_rp = a.rp_end[a.n - 1];
@@ -242,7 +258,7 @@ __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int
 
 }  // namespace
 
-size_t act_image_bytes(int64_t K) { return (size_t) K + (size_t) (K / 32) * 8; }
+size_t act_image_bytes(int64_t K) { return (size_t) K + (size_t) (K / 256) * 4 + (size_t) (K / 32) * 4; }
 
 int launch_quantize_act(const float * x, void * img, int64_t K, hipStream_t st) {
     PKV_REQUIRE(K > 0 && K % 256 == 0, "pkv_quantize_act: K must be a positive multiple of 256");

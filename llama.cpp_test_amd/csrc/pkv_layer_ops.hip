@@ -81,18 +81,26 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
                 if (y_norm) reinterpret_cast<float4 *>(y_norm + ro)[i] = n;
                 if (y) reinterpret_cast<float4 *>(y + ro)[i] = w ? make_float4(n.x * wv[j].x, n.y * wv[j].y, n.z * wv[j].z, n.w * wv[j].w) : n;
             }
-            if (img) {   // 8 consecutive threads hold one 32-element block (ne0 % 256 == 0: a block never straddles the row's end)
+            if (img) {   // q8_K image (pkv_gemv.hip): the 64 lanes of a wave hold one 256-element block (ne0 % 256 == 0)
                 const float4 o = w ? make_float4(v[j].x * scale * wv[j].x, v[j].y * scale * wv[j].y, v[j].z * scale * wv[j].z, v[j].w * scale * wv[j].w)
                                    : make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
-                float amax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
-                amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
-                const float dq = amax / 127.0f, id = amax != 0.0f ? 127.0f / amax : 0.0f;
-                const int q0 = (int) __builtin_rintf(o.x * id), q1 = (int) __builtin_rintf(o.y * id), q2 = (int) __builtin_rintf(o.z * id), q3 = (int) __builtin_rintf(o.w * id);
+                float am = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+                float mx = fabsf(o.x) == am ? o.x : (fabsf(o.y) == am ? o.y : (fabsf(o.z) == am ? o.z : o.w));
+                const int ln = threadIdx.x & 63;
+#pragma unroll
+                for (int s_ = 1; s_ < 64; s_ <<= 1) {
+                    const float oa = __shfl_xor(am, s_), om = __shfl_xor(mx, s_);
+                    if (oa > am || (oa == am && (ln & s_))) { am = oa; mx = om; }
+                }
+                const float iscale = am != 0.0f ? -127.0f / mx : 0.0f;
+                const int q0 = (int) __builtin_rintf(iscale * o.x), q1 = (int) __builtin_rintf(iscale * o.y), q2 = (int) __builtin_rintf(iscale * o.z),
+                          q3 = (int) __builtin_rintf(iscale * o.w);
                 int qs = q0 + q1 + q2 + q3;
                 qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
                 if (i < n4) {
                     reinterpret_cast<uint32_t *>(img)[i] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
-                    if ((i & 7) == 0) { float * dd = reinterpret_cast<float *>(img + ne0); dd[i >> 3] = dq; dd[(ne0 >> 5) + (i >> 3)] = dq * (float) qs; }
+                    if ((i & 63) == 0) reinterpret_cast<float *>(img + ne0)[i >> 6] = am != 0.0f ? 1.0f / iscale : 0.0f;
+                    if ((i & 7) == 0) reinterpret_cast<int *>(img + ne0 + (ne0 >> 8) * 4)[i >> 3] = qs;
                 }
             }
         }

@@ -205,9 +205,13 @@ def read_gguf(path: str):
 
 def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv: int, n_ff: int, n_vocab: int, n_ctx: int = 4096,
                 rope_freq_base: float = 10000.0, rms_eps: float = 1e-5, wtype: int = GGML_F16, seed: int = 1234, name: str = "synthetic-llama",
-                rope_freqs: bool = False):
+                rope_freqs: bool = False, k_mix: bool = False, quantize=None):
     """random-weight llama-arch GGUF (norm weights f32 near 1, matrices N(0, 1/sqrt(fan_in)) in `wtype`); rope_freqs adds the
-    Llama-3.1-style `rope_freqs.weight` table of per-pair frequency factors (/root/reference/src/llama-model.cpp:1625, :11431-11443)"""
+    Llama-3.1-style `rope_freqs.weight` table of per-pair frequency factors (/root/reference/src/llama-model.cpp:1625, :11431-11443).
+    k_mix (with wtype q4_K): the tensor-type mix of a Q4_K_M file — output.weight, and attn_v / ffn_down of the first and last eighth of
+    the layers and of every third layer in between, in q6_K (llama_tensor_get_type + use_more_bits, /root/reference/src/llama-quant.cpp:130-340).
+    quantize (optional): callable (ggml_type, f32 rows) -> bytes that quantizes REAL Gaussian weights (tests pass the compiled
+    reference's from_float_ref); without it K-quant tensors are random well-formed blocks of the same statistics."""
     rng = np.random.default_rng(seed)
     hd = n_embd // n_head
     kv = [("general.architecture", T_STR, "llama"), ("general.name", T_STR, name), ("llama.context_length", T_U32, n_ctx),
@@ -218,9 +222,17 @@ def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv:
           ("tokenizer.ggml.model", T_STR, "no_vocab")]
     tensors = []
 
-    def mat(nm, ne0, ne1):                      # ggml [ne0 = in, ne1 = out]; numpy array [ne1][ne0]
+    def more_bits(il):                          # use_more_bits(i_layer, n_layer)
+        return il < n_layer // 8 or il >= 7 * n_layer // 8 or (il - n_layer // 8) % 3 == 2
+
+    def mat(nm, ne0, ne1, q6=False):            # ggml [ne0 = in, ne1 = out]; numpy array [ne1][ne0]
         if wtype == GGML_Q4_K and ne0 % 256 == 0:
-            tensors.append((nm, (ne0, ne1), GGML_Q4_K, random_q4_K(rng, ne1, ne0)))
+            t = GGML_Q6_K if (k_mix and q6) else GGML_Q4_K
+            if quantize is not None:
+                w = (rng.standard_normal((ne1, ne0)) / np.sqrt(ne0)).astype(np.float32)
+                tensors.append((nm, (ne0, ne1), t, bytes(quantize(t, w))))
+            else:
+                tensors.append((nm, (ne0, ne1), t, (random_q6_K if t == GGML_Q6_K else random_q4_K)(rng, ne1, ne0)))
             return
         t = GGML_F16 if wtype == GGML_Q4_K else wtype          # rows that are not a multiple of 256 stay f16
         w = (rng.standard_normal((ne1, ne0)) / np.sqrt(ne0)).astype(np.float32)
@@ -230,7 +242,7 @@ def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv:
         tensors.append((nm, (n,), GGML_F32, encode(1.0 + 0.1 * rng.standard_normal(n), GGML_F32)))
     mat("token_embd.weight", n_embd, n_vocab)
     vec("output_norm.weight", n_embd)
-    mat("output.weight", n_embd, n_vocab)
+    mat("output.weight", n_embd, n_vocab, q6=True)
     if rope_freqs:   # factors 1 (high frequencies) ... 8 (low frequencies), the shape of the llama-3 long-context table
         ff = np.clip(8.0 * (np.arange(hd // 2) / (hd // 2 - 1)) ** 3, 1.0, 8.0).astype(np.float32)
         tensors.append(("rope_freqs.weight", (hd // 2,), GGML_F32, encode(ff, GGML_F32)))
@@ -239,11 +251,11 @@ def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv:
         vec(p + "attn_norm.weight", n_embd)
         mat(p + "attn_q.weight", n_embd, n_embd)
         mat(p + "attn_k.weight", n_embd, hd * n_head_kv)
-        mat(p + "attn_v.weight", n_embd, hd * n_head_kv)
+        mat(p + "attn_v.weight", n_embd, hd * n_head_kv, q6=more_bits(il))
         mat(p + "attn_output.weight", n_embd, n_embd)
         vec(p + "ffn_norm.weight", n_embd)
         mat(p + "ffn_gate.weight", n_embd, n_ff)
-        mat(p + "ffn_down.weight", n_ff, n_embd)
+        mat(p + "ffn_down.weight", n_ff, n_embd, q6=more_bits(il))
         mat(p + "ffn_up.weight", n_embd, n_ff)
     write_gguf(path, kv, tensors)
     return kv, tensors
