@@ -371,8 +371,11 @@ typedef struct pkv_gemv {
     float *       y[PKV_GEMV_MAX];     /* device f32 [M[i]]                                                                   */
     int64_t       M[PKV_GEMV_MAX];
     int64_t       K;
-    const void *  xq;                  /* activation image                                                                    */
+    const void *  xq;                  /* activation image, or NULL: the kernel builds it itself from `x` (below)              */
     const float * residual;            /* optional (n == 1): y[0][m] = residual[m] + (W x)[m]; may alias y[0]                 */
+    const float * x;                   /* xq == NULL: the f32 activation column [K] (16-byte aligned); every workgroup quantizes   */
+    const float * norm_w;              /*   it into LDS under its first weight loads — after rms_norm(x) * norm_w when norm_w != NULL */
+    float         eps;                 /*   (build_norm feeding the product: no norm launch, no quantize launch; K <= 8192 then)   */
 } pkv_gemv;
 size_t pkv_act_image_bytes(int64_t K);
 int pkv_quantize_act(const float * x, void * image, int64_t K, void * stream);

@@ -14,14 +14,13 @@
 // weights, 0.18-0.39 of HBM peak.
 #include "pkv_common.h"
 
+// every instantiation of the product kernel must round a given row identically (one launch for wq + wk + wv == three launches, bit for bit):
+// no implicit FMA contraction anywhere in this file
+#pragma clang fp contract(off)
+
 namespace pkv {
 namespace {
 
-__device__ __forceinline__ float wsum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
-}
 __device__ __forceinline__ float h2f(uint16_t b) { return (float) *reinterpret_cast<const _Float16 *>(&b); }
 
 // ---- activation column -> q8_K, the reference's own operand of a q4_K / q6_K product ---------------------------------------------
@@ -31,22 +30,32 @@ __device__ __forceinline__ float h2f(uint16_t b) { return (float) *reinterpret_c
 // a product differs from the CPU backend's only by the order of a handful of f32 additions.  (Which of two elements of equal magnitude
 // and opposite sign supplies `max` only flips the sign of d and of every q together: the products q * d are the same bits.)
 // One wave per 256-element block, 4 elements per lane.
+template <int CTRL> __device__ __forceinline__ float dppq(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_amax(float x) {     // all-reduce max over the wave: DPP inside the rows of 16, permlane swaps across them (no LDS)
+    x = fmaxf(x, dppq<0xB1>(x)); x = fmaxf(x, dppq<0x4E>(x)); x = fmaxf(x, dppq<0x141>(x)); x = fmaxf(x, dppq<0x140>(x));
+    { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    return x;
+}
+__device__ __forceinline__ int sum8(int x) {               // sum over aligned groups of 8 lanes, every lane gets it
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);   // row_half_mirror: lane i <-> 7 - i, the other quad
+    return x;
+}
+// The reference takes `max` = the signed value of largest magnitude, so the sign of (d, q) follows that element's sign; here max = +amax
+// always: where the reference's max is negative, d and every q of the block come out negated TOGETHER — the products q * d, d * bsum and
+// with them every dot are the same bits (the GEMV only ever multiplies d with sums of q).
 __device__ __forceinline__ void quant_block_q8k(const float4 v, int lane, uint32_t & packed, float & d, int & bsum32) {
-    float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    float mx = fabsf(v.x) == am ? v.x : (fabsf(v.y) == am ? v.y : (fabsf(v.z) == am ? v.z : v.w));
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float oa = __shfl_xor(am, o), om = __shfl_xor(mx, o);
-        if (oa > am || (oa == am && (lane & o))) { am = oa; mx = om; }     // equal magnitudes: every lane settles on the lower lane's value
-    }
-    const float iscale = am != 0.0f ? -127.0f / mx : 0.0f;
+    const float am = wave_amax(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    const float iscale = am != 0.0f ? -127.0f / am : 0.0f;
     const int q0 = (int) __builtin_rintf(iscale * v.x), q1 = (int) __builtin_rintf(iscale * v.y), q2 = (int) __builtin_rintf(iscale * v.z),
               q3 = (int) __builtin_rintf(iscale * v.w);
-    int qs = q0 + q1 + q2 + q3;
-    qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
     packed = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
     d = am != 0.0f ? 1.0f / iscale : 0.0f;
-    bsum32 = qs;
+    bsum32 = sum8(q0 + q1 + q2 + q3);
 }
 __global__ void __launch_bounds__(256) quant_act_kernel(const float * x, char * img, int64_t K) {
     const int64_t i4 = (int64_t) blockIdx.x * 256 + threadIdx.x;            // float4 index; K % 256 == 0: a wave never straddles the end
@@ -67,6 +76,9 @@ struct GemvArgs {
     int          n, silu_mul;
     const float * residual;
     const char * img;
+    const float * x;                     // img == NULL: quantize this column in the kernel (after rms_norm(x) * norm_w when norm_w != NULL)
+    const float * norm_w;
+    float        eps;
     int64_t      K;
     int          gpr, gs;                // 64-element groups per row, LDS row stride (odd)
 };
@@ -82,10 +94,13 @@ __device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, co
     const float dx = sd[g];                                                     // the column's scale for this 256-block
     const int   b0 = reinterpret_cast<const int *>(ss)[g], b1 = reinterpret_cast<const int *>(ss)[gs + g];   // sums of its quants, per 32
     const float d = h2f((uint16_t) (hdr.x & 0xFFFF)) * dx, dmin = h2f((uint16_t) (hdr.x >> 16)) * dx;       // as ggml_vec_dot_q4_K_q8_K forms them
-    auto sc = [&](int k) -> int { const uint32_t wd_ = k < 4 ? hdr.y : (k < 8 ? hdr.z : hdr.w); return (int) ((wd_ >> (8 * (k & 3))) & 0xFF); };
-    auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
-        if (j < 4) { s_ = sc(j) & 63; m_ = sc(j + 4) & 63; }
-        else       { s_ = (sc(j + 4) & 0xF) | ((sc(j - 4) >> 6) << 4); m_ = (sc(j + 4) >> 4) | ((sc(j) >> 6) << 4); }
+    // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638) for sub-blocks j = 2 p, 2 p + 1, with shifts only (selecting one of hdr.y / .z / .w
+    // by a runtime index sends the header through scratch memory): byte jj = j & 3 of the three scale dwords
+    auto scale_min = [&](int j, int & s_, int & m_) {
+        const int sh = 8 * (j & 3);
+        const int b0 = (int) ((hdr.y >> sh) & 0xFF), b1 = (int) ((hdr.z >> sh) & 0xFF), b2 = (int) ((hdr.w >> sh) & 0xFF);
+        s_ = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4));
+        m_ = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
     };
     int s1, m1, s2, m2;
     scale_min(2 * p, s1, m1);
@@ -101,22 +116,15 @@ __device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, co
     return d * (float) (s1 * ilo + s2 * ihi) - dmin * (float) (m1 * b0 + m2 * b1);
 }
 
-// block_q6_K (210 bytes, 2-byte aligned): quarter `qt` = (n, is) of block -> elements n*128 + 32 j + 16 is + [0, 16), j = 0..3, scale index
-// 8 n + is + 2 j (dequantize_row_q6_K, /ref/ggml/src/ggml-quants.c:1690-1719).  Loads are 2-byte pieces assembled in registers (odd blocks
-// sit 2 bytes off a dword boundary).
-__device__ __forceinline__ uint32_t ld_u32_b2(const unsigned char * p) {
-    const uint16_t * h = reinterpret_cast<const uint16_t *>(p);
-    return (uint32_t) h[0] | ((uint32_t) h[1] << 16);
-}
-__device__ __forceinline__ float dot_q6k(const unsigned char * blk, int qt, const uint32_t * sq, const float * sd, int gs, int g64) {
+// block_q6_K (210 bytes: every other block sits 2 bytes off a dword boundary — the 16-byte loads below are misaligned, which gfx950 global
+// loads serve correctly, probes/unaligned_probe.hip): quarter `qt` = (n, is) of the block -> elements n*128 + 32 j + 16 is + [0, 16), j = 0..3,
+// scale index 8 n + is + 2 j (dequantize_row_q6_K, /ref/ggml/src/ggml-quants.c:1690-1719).  la = ql[16 is ..], lb = ql[32 + 16 is ..],
+// hh = qh[16 is ..] of half n; sc16 = the block's 16 scales; dbits = its f16 d.
+__device__ __forceinline__ float dot_q6k(const uint4 & la4, const uint4 & lb4, const uint4 & hh4, const uint4 & sc16, uint16_t dbits, int qt,
+                                         const uint32_t * sq, const float * sd, int gs, int g64) {
     const int n = qt >> 1, is = qt & 1;
-    const unsigned char * ql = blk + 64 * n + 16 * is;          // ql[l], l = 16 is .. 16 is + 15; ql[l + 32] 32 bytes on
-    const unsigned char * qh = blk + 128 + 32 * n + 16 * is;
-    const signed char *   sc = reinterpret_cast<const signed char *>(blk + 192) + 8 * n + is;
-    const float d = h2f(*reinterpret_cast<const uint16_t *>(blk + 208));
-    uint32_t la[4], lb[4], hh[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { la[w] = ld_u32_b2(ql + 4 * w); lb[w] = ld_u32_b2(ql + 32 + 4 * w); hh[w] = ld_u32_b2(qh + 4 * w); }
+    const uint32_t la[4] = {la4.x, la4.y, la4.z, la4.w}, lb[4] = {lb4.x, lb4.y, lb4.z, lb4.w}, hh[4] = {hh4.x, hh4.y, hh4.z, hh4.w};
+    const uint32_t scw[4] = {sc16.x, sc16.y, sc16.z, sc16.w};
     int acc = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -130,85 +138,188 @@ __device__ __forceinline__ float dot_q6k(const unsigned char * blk, int qt, cons
             const uint32_t v  = ((u | 0x80808080u) - 0x20202020u) ^ 0x80808080u;                     // per byte: q - 32 as int8
             idot = __builtin_amdgcn_sdot4((int) v, (int) sq[(wi0 + w) * gs + g], idot, false);
         }
-        acc += (int) sc[2 * j] * idot;
+        const int si = 8 * n + is + 2 * j;                                                           // scale of this run of 16
+        const int scv = (int) (signed char) ((scw[si >> 2] >> (8 * (si & 3))) & 0xFF);
+        acc += scv * idot;
     }
-    return d * sd[g64] * (float) acc;                           // ggml_vec_dot_q6_K_q8_K: d = x.d * y.d, sum_is scale * (q6 . q8)
+    return h2f(dbits) * sd[g64] * (float) acc;                  // ggml_vec_dot_q6_K_q8_K: d = x.d * y.d, sum_is scale * (q6 . q8)
 }
 
+// wave-wide sum without LDS: DPP inside the rows of 16, permlane swaps across them
+template <int CTRL> __device__ __forceinline__ float dppf(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wsum_dpp(float x) {
+    x += dppf<0xB1>(x); x += dppf<0x4E>(x); x += dppf<0x141>(x); x += dppf<0x140>(x);        // quad_perm, quad_perm, row_half_mirror, row_mirror
+    { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    return x;
+}
+
+// One unit of a wave's work = 128 (row, 64-element group) items of a row pair: the lane's items u = 0, 1.  Its loads (MODE 12: q4_K rows
+// only, 3 x 16 bytes per item; MODE 14: q6_K only, 4 x 16 + 2; MODE 0: any mix, the q6_K shape for every lane so that the number of loads
+// in flight does not depend on the lane's type — a q4_K lane re-reads its header) are issued one unit AHEAD of the dots that consume them.
+// Plain named registers per pipeline stage (a struct handed to lambdas by reference ended up in scratch memory: 368 bytes per lane and
+// every weight load doubled by a scratch store — rocprofv3 Scratch_Size column).
+#define PKV_UNIT_DECL(S) uint4 S##r0[2], S##r1[2], S##r2[2], S##r3[2]; uint16_t S##dh[2]; int S##g[2], S##p[2], S##ty[2], S##rs[2]; bool S##ok[2];
+#define PKV_UNIT_LOAD(S, IT)                                                                                                                   \
+    {                                                                                                                                          \
+        const int it_ = (IT);                                                                                                                  \
+        const int rp_ = first + (it_ / n_f0) * stride, f0_ = (it_ % n_f0) * 128;                                                               \
+        const char * q0_, * q1_; int t0_, t1_, mi_; int64_t m0_;                                                                               \
+        rows_of(rp_, q0_, q1_, t0_, t1_, mi_, m0_);                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                                        \
+            const int f = f0_ + 64 * u + lane;                                                                                                 \
+            S##ok[u] = f < 2 * gpr;                                                                                                            \
+            const int fc = S##ok[u] ? f : 2 * gpr - 1;                                                                                         \
+            S##rs[u] = fc >= gpr;                                                                                                              \
+            S##g[u] = fc - S##rs[u] * gpr;                                                                                                     \
+            S##p[u] = S##g[u] & 3;                                                                                                             \
+            S##ty[u] = MODE ? MODE : (S##rs[u] ? t1_ : t0_);                                                                                   \
+            const unsigned char * bp = reinterpret_cast<const unsigned char *>(S##rs[u] ? q1_ : q0_) +                                        \
+                                       (size_t) (S##g[u] >> 2) * (S##ty[u] == PKV_TYPE_Q4_K ? 144 : 210);                                      \
+            const int n_ = S##p[u] >> 1, is_ = S##p[u] & 1;                                                                                    \
+            if (MODE == PKV_TYPE_Q4_K) {                                                                                                       \
+                S##r0[u] = *reinterpret_cast<const uint4 *>(bp);                                                                               \
+                S##r1[u] = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * S##p[u]);                                                           \
+                S##r2[u] = *reinterpret_cast<const uint4 *>(bp + 32 + 32 * S##p[u]);                                                           \
+                S##r3[u] = make_uint4(0, 0, 0, 0); S##dh[u] = 0;                                                                               \
+            } else {                                                                                                                           \
+                const bool k4 = MODE == 0 && S##ty[u] == PKV_TYPE_Q4_K;                                                                        \
+                S##r0[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 0 : 64 * n_ + 16 * is_));                                               \
+                S##r1[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 16 + 32 * S##p[u] : 64 * n_ + 16 * is_ + 32));                          \
+                S##r2[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 32 + 32 * S##p[u] : 128 + 32 * n_ + 16 * is_));                         \
+                S##r3[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 0 : 192));                                                              \
+                S##dh[u] = *reinterpret_cast<const uint16_t *>(bp + (k4 ? 0 : 208));                                                           \
+            }                                                                                                                                  \
+        }                                                                                                                                      \
+    }
+#define PKV_UNIT_COMPUTE(S, IT)                                                                                                                \
+    {                                                                                                                                          \
+        const int it_ = (IT);                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                                        \
+            float part;                                                                                                                        \
+            if (S##ty[u] == PKV_TYPE_Q4_K) part = dot_q4k(S##r0[u], S##r1[u], S##r2[u], S##p[u], sq, sd, ss, gs, S##g[u]);                     \
+            else part = dot_q6k(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##dh[u], S##p[u], sq, sd, gs, (S##g[u] & ~3) + 2 * (S##p[u] >> 1));  \
+            if (!S##ok[u]) part = 0.0f;                                                                                                        \
+            acc0 += S##rs[u] ? 0.0f : part;                                                                                                    \
+            acc1 += S##rs[u] ? part : 0.0f;                                                                                                    \
+        }                                                                                                                                      \
+        if ((it_ + 1) % n_f0 == 0) { /* the row pair is complete */                                                                            \
+            const int rp_ = first + (it_ / n_f0) * stride;                                                                                     \
+            const char * q0_, * q1_; int t0_, t1_, mi_; int64_t m0_;                                                                           \
+            rows_of(rp_, q0_, q1_, t0_, t1_, mi_, m0_);                                                                                        \
+            const float s0 = wsum_dpp(acc0), s1 = wsum_dpp(acc1);                                                                              \
+            if (lane == 0 && live) {                                                                                                           \
+                if (a.silu_mul) {                                                                                                              \
+                    a.y[0][m0_] = s0 / (1.0f + expf(-s0)) * s1;                                                                                \
+                } else {                                                                                                                       \
+                    float * y = mi_ == 0 ? a.y[0] : (mi_ == 1 ? a.y[1] : a.y[2]);                                                              \
+                    if (a.residual) *reinterpret_cast<float2 *>(y + m0_) = make_float2(a.residual[m0_] + s0, a.residual[m0_ + 1] + s1);        \
+                    else            *reinterpret_cast<float2 *>(y + m0_) = make_float2(s0, s1);                                                \
+                }                                                                                                                              \
+            }                                                                                                                                  \
+            acc0 = acc1 = 0.0f;                                                                                                                \
+        }                                                                                                                                      \
+    }
+
+template <int MODE>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int gs = a.gs, gpr = a.gpr;
     uint32_t * sq = g_lds;
     float *    sd = reinterpret_cast<float *>(g_lds + 16 * gs);
     float *    ss = sd + 2 * gs;
-    // stage the column image: K / 4 dwords of int8, K / 32 scales and scaled sums
-    for (int i = threadIdx.x; i < (int) (a.K >> 2); i += 256) sq[(i & 15) * gs + (i >> 4)] = reinterpret_cast<const uint32_t *>(a.img)[i];
-    const float * dd = reinterpret_cast<const float *>(a.img + a.K);
-    const int *   bb = reinterpret_cast<const int *>(a.img + a.K + (a.K >> 8) * 4);
-    for (int g = threadIdx.x; g < gpr; g += 256) sd[g] = dd[g >> 2];                                  // the 256-block's scale, once per 64-group
-    for (int b = threadIdx.x; b < (int) (a.K >> 5); b += 256) reinterpret_cast<int *>(ss)[(b & 1) * gs + (b >> 1)] = bb[b];
-    __syncthreads();
-
-    const int total_rp = a.rp_end[a.n - 1];
-    for (int rp = (int) blockIdx.x * 4 + wv; rp < total_rp; rp += (int) gridDim.x * 4) {
-        int mi = 0;
-        while (mi + 1 < a.n && rp >= a.rp_end[mi]) ++mi;
-        const int rpl = rp - (mi ? a.rp_end[mi - 1] : 0);
-        // the two rows of the pair: consecutive rows of one matrix, or (gate row m, up row m) for the SwiGLU epilogue
+    const int total_rp = a.rp_end[0] > a.rp_end[1] ? (a.rp_end[0] > a.rp_end[2] ? a.rp_end[0] : a.rp_end[2]) : (a.rp_end[1] > a.rp_end[2] ? a.rp_end[1] : a.rp_end[2]);
+    const int stride = (int) gridDim.x * 4;
+    const bool live = (int) blockIdx.x * 4 + wv < total_rp;          // a surplus wave shadows the last row pair up to the stores: no early exit before the barriers
+    const int first = min((int) blockIdx.x * 4 + wv, total_rp - 1);
+    const int n_rp = (total_rp - first + stride - 1) / stride;       // row pairs of this wave
+    const int n_f0 = (2 * gpr + 127) / 128;                          // units per row pair
+    const int n_it = n_rp * n_f0;
+    // kernel-argument arrays are only ever indexed with constants (a dynamic index would move the struct to scratch)
+    const int e0 = a.rp_end[0], e1 = a.rp_end[1];
+    auto rows_of = [&](int rp, const char *& r0, const char *& r1, int & type0, int & type1, int & mi, int64_t & m0) {
+        mi = rp < e0 ? 0 : (rp < e1 ? 1 : 2);
+        const int rpl = rp - (mi == 0 ? 0 : (mi == 1 ? e0 : e1));
         const char * w0, * w1;
-        int type0, type1;
-        int64_t m0;
-        if (a.silu_mul) { m0 = rp; w0 = a.w[0]; w1 = a.w[1]; type0 = a.type[0]; type1 = a.type[1]; }
-        else            { m0 = 2 * (int64_t) rpl; w0 = w1 = a.w[mi]; type0 = type1 = a.type[mi]; }
-        const size_t rb0 = row_size(type0, a.K), rb1 = row_size(type1, a.K);
-        const char * r0 = w0 + (size_t) m0 * rb0;
-        const char * r1 = w1 + (size_t) (a.silu_mul ? m0 : m0 + 1) * rb1;
-        float acc0 = 0.0f, acc1 = 0.0f;
-        for (int f0 = 0; f0 < 2 * gpr; f0 += 128) {             // two passes of 64 (row, group) items per iteration: 6 loads in flight (q4_K)
-            float part[2];
-            int   rowsel[2];
-            // q4_K: every load of both passes goes out before the first dot
-            uint4 hdr[2], qa[2], qb[2];
-            const unsigned char * bp[2];
-            int   g[2], p[2], ty[2];
-            bool  ok[2];
+        if (a.silu_mul) { m0 = rp; w0 = a.w[0]; w1 = a.w[1]; type0 = a.type[0]; type1 = a.type[1]; mi = 0; }
+        else {
+            m0 = 2 * (int64_t) rpl;
+            w0 = w1 = mi == 0 ? a.w[0] : (mi == 1 ? a.w[1] : a.w[2]);
+            type0 = type1 = mi == 0 ? a.type[0] : (mi == 1 ? a.type[1] : a.type[2]);
+        }
+        r0 = w0 + (size_t) m0 * row_size(type0, a.K);
+        r1 = w1 + (size_t) (a.silu_mul ? m0 : m0 + 1) * row_size(type1, a.K);
+    };
+    float acc0 = 0.0f, acc1 = 0.0f;
+    PKV_UNIT_DECL(A) PKV_UNIT_DECL(B)
+    PKV_UNIT_LOAD(A, 0)                                               // the first weight loads fly while the column is prepared
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (a.img) {
+        // the column image was made by a launch of its own: copy K / 4 dwords of int8, the 256-block scales, the per-32 sums
+        for (int i = threadIdx.x; i < (int) (a.K >> 2); i += 256) sq[(i & 15) * gs + (i >> 4)] = reinterpret_cast<const uint32_t *>(a.img)[i];
+        const float * dd = reinterpret_cast<const float *>(a.img + a.K);
+        const int *   bb = reinterpret_cast<const int *>(a.img + a.K + (a.K >> 8) * 4);
+        for (int g = threadIdx.x; g < gpr; g += 256) sd[g] = dd[g >> 2];                              // the 256-block's scale, once per 64-group
+        for (int b = threadIdx.x; b < (int) (a.K >> 5); b += 256) reinterpret_cast<int *>(ss)[(b & 1) * gs + (b >> 1)] = bb[b];
+    } else {
+        // ... or here: [rms_norm(x) * w ->] q8_K straight into LDS.  float4 index i = tid + 256 j: the 64 lanes of a wave hold one 256-block.
+        // The norm rounds exactly as rms_norm_mul_kernel does (pkv_layer_ops.hip: per-thread fmaf chain in j order, xor-shuffle tree, the four
+        // wave sums left to right), so the fused launch and the norm + quantize + product launches produce the same bits.
+        const int n4 = (int) (a.K >> 2);
+        float scale = 1.0f;
+        constexpr int NV = 8;                                         // norm: K <= 8192 (checked on the host)
+        float4 v[NV];
+        if (a.norm_w) {
+            float sq_sum = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int f = f0 + 64 * u + lane;
-                ok[u] = f < 2 * gpr;
-                const int fc = ok[u] ? f : 2 * gpr - 1;
-                rowsel[u] = fc >= gpr;
-                g[u] = fc - rowsel[u] * gpr;
-                p[u] = g[u] & 3;
-                ty[u] = rowsel[u] ? type1 : type0;
-                const char * rr = rowsel[u] ? r1 : r0;
-                bp[u] = reinterpret_cast<const unsigned char *>(rr) + (size_t) (g[u] >> 2) * (ty[u] == PKV_TYPE_Q4_K ? 144 : 210);
-                if (ty[u] == PKV_TYPE_Q4_K) {
-                    hdr[u] = *reinterpret_cast<const uint4 *>(bp[u]);
-                    qa[u]  = *reinterpret_cast<const uint4 *>(bp[u] + 16 + 32 * p[u]);
-                    qb[u]  = *reinterpret_cast<const uint4 *>(bp[u] + 32 + 32 * p[u]);
+            for (int j = 0; j < NV; ++j) {
+                const int i = threadIdx.x + 256 * j;
+                v[j] = i < n4 ? reinterpret_cast<const float4 *>(a.x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                sq_sum = __fmaf_rn(v[j].x, v[j].x, sq_sum); sq_sum = __fmaf_rn(v[j].y, v[j].y, sq_sum);
+                sq_sum = __fmaf_rn(v[j].z, v[j].z, sq_sum); sq_sum = __fmaf_rn(v[j].w, v[j].w, sq_sum);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sq_sum += __shfl_xor(sq_sum, o);
+            float * red = ss;                                         // four floats of LDS, overwritten by the sums below after the barrier
+            if (lane == 0) red[wv] = sq_sum;
+            __syncthreads();
+            const float mean = (red[0] + red[1] + red[2] + red[3]) / (float) a.K;
+            scale = 1.0f / sqrtf(mean + a.eps);
+            __syncthreads();
+        }
+        auto put = [&](int i, const float4 o) {
+            uint32_t packed; float d; int bs;
+            quant_block_q8k(o, lane, packed, d, bs);
+            sq[(i & 15) * gs + (i >> 4)] = packed;
+            if ((i & 15) == 0) sd[i >> 4] = d;                        // the block's scale, once per 64-group
+            if ((i & 7) == 0) reinterpret_cast<int *>(ss)[((i >> 3) & 1) * gs + (i >> 4)] = bs;
+        };
+        if (a.norm_w) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = threadIdx.x + 256 * j;                  // n4 % 64 == 0: a wave is in or out as a whole
+                if (i - lane < n4) {
+                    const float4 w4 = reinterpret_cast<const float4 *>(a.norm_w)[i];
+                    put(i, make_float4(v[j].x * scale * w4.x, v[j].y * scale * w4.y, v[j].z * scale * w4.z, v[j].w * scale * w4.w));
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (ty[u] == PKV_TYPE_Q4_K) part[u] = dot_q4k(hdr[u], qa[u], qb[u], p[u], sq, sd, ss, gs, g[u]);
-                else                        part[u] = dot_q6k(bp[u], p[u], sq, sd, gs, (g[u] & ~3) + 2 * (p[u] >> 1));
-                if (!ok[u]) part[u] = 0.0f;
-                acc0 += rowsel[u] ? 0.0f : part[u];
-                acc1 += rowsel[u] ? part[u] : 0.0f;
-            }
+        } else {
+            for (int i = threadIdx.x; i - lane < n4; i += 256) put(i, reinterpret_cast<const float4 *>(a.x)[i]);
         }
-        acc0 = wsum(acc0);
-        acc1 = wsum(acc1);
-        if (lane == 0) {
-            if (a.silu_mul) {
-                a.y[0][m0] = acc0 / (1.0f + expf(-acc0)) * acc1;
-            } else {
-                float * y = a.y[mi];
-                if (a.residual) { y[m0] = a.residual[m0] + acc0; y[m0 + 1] = a.residual[m0 + 1] + acc1; }
-                else            { y[m0] = acc0; y[m0 + 1] = acc1; }
-            }
-        }
+    }
+    __syncthreads();
+
+    for (int it = 0; it < n_it; it += 2) {
+        PKV_UNIT_LOAD(B, min(it + 1, n_it - 1))          // one unit ahead; past the end: a harmless re-read of the last unit (the load count stays static)
+        PKV_UNIT_COMPUTE(A, it)
+        PKV_UNIT_LOAD(A, min(it + 2, n_it - 1))
+        if (it + 1 < n_it) PKV_UNIT_COMPUTE(B, it + 1)
     }
 }
 
@@ -268,7 +379,9 @@ int launch_quantize_act(const float * x, void * img, int64_t K, hipStream_t st) 
 }
 
 int launch_gemv(const pkv_gemv & g, hipStream_t st) {
-    PKV_REQUIRE(g.n >= 1 && g.n <= PKV_GEMV_MAX && g.xq && g.K > 0 && g.K % 256 == 0 && g.K <= 49152, "pkv_gemv_q: bad arguments");
+    PKV_REQUIRE(g.n >= 1 && g.n <= PKV_GEMV_MAX && (g.xq || g.x) && g.K > 0 && g.K % 256 == 0 && g.K <= 49152, "pkv_gemv_q: bad arguments");
+    PKV_REQUIRE(g.xq || (((uintptr_t) g.x % 16) == 0 && (!g.norm_w || (g.K <= 8192 && ((uintptr_t) g.norm_w % 16) == 0 && g.eps >= 0.0f))),
+                "pkv_gemv_q: in-kernel column: x (and norm_w) 16-byte aligned, K <= 8192 with a norm");
     PKV_REQUIRE(!g.silu_mul || (g.n == 2 && g.M[0] == g.M[1] && !g.residual), "pkv_gemv_q: silu_mul needs two products of equal M and no residual");
     PKV_REQUIRE(!g.residual || g.n == 1, "pkv_gemv_q: the residual epilogue takes one product");
     GemvArgs a = {};
@@ -280,14 +393,21 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
         tot += g.silu_mul ? (i == 0 ? (int) g.M[0] : 0) : (int) (g.M[i] / 2);
         a.rp_end[i] = tot;
     }
+    for (int i = g.n; i < PKV_GEMV_MAX; ++i) { a.rp_end[i] = tot; a.w[i] = a.w[0]; a.y[i] = a.y[0]; a.M[i] = 0; a.type[i] = a.type[0]; }
     a.n = g.n; a.silu_mul = g.silu_mul; a.residual = g.residual; a.img = (const char *) g.xq; a.K = g.K;
+    a.x = g.x; a.norm_w = g.xq ? nullptr : g.norm_w; a.eps = g.eps;
     a.gpr = (int) (g.K / 64); a.gs = a.gpr | 1;
     const size_t lds = (size_t) 20 * a.gs * 4;
-    // every workgroup pays one copy of the column image: a few row pairs per wave at least, 4 workgroups per CU at most
-    int grid = (tot + 3) / 4;
-    const int cap = 256 * 4;
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(gemv_kernel, dim3((unsigned) grid), dim3(256), lds, st, a);
+    // every workgroup pays one copy of the column image and every wave one pipeline fill: at least two row pairs per wave where the product
+    // has them, one workgroup per CU at least, four at most
+    int grid = (tot + 7) / 8;
+    if (grid < 256) grid = (tot + 3) / 4 < 256 ? (tot + 3) / 4 : 256;
+    if (grid > 1024) grid = 1024;
+    bool all4 = true, all6 = true;
+    for (int i = 0; i < g.n; ++i) { all4 = all4 && g.type_w[i] == PKV_TYPE_Q4_K; all6 = all6 && g.type_w[i] == PKV_TYPE_Q6_K; }
+    if (all4)      hipLaunchKernelGGL(gemv_kernel<PKV_TYPE_Q4_K>, dim3((unsigned) grid), dim3(256), lds, st, a);
+    else if (all6) hipLaunchKernelGGL(gemv_kernel<PKV_TYPE_Q6_K>, dim3((unsigned) grid), dim3(256), lds, st, a);
+    else           hipLaunchKernelGGL(gemv_kernel<0>, dim3((unsigned) grid), dim3(256), lds, st, a);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

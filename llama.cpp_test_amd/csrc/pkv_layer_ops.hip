@@ -11,6 +11,21 @@
 namespace pkv {
 namespace {
 
+template <int CTRL> __device__ __forceinline__ float dppl(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float q8k_wave_amax(float x) {  // all-reduce max over the wave without LDS (as pkv_gemv.hip's wave_amax)
+    x = fmaxf(x, dppl<0xB1>(x)); x = fmaxf(x, dppl<0x4E>(x)); x = fmaxf(x, dppl<0x141>(x)); x = fmaxf(x, dppl<0x140>(x));
+    { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    return x;
+}
+__device__ __forceinline__ int q8k_sum8(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);
+    return x;
+}
 __device__ __forceinline__ float wave_sum_f(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -84,19 +99,11 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
             if (img) {   // q8_K image (pkv_gemv.hip): the 64 lanes of a wave hold one 256-element block (ne0 % 256 == 0)
                 const float4 o = w ? make_float4(v[j].x * scale * wv[j].x, v[j].y * scale * wv[j].y, v[j].z * scale * wv[j].z, v[j].w * scale * wv[j].w)
                                    : make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);
-                float am = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
-                float mx = fabsf(o.x) == am ? o.x : (fabsf(o.y) == am ? o.y : (fabsf(o.z) == am ? o.z : o.w));
-                const int ln = threadIdx.x & 63;
-#pragma unroll
-                for (int s_ = 1; s_ < 64; s_ <<= 1) {
-                    const float oa = __shfl_xor(am, s_), om = __shfl_xor(mx, s_);
-                    if (oa > am || (oa == am && (ln & s_))) { am = oa; mx = om; }
-                }
-                const float iscale = am != 0.0f ? -127.0f / mx : 0.0f;
+                const float am = q8k_wave_amax(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                const float iscale = am != 0.0f ? -127.0f / am : 0.0f;     // max = +amax (pkv_gemv.hip: the sign convention cancels in every product)
                 const int q0 = (int) __builtin_rintf(iscale * o.x), q1 = (int) __builtin_rintf(iscale * o.y), q2 = (int) __builtin_rintf(iscale * o.z),
                           q3 = (int) __builtin_rintf(iscale * o.w);
-                int qs = q0 + q1 + q2 + q3;
-                qs += __shfl_xor(qs, 1); qs += __shfl_xor(qs, 2); qs += __shfl_xor(qs, 4);
+                const int qs = q8k_sum8(q0 + q1 + q2 + q3);
                 if (i < n4) {
                     reinterpret_cast<uint32_t *>(img)[i] = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
                     if ((i & 63) == 0) reinterpret_cast<float *>(img + ne0)[i >> 6] = am != 0.0f ? 1.0f / iscale : 0.0f;
@@ -223,10 +230,13 @@ __device__ __forceinline__ void q4k_rows(const char * w, const float * x, float 
                     for (int r = 0; r < R; ++r) {
                         const uint16_t dlo = (uint16_t) (hdr[r].x & 0xFFFF), dhi = (uint16_t) (hdr[r].x >> 16);
                         const float d = (float) *reinterpret_cast<const _Float16 *>(&dlo), dmin = (float) *reinterpret_cast<const _Float16 *>(&dhi);
-                        auto sc = [&](int k) -> int { const uint32_t wd_ = k < 4 ? hdr[r].y : (k < 8 ? hdr[r].z : hdr[r].w); return (int) ((wd_ >> (8 * (k & 3))) & 0xFF); };
-                        auto scale_min = [&](int j, int & s_, int & m_) {   // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638)
-                            if (j < 4) { s_ = sc(j) & 63; m_ = sc(j + 4) & 63; }
-                            else       { s_ = (sc(j + 4) & 0xF) | ((sc(j - 4) >> 6) << 4); m_ = (sc(j + 4) >> 4) | ((sc(j) >> 6) << 4); }
+                        // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638) with shifts only: picking one of hdr.y / .z / .w by a runtime index
+                        // sent the header through scratch memory (r01: 368 bytes of private segment per lane)
+                        auto scale_min = [&](int j, int & s_, int & m_) {
+                            const int sh = 8 * (j & 3);
+                            const int b0 = (int) ((hdr[r].y >> sh) & 0xFF), b1 = (int) ((hdr[r].z >> sh) & 0xFF), b2 = (int) ((hdr[r].w >> sh) & 0xFF);
+                            s_ = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4));
+                            m_ = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
                         };
                         int s1, m1, s2, m2;
                         scale_min(2 * p, s1, m1);

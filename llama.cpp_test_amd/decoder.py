@@ -3,13 +3,13 @@ sequence, driven through the C ABI only (no reference code anywhere on this path
 
     inp_embd = get_rows(tok_embd, token)                                   :4047   pkv_get_rows
     per layer:
-      attn_norm            rms_norm(x) * w                                  :4059   pkv_rms_norm_mul_q      (-> int8 activation image)
-      Qcur, Kcur, Vcur     wq / wk / wv products                            :4070   pkv_gemv_q              (one launch for the three)
+      attn_norm + Qcur, Kcur, Vcur   rms_norm(x) * w, wq / wk / wv          :4059   pkv_gemv_q   (ONE launch: norm + q8_K column in its prologue)
       rope, KV store, attention over the paged cache                        :4091   pkv_attn_decode_step    (+ the split-KV merge)
-      attn_out + residual  wo product, ffn_inp = cur + inpSA                :4120   pkv_quantize_act, pkv_gemv_q (residual epilogue)
-      ffn_norm, SwiGLU     silu(gate x) * (up x)                            :4140   pkv_rms_norm_mul_q, pkv_gemv_q (silu_mul epilogue)
-      ffn_down + residual                                                   :4160   pkv_quantize_act, pkv_gemv_q (residual epilogue)
-    output_norm, lm_head                                                    :4180   pkv_rms_norm_mul_q, pkv_gemv_q
+      attn_out + residual  wo product, ffn_inp = cur + inpSA                :4120   pkv_gemv_q   (residual epilogue)
+      ffn_norm + SwiGLU    silu(gate x') * (up x'), x' = rms_norm(x) * w    :4140   pkv_gemv_q   (norm prologue, silu_mul epilogue)
+      ffn_down + residual                                                   :4160   pkv_gemv_q   (residual epilogue)
+    output_norm + lm_head                                                   :4180   pkv_gemv_q
+  = 6 launches per layer.
 
 The host half of `llama_context::decode` (:1155-1487) is the paged block manager: find_slot -> block table / sequence length, no dense
 mask.  Every per-step input (token id, position, sequence length, block-table row) lives in device buffers that the host refreshes
@@ -24,8 +24,8 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from . import (F16, F32, Q4_K, Q6_K, Q8_0, PagedKVCache, PkvError, act_image, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add,
-               quantize_act, rms_norm_mul, rms_norm_mul_q, rope_cache, rope_params, silu_mul, kv_store)
+from . import (F16, Q4_K, Q6_K, PagedKVCache, PkvError, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add, rms_norm_mul, rope_cache,
+               rope_params, silu_mul, kv_store)
 from .gguf_synth import read_gguf, row_bytes
 
 _KQ = (Q4_K, Q6_K)
@@ -69,8 +69,6 @@ class LlamaDecoder:
         self.q, self.k_cur, self.v_cur = f32(1, self.n_head, self.D), f32(1, self.n_head_kv, self.D), f32(1, self.n_head_kv, self.D)
         self.attn, self.act, self.logits = f32(1, self.n_head, self.D), f32(F), f32(self.n_vocab)
         self.gate, self.upv, self.tmp_e = f32(F), f32(F), f32(E)
-        self.img_e = act_image(E, dev) if E % 256 == 0 else None
-        self.img_f = act_image(F, dev) if F % 256 == 0 else None
         self.ws = attn_workspace(1, self.n_head, self.D, n_ctx, block_size, device=dev)
         self.tok = torch.zeros(1, dtype=torch.int32, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -99,13 +97,19 @@ class LlamaDecoder:
     def _kq(self, names) -> bool:
         return all(self.w[n][1] in _KQ for n in names) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
 
-    def _products(self, names, outs, image, x_f32, *, residual=None, silu=False):
-        """outs[i] = W_i x (+ residual | SwiGLU): one pkv_gemv_q launch for K-quant rows, pkv_mul_mat + element-wise launches otherwise"""
+    def _products(self, names, outs, x_f32, *, norm=None, residual=None, silu=False):
+        """outs[i] = W_i x' (+ residual | SwiGLU) with x' = x, or rms_norm(x) * norm weights: ONE pkv_gemv_q launch for K-quant rows (the column is
+        normalised and quantized inside it), pkv_rms_norm_mul_f32 / pkv_mul_mat + element-wise launches otherwise"""
         ws = [self.w[n] for n in names]
         K = ws[0][2][0]
-        if image is not None and self._kq(names):
-            gemv_q([w[0] for w in ws], [w[1] for w in ws], [w[2][1] for w in ws], K, image, outs, residual=residual, silu_mul=silu)
+        nw = self.w[norm][0].view(self.torch.float32) if norm is not None else None
+        if self._kq(names) and (nw is None or K <= 8192):
+            gemv_q([w[0] for w in ws], [w[1] for w in ws], [w[2][1] for w in ws], K, None, outs, residual=residual, silu_mul=silu,
+                   x=x_f32, norm_w=nw, eps=self.eps)
             return
+        if nw is not None:
+            self.xn.copy_(rms_norm_mul(x_f32.reshape(1, -1), nw, self.eps).reshape(-1))
+            x_f32 = self.xn
         x2 = x_f32.reshape(1, K)
         if silu:
             mul_mat(ws[0][0], ws[0][1], ws[0][2][1], K, x2, out=self.gate.reshape(1, -1))
@@ -119,14 +123,6 @@ class LlamaDecoder:
             else:
                 mul_mat(w[0], w[1], w[2][1], K, x2, out=o.reshape(1, -1))
 
-    def _norm(self, wname, image):
-        """xn (f32) and the activation image of rms_norm(h) * w"""
-        w = self.w[wname][0].view(self.torch.float32)
-        if image is not None:
-            rms_norm_mul_q(self.h, w, self.eps, image, y=self.xn)
-        else:
-            self.xn.copy_(rms_norm_mul(self.h.reshape(1, -1), w, self.eps).reshape(-1))
-
     # ---- one step: every launch of one token, reading tok / pos / seq_lens / block_table from device buffers --------------------
     def launches(self, max_seq_len: Optional[int] = None):
         E = self.n_embd
@@ -136,25 +132,17 @@ class LlamaDecoder:
         msl = max_seq_len or self.n_ctx
         for l in range(self.n_layer):
             p = f"blk.{l}."
-            self._norm(p + "attn_norm.weight", self.img_e)
             self._products([p + "attn_q.weight", p + "attn_k.weight", p + "attn_v.weight"],
-                           [self.q.reshape(-1), self.k_cur.reshape(-1), self.v_cur.reshape(-1)], self.img_e, self.xn)
+                           [self.q.reshape(-1), self.k_cur.reshape(-1), self.v_cur.reshape(-1)], self.h, norm=p + "attn_norm.weight")
             attn_decode_step(self.q, self.k_cur, self.v_cur, self.pos, self.rope, self.cache.k_pool(l), self.cache.v_pool(l), self.block_table,
                              self.seq_lens, n_head_kv=self.n_head_kv, type_k=self.tk, type_v=self.tv, block_size=self.BS, scale=self.scale,
                              max_seq_len=msl, out=self.attn, workspace=self.ws, rope_cache=self.rope_cs)
             if self.trace is not None:   # debugging aid (eager launches only): per-layer copies of the attention path's inputs and output
                 self.trace.append({k: getattr(self, k).detach().clone() for k in ("q", "k_cur", "v_cur", "attn")})
-            a = self.attn.reshape(-1)
-            if self.img_e is not None:
-                quantize_act(a, self.img_e)
-            self._products([p + "attn_output.weight"], [self.h], self.img_e, a, residual=self.h)
-            self._norm(p + "ffn_norm.weight", self.img_e)
-            self._products([p + "ffn_gate.weight", p + "ffn_up.weight"], [self.act], self.img_e, self.xn, silu=True)
-            if self.img_f is not None:
-                quantize_act(self.act, self.img_f)
-            self._products([p + "ffn_down.weight"], [self.h], self.img_f, self.act, residual=self.h)
-        self._norm("output_norm.weight", self.img_e)
-        self._products(["output.weight"], [self.logits], self.img_e, self.xn)
+            self._products([p + "attn_output.weight"], [self.h], self.attn.reshape(-1), residual=self.h)
+            self._products([p + "ffn_gate.weight", p + "ffn_up.weight"], [self.act], self.h, norm=p + "ffn_norm.weight", silu=True)
+            self._products([p + "ffn_down.weight"], [self.h], self.act, residual=self.h)
+        self._products(["output.weight"], [self.logits], self.h, norm="output_norm.weight")
 
     # ---- host half ---------------------------------------------------------------------------------------------------------------
     def clear(self):

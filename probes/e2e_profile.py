@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""probes/e2e_profile.py — the end-to-end decode step of bench.py's `e2e` record alone (for rocprofv3 --kernel-trace --stats):
+python probes/e2e_profile.py [--steps N] [--eager]"""
+import argparse, os, shutil, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import _load_pkg
+import bench
+pkv = _load_pkg.load(); pkv.lib()
+from llama_cpp_test_amd import gguf_synth as G
+from llama_cpp_test_amd.decoder import LlamaDecoder
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--eager", action="store_true"); ap.add_argument("--ctx", type=int, default=4096)
+a = ap.parse_args()
+tmp = tempfile.mkdtemp(dir="/tmp", prefix="pkv_e2e_")
+path = os.path.join(tmp, "m.gguf")
+try:
+    G.synth_llama(path, wtype=G.GGML_Q4_K, k_mix=True, seed=8, **bench.LLAMA3_8B)
+    dec = LlamaDecoder(path, n_ctx=a.ctx)
+    dec.fill_kv_synthetic(a.ctx - 1, seed=3)
+    dec._place(12345, a.ctx - 1)
+    if a.eager:
+        run = lambda: dec.launches(max_seq_len=a.ctx)
+    else:
+        g = dec.capture(); run = g.replay
+    for _ in range(3): run()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps): run()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+    print(f"{1 / dt:.1f} tok/s, {dt * 1e3:.3f} ms/token ({'eager' if a.eager else 'graph'})")
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)

@@ -47,17 +47,22 @@ def test_quantize_act_image(pkv, O):
         img = pkv.quantize_act(dev(x)).cpu().numpy()
         q, d, _ = quant_act_ref(x)
         got_q, got_d, got_bs = img[:K].view(np.int8), img[K:K + K // 64].view(np.float32), img[K + K // 64:].view(np.int32)
-        assert np.array_equal(got_q, q.reshape(-1)) and np.array_equal(got_d, d)
-        assert np.array_equal(got_bs, q.astype(np.int32).reshape(K // 32, 32).sum(-1))
+        # the device always takes max = +amax (the reference: the signed value of largest magnitude): d and the block's q may come out negated
+        # TOGETHER; every quantity a product uses — d * q, d * bsum — is the same bits
+        sgn = np.where(np.sign(got_d) == np.sign(d), 1, -1).astype(np.int32)
+        assert np.array_equal(np.abs(got_d), np.abs(d))
+        assert np.array_equal(got_q.reshape(-1, 256).astype(np.int32) * sgn[:, None], q.reshape(-1, 256).astype(np.int32))
+        assert np.array_equal(got_bs.reshape(-1, 8) * sgn[:, None], q.astype(np.int32).reshape(K // 256, 8, 32).sum(-1))
         if O.ref_available():                                      # block_q8_K = {f32 d, i8 qs[256], i16 bsums[16]}
             O.ref_rope(np.zeros((1, 1, 64), np.float32), np.zeros(1, np.int32), n_dims=64)
             import ctypes, os
             L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libggml_ref.so"))
             rb = np.zeros((K // 256, 292), np.uint8)                 # (the reference leaves the bsums of an all-zero block unwritten)
             L.quantize_row_q8_K_ref(x.ctypes.data_as(ctypes.c_void_p), rb.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(K))
-            assert np.array_equal(rb[:, :4].copy().view(np.float32)[:, 0], got_d)
-            assert np.array_equal(rb[:, 4:260].copy().view(np.int8).reshape(-1), got_q)
-            assert np.array_equal(rb[:, 260:].copy().view(np.int16).astype(np.int32).reshape(K // 32, 2).sum(-1), got_bs)
+            rd, rq = rb[:, :4].copy().view(np.float32)[:, 0], rb[:, 4:260].copy().view(np.int8).astype(np.int32)
+            assert np.array_equal(rd.astype(np.float64)[:, None] * rq, got_d.astype(np.float64)[:, None] * got_q.reshape(-1, 256))
+            rbs = rb[:, 260:].copy().view(np.int16).astype(np.int32).reshape(K // 256, 8, 2).sum(-1)
+            assert np.array_equal(rd.astype(np.float64)[:, None] * rbs, got_d.astype(np.float64)[:, None] * got_bs.reshape(-1, 8))
 
 
 @pytest.mark.parametrize("tname,M,K", [("q4_K", 4096, 4096), ("q4_K", 1024, 4096), ("q4_K", 4096, 14336), ("q4_K", 14336, 4096), ("q4_K", 6, 256),
@@ -151,3 +156,29 @@ def test_get_rows(pkv, O, tname):
     ids = np.array([5, 0, 299, 5, 17, 123], np.int32)
     out = pkv.get_rows(dev(np.ascontiguousarray(wb).reshape(-1)), t, dev(ids), K, n_rows).cpu().numpy()
     assert np.array_equal(out, np.asarray(wd).reshape(n_rows, K)[ids])
+
+
+@pytest.mark.parametrize("K,norm", [(4096, True), (4096, False), (14336, False), (8192, True), (256, True)])
+def test_gemv_in_kernel_column_equals_separate_launches(pkv, K, norm):
+    """x (or rms_norm(x) * w) quantized in the product's own prologue == pkv_rms_norm_mul_q / pkv_quantize_act followed by the product, bit for bit"""
+    from llama_cpp_test_amd import gguf_synth as G
+    rng = np.random.default_rng(K + norm)
+    M = 512
+    wq, _ = weights(G, rng, 12, M, K)
+    w6, _ = weights(G, rng, 14, M, K)
+    x = dev(rng.standard_normal(K).astype(np.float32) * 2)
+    nw = dev((1 + 0.1 * rng.standard_normal(K)).astype(np.float32)) if norm else None
+    img = pkv.rms_norm_mul_q(x, nw, 1e-5, pkv.act_image(K)) if norm else pkv.quantize_act(x)
+    want = [torch.zeros(M, device="cuda") for _ in range(2)]
+    pkv.gemv_q([wq, w6], [12, 14], [M, M], K, img, want)
+    got = [torch.zeros(M, device="cuda") for _ in range(2)]
+    pkv.gemv_q([wq, w6], [12, 14], [M, M], K, None, got, x=x, norm_w=nw, eps=1e-5)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # a residual epilogue in place on a SMALL product (more waves than row pairs: surplus waves must not add twice)
+    r = dev(rng.standard_normal(6).astype(np.float32))
+    w_small, _ = weights(G, rng, 12, 6, K)
+    y1 = r.clone()
+    pkv.gemv_q([w_small], [12], [6], K, img, [y1], residual=y1)
+    y0 = torch.zeros(6, device="cuda")
+    pkv.gemv_q([w_small], [12], [6], K, img, [y0])
+    assert torch.equal(y1, r + y0)
