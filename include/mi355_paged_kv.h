@@ -346,6 +346,11 @@ int pkv_add_rms_norm_mul_f32(const float * a, const float * b, float * sum, cons
 int pkv_add_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_mul_f32(const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, void * stream);
 int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream);
+/* ggml_soft_max_ext (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10222-10318; the softmax of the non-flash-attention path, /ref/src/llama-graph.cpp:1201-1239):
+ * y[i3][i2][i1][:] = softmax(x[...][:] * scale + slope(i2) * mask[i1][:]); x, y f32 contiguous [ne03][ne02][ne01][ne00] (y may alias x); mask NULL or
+ * [>= ne01][ne00] rows of f32 (mask_f16 = 0) or f16 (1), broadcast over i2, i3; slope = ALiBi (max_bias > 0: m0^(h+1) / m1^(2(h-n_head_log2)+1), h = i2) else 1 */
+int pkv_soft_max_ext_f32(const float * x, const void * mask, int mask_f16, float * y, int64_t ne00, int64_t ne01, int64_t ne02, int64_t ne03, float scale,
+                         float max_bias, void * stream);
 int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream);
 /* n (1..PKV_MUL_MAT_MAX) products that share x, K, n_cols and the weight type — wq / wk / wv of a layer, gate / up of its FFN
  * (/ref/src/llama-model.cpp build_attn inputs, build_ffn LLM_FFN_PAR) — results identical to n pkv_mul_mat calls; q4_K and q8_0

@@ -447,6 +447,18 @@ def silu(x, out=None, stream=None):
     return out
 
 
+def soft_max_ext(x, mask=None, scale: float = 1.0, max_bias: float = 0.0, out=None, stream=None):
+    """ggml_soft_max_ext over the last dimension of x f32 [ne3][ne2][ne1][ne0] (fewer dimensions: leading ones); mask f32 / f16 [>= ne1][ne0]"""
+    import torch
+    out = x.new_empty(x.shape) if out is None else out
+    sh = (1,) * (4 - x.dim()) + tuple(x.shape)
+    mf16 = int(mask is not None and mask.dtype == torch.float16)
+    check(lib().pkv_soft_max_ext_f32(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(mask) if mask is not None else None), C.c_int(mf16), C.c_void_p(_ptr(out)),
+                                     C.c_int64(sh[3]), C.c_int64(sh[2]), C.c_int64(sh[1]), C.c_int64(sh[0]), C.c_float(scale), C.c_float(max_bias),
+                                     C.c_void_p(_stream(stream))))
+    return out
+
+
 def mul_mat(w, type_w: int, M: int, K: int, x, out=None, stream=None):
     """ggml_mul_mat: w = M rows of K elements in f32 / f16 / q8_0 reference row format (device bytes), x f32 [n_cols][K] ->
     f32 [n_cols][M]"""

@@ -366,6 +366,13 @@ bool supports_binary(const ggml_tensor * op) {
     }
     return true;
 }
+// ggml_soft_max_ext: f32 contiguous logits, optional f32 / f16 contiguous mask of >= ne01 rows of ne00 (the KQ_mask of a -fa 0 graph)
+bool supports_soft_max(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0], * m = op->src[1];
+    if (!f32c(a) || !f32c(op) || !ggml_are_same_shape(a, op)) return false;
+    if (m && ((m->type != GGML_TYPE_F32 && m->type != GGML_TYPE_F16) || !ggml_is_contiguous(m) || m->ne[0] != a->ne[0] || m->ne[1] < a->ne[1])) return false;
+    return true;
+}
 bool supports_silu(const ggml_tensor * op) { return ggml_get_unary_op(op) == GGML_UNARY_OP_SILU && f32c(op->src[0]) && f32c(op); }
 bool supports_mul_mat(const ggml_tensor * op) {
     const ggml_tensor * w = op->src[0], * x = op->src[1];
@@ -384,6 +391,11 @@ ggml_status run_layer_op(backend_ctx * bc, ggml_tensor * op) {
         } break;
         case GGML_OP_ADD: rc = pkv_add_f32((const float *) a->data, (const float *) b->data, (float *) op->data, ggml_nrows(a), a->ne[0], ggml_nrows(b), bc->stream); break;
         case GGML_OP_MUL: rc = pkv_mul_f32((const float *) a->data, (const float *) b->data, (float *) op->data, ggml_nrows(a), a->ne[0], ggml_nrows(b), bc->stream); break;
+        case GGML_OP_SOFT_MAX: {
+            float scale, max_bias; memcpy(&scale, (const float *) op->op_params + 0, sizeof(float)); memcpy(&max_bias, (const float *) op->op_params + 1, sizeof(float));
+            rc = pkv_soft_max_ext_f32((const float *) a->data, b ? b->data : nullptr, b && b->type == GGML_TYPE_F16, (float *) op->data, a->ne[0], a->ne[1], a->ne[2], a->ne[3],
+                                      scale, max_bias, bc->stream);
+        } break;
         case GGML_OP_UNARY: rc = pkv_silu_f32((const float *) a->data, (float *) op->data, ggml_nelements(a), bc->stream); break;
         case GGML_OP_MUL_MAT: rc = pkv_mul_mat(a->data, a->type, (const float *) b->data, (float *) op->data, a->ne[1], a->ne[0], b->ne[1], bc->stream); break;
         default: break;
@@ -620,7 +632,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             case GGML_OP_ROPE:           st = run_rope(bc, n, false); break;
             case GGML_OP_ROPE_BACK:      st = run_rope(bc, n, true); break;
             case GGML_OP_CPY:            st = run_cpy(bc, n); break;
-            case GGML_OP_RMS_NORM: case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_UNARY: case GGML_OP_MUL_MAT: st = run_layer_op(bc, n); break;
+            case GGML_OP_RMS_NORM: case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_UNARY: case GGML_OP_MUL_MAT: case GGML_OP_SOFT_MAX: st = run_layer_op(bc, n); break;
             default: MI355_LOG("op %s reached graph_compute but is not supported\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
         }
         if (st != GGML_STATUS_SUCCESS) return st;
@@ -680,6 +692,7 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
         case GGML_OP_RMS_NORM: return supports_rms_norm(op);
         case GGML_OP_ADD: case GGML_OP_MUL: return supports_binary(op);
         case GGML_OP_UNARY: return supports_silu(op);
+        case GGML_OP_SOFT_MAX: return supports_soft_max(op);
         case GGML_OP_MUL_MAT: return supports_mul_mat(op);
         default: return false;
     }

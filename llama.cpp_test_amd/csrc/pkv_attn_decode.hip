@@ -309,7 +309,12 @@ struct Geo {
     using KT_ = KTr<KT, D>;
     static constexpr int K_LPR = KT_::LPR, K_RPL = 64 / K_LPR;
     static constexpr int V_LPR = D / 4, V_TL = VTr<VT>::TL, V_RPL = (64 / V_LPR) * V_TL;
-    static constexpr int TPW = imax(16, imax(K_RPL, V_RPL));   // tokens per wave
+#ifndef PKV_TPW_Q
+#define PKV_TPW_Q 16
+#endif
+    // quantized tiles are 2-4x fewer bytes per token: a wave that owns 16 tokens spends more instructions on its fixed work (softmax, reductions, the
+    // strip, the merge) than on the dots — PKV_TPW_Q tokens per wave for them
+    static constexpr int TPW = imax((KT != PKV_TYPE_F16 || VT != PKV_TYPE_F16) ? PKV_TPW_Q : 16, imax(K_RPL, V_RPL));   // tokens per wave
     static constexpr int NW  = WG_TOK / TPW;                   // waves per workgroup
     static constexpr int K_NL = TPW / K_RPL, V_NL = TPW / V_RPL;
 };
@@ -350,7 +355,10 @@ __device__ __forceinline__ float head_reduce2(float x) {
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int off) {
-    const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+#ifndef PKV_KV_AUX
+#define PKV_KV_AUX 2
+#endif
+    const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, PKV_KV_AUX);   // aux 2 = nt (experiment)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -383,10 +391,14 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decod
     constexpr int TPW = GE::TPW, NW = GE::NW, NT = 64 * NW;
     constexpr int NV = K_NL * G, NS = ilog2(K_LPR) < ilog2(NV) ? ilog2(K_LPR) : ilog2(NV), NVF = NV >> NS;
     constexpr bool P16 = VT == PKV_TYPE_F16;                   // P travels as half2 token pairs for the dot2 PV
+    // quantized V (r02): the weight of a cell is folded with the cell's block scale BEFORE it meets the quants — P''[t][g][b] = f16(p[t][g] * d_V[t][b]),
+    // one rounding — and travels as half2 token pairs like the f16 case; the int8 / nibble quants become f16 by a byte permute against the magic
+    // 0x6400 (1024 + u) and one packed add, so that P.V is a v_dot2c_f32_f16 stream for every V type (r01: 16 int->float converts + 64 FMAs per 16 V bytes)
+    constexpr bool PQ = VT != PKV_TYPE_F16;
     constexpr int K_ROWB = KT == PKV_TYPE_F16 ? D * 2 : (KT == PKV_TYPE_Q8_0 ? D : D / 2);   // quant bytes per token row of a K tile
     constexpr int NB = D / PKV_QK;
 
-    __shared__ __attribute__((aligned(16))) float sP[NW][TPW * G / (P16 ? 2 : 1)];  // per-wave probabilities
+    __shared__ __attribute__((aligned(16))) float sP[NW][TPW * G / 2 * (VT != PKV_TYPE_F16 ? D / PKV_QK : 1)];  // per-wave weights, half2 token pairs [x V block]
     __shared__ __attribute__((aligned(16))) float sO[NW][G][D];                     // per-wave partial outputs
     __shared__ __attribute__((aligned(16))) float sML[NW][G][2];                    // per-wave (max, sum)
 #ifndef PKV_WGMAX
@@ -473,6 +485,20 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decod
             ksc[i] = h_val(hb);                                 // a row past the end reads scale 0
         }
     }
+    // quantized V: the block scales of the cells whose logits this lane will own (NVF cells x NB blocks, 2 bytes each), behind the K stream
+    constexpr int NVF_ = ((K_NL * G) >> (ilog2(K_LPR) < ilog2(K_NL * G) ? ilog2(K_LPR) : ilog2(K_NL * G)));
+    [[maybe_unused]] unsigned short vsb[PQ ? NVF_ : 1][PQ ? NB : 1];
+    if constexpr (PQ) {
+        constexpr int NS_ = ilog2(K_LPR) < ilog2(K_NL * G) ? ilog2(K_LPR) : ilog2(K_NL * G);
+        const int cidx_ = NVF_ * (kc >> (ilog2(K_LPR) - NS_));
+#pragma unroll
+        for (int j = 0; j < NVF_; ++j) {
+            const int t = wave * TPW + ((cidx_ + j) / G) * K_RPL + kr;          // cell inside the workgroup's 128
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                vsb[j][b] = __builtin_amdgcn_raw_buffer_load_b16(rs_vs, (((t / V_TL) * NB + b) * V_TL + t % V_TL) * 2, 0, 0);   // past the end: 0
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     ts.at(3);                           // row and K loads issued
 
@@ -502,22 +528,9 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decod
 #define PKV_VSCHED 0
 #endif
     uint4 vreg[V_NL];
-    float vsc[V_NL][V_TL];
     auto issue_v = [&](int i) {
         __builtin_amdgcn_sched_barrier(0);                      // program order = issue order
         vreg[i] = buf_load16(rs_v, v_off + i * 1024);
-        if constexpr (VT != PKV_TYPE_F16) {
-            const int tw  = wave * TPW + i * V_RPL + vl * V_TL;          // first token of this lane-load
-            const int so  = ((tw / V_TL) * NB + vc / 8) * V_TL * 2;      // its group's scales for this lane's 32-block: V_TL consecutive halfs
-            uint32_t sw[V_TL / 2];
-            if constexpr (V_TL == 4) { const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; }
-            else                     { const u4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs_vs, so, 0, 0); sw[0] = t.x; sw[1] = t.y; sw[2] = t.z; sw[3] = t.w; }
-#pragma unroll
-            for (int t = 0; t < V_TL; ++t) {
-                const float sc = h_val((uint16_t) (sw[t / 2] >> (16 * (t & 1))));
-                vsc[i][t] = tw + t < n_valid ? sc : 0.0f;       // a stale scale of a cell past the end must not reach 0 * NaN
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
     };
     if (PKV_VSCHED == 2) {              // every V chunk right behind the row job, ahead of the barrier (all waves: the counts must not depend on the path)
@@ -601,7 +614,16 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decod
     for (int j = 0; j < NVF; ++j) {
         const int g = (cidx + j) % G, t = tok[j] - wave * TPW;
         if constexpr (P16) reinterpret_cast<_Float16 *>(sP[wave])[((t >> 1) * G + g) * 2 + (t & 1)] = (_Float16) pj[j];
-        else               sP[wave][t * G + g] = pj[j];
+        else {   // pair of a cell: q8_0 (t, t + 1), q4_0 (t, t + 4) inside its group of 8 — the cells one V dword's byte / nibble pairs hold
+            const int pair = V_TL == 4 ? (t >> 1) : ((t >> 3) * 4 + (t & 3)), el = V_TL == 4 ? (t & 1) : ((t >> 2) & 1);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float sc = h_val(vsb[j][b]);
+                if constexpr (PREP) { if (is_last && tok[j] == n_valid - 1) sc = sVc.d[b]; }   // the new token: its scale is not in the pool yet
+                const float pw = pj[j] == 0.0f ? 0.0f : pj[j] * sc;      // a stale scale of a cell past the end must not reach 0 * NaN
+                reinterpret_cast<_Float16 *>(sP[wave])[((pair * NB + b) * G + g) * 2 + el] = (_Float16) pw;
+            }
+        }
         const float l = head_reduce2<TPW, false>(pj[j]);      // sums over the token bits of the lane id only
         if ((lane >> ilog2(64 / TPW)) == 0) *reinterpret_cast<float2 *>(&sML[wave][g][0]) = make_float2(mg[j], l);
     }
@@ -624,11 +646,6 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decod
                     const uint4 nv = *reinterpret_cast<const uint4 *>(&sVc.w[vc * 4]);
                     vreg[i].x = (vreg[i].x & keep) | nv.x; vreg[i].y = (vreg[i].y & keep) | nv.y;
                     vreg[i].z = (vreg[i].z & keep) | nv.z; vreg[i].w = (vreg[i].w & keep) | nv.w;
-                    if constexpr (VT != PKV_TYPE_F16) {
-#pragma unroll
-                        for (int t = 0; t < V_TL; ++t)
-                            if (t == sub) vsc[i][t] = sVc.d[vc / 8];
-                    }
                 }
             }
         }
@@ -659,19 +676,34 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decod
                 for (int j = 0; j < 4; ++j)
                     acc[g][j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const half2_t *>(&w[j]), pp[g], acc[g][j], false);
         } else {
+            constexpr int NP = V_TL / 2;                      // token pairs per V dword: q8_0 (t0, t0+1) (t0+2, t0+3); q4_0 (t0+k, t0+k+4), k = 0..3
+            const int p0 = V_TL == 4 ? (t0 >> 1) : (t0 >> 3) * 4, blk = vc / 8;   // the lane's 4 d sit in V block vc * 4 / 32
+            half2_t pp[NP][G];
 #pragma unroll
-            for (int t = 0; t < V_TL; ++t) {
-                float p[G];   // p is already 0 for cells past the end of the sequence, and so is their scale
+            for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
-                for (int g = 0; g < G; ++g) p[g] = sP[wave][(t0 + t) * G + g] * vsc[i][t];
+                for (int g = 0; g < G; ++g) pp[pr][g] = reinterpret_cast<const half2_t *>(sP[wave])[((p0 + pr) * NB + blk) * G + g];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float vf;
-                    if constexpr (VT == PKV_TYPE_Q8_0) vf = (float) (int) (signed char) (vw[j] >> (8 * t));
-                    else                               vf = (float) ((int) ((vw[j] >> (4 * t)) & 0xF) - 8);
+            for (int j = 0; j < 4; ++j) {
+                half2_t h[NP];
+                if constexpr (VT == PKV_TYPE_Q8_0) {          // int8 b -> offset binary b + 128 -> f16 bits 0x6400 | u = 1024 + u -> minus 1152
+                    const uint32_t y = vw[j] ^ 0x80808080u;
+                    const uint32_t a01 = __builtin_amdgcn_perm(0x64646464u, y, 0x04010400u), a23 = __builtin_amdgcn_perm(0x64646464u, y, 0x04030402u);
+                    const half2_t off = {(_Float16) -1152.0f, (_Float16) -1152.0f};
+                    h[0] = *reinterpret_cast<const half2_t *>(&a01) + off;
+                    h[1] = *reinterpret_cast<const half2_t *>(&a23) + off;
+                } else {                                      // nibbles k and k + 4: 1024 + n -> minus 1032 (the -8 of q4_0 included)
+                    const half2_t off = {(_Float16) -1032.0f, (_Float16) -1032.0f};
 #pragma unroll
-                    for (int g = 0; g < G; ++g) acc[g][j] = fmaf(p[g], vf, acc[g][j]);
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t a = ((vw[j] >> (4 * k)) & 0x000F000Fu) | 0x64006400u;
+                        h[k] = *reinterpret_cast<const half2_t *>(&a) + off;
+                    }
                 }
+#pragma unroll
+                for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g][j] = __builtin_amdgcn_fdot2(h[pr], pp[pr][g], acc[g][j], false);
             }
         }
     }
@@ -712,6 +744,48 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decod
     ts.at(9);                           // every wave of the workgroup has arrived
 
     // ---- merge the waves (each has its own max) and publish one (m, l, O) partial per workgroup -------------------
+#ifndef PKV_PART_WIDE
+#define PKV_PART_WIDE 1
+#endif
+#ifndef PKV_KV_AUX
+#define PKV_KV_AUX 2
+#endif
+    if constexpr (!FUSED && PKV_PART_WIDE != 0) {   // experiment: the partial leaves as 16-byte stores of G * D / 4 threads (2: write-through, no dirty L2 lines at the end of the kernel)
+        constexpr int C4w = G * D / 4;
+        if (tid < C4w) {
+            const int g = tid / (D / 4), d4 = tid % (D / 4);
+            float mw[NW], lw[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const float2 t = *reinterpret_cast<const float2 *>(&sML[w][g][0]); mw[w] = t.x; lw[w] = t.y; }
+            float M = mw[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, mw[w]);
+            const float Mf = fmaxf(M, -3.0e38f);
+            float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float l = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float  f = __expf(mw[w] - Mf);
+                const float4 v = *reinterpret_cast<const float4 *>(&sO[w][g][d4 * 4]);
+                o.x = fmaf(v.x, f, o.x); o.y = fmaf(v.y, f, o.y); o.z = fmaf(v.z, f, o.z); o.w = fmaf(v.w, f, o.w);
+                l = fmaf(lw[w], f, l);
+            }
+            const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
+            if (PKV_PART_WIDE == 2) {
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.part_o + pi * D, 0, D * 4, 0x00020000);
+                u4_t ov; ov.x = __float_as_uint(o.x); ov.y = __float_as_uint(o.y); ov.z = __float_as_uint(o.z); ov.w = __float_as_uint(o.w);
+                __builtin_amdgcn_raw_buffer_store_b128(ov, ro, d4 * 16, 0, 16);
+                if (d4 == 0) {
+                    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.part_ml + pi * 2, 0, 8, 0x00020000);
+                    u2_t mv; mv.x = __float_as_uint(M); mv.y = __float_as_uint(l);
+                    __builtin_amdgcn_raw_buffer_store_b64(mv, rm, 0, 0, 16);
+                }
+            } else {
+                *reinterpret_cast<float4 *>(&a.part_o[pi * D + d4 * 4]) = o;
+                if (d4 == 0) *reinterpret_cast<float2 *>(&a.part_ml[pi * 2]) = make_float2(M, l);
+            }
+        }
+    } else
     if constexpr (!FUSED) {
         static_assert((G * D) % NT == 0 || G * D < NT, "one output element per thread and pass");
         for (int e = tid; e < G * D; e += NT) {

@@ -512,6 +512,12 @@ int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream) {
     PKV_REQUIRE(x && y && n >= 0, "pkv_silu_f32: bad arguments");
     return launch_silu(x, y, n, (hipStream_t) stream);
 }
+int pkv_soft_max_ext_f32(const float * x, const void * mask, int mask_f16, float * y, int64_t ne00, int64_t ne01, int64_t ne02, int64_t ne03, float scale,
+                         float max_bias, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(x && y && ne00 > 0 && ne01 >= 0 && ne02 > 0 && ne03 > 0 && max_bias >= 0.0f, "pkv_soft_max_ext_f32: bad arguments");
+    return launch_soft_max(x, mask, mask_f16, y, ne00, ne01, ne02, ne03, scale, max_bias, (hipStream_t) stream);
+}
 int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0, "pkv_mul_mat: bad arguments");

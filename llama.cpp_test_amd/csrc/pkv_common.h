@@ -45,6 +45,29 @@ __host__ __device__ inline size_t row_size(int type, int64_t ne) {
 }
 inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0; }
 
+// ---- canonical sum of squares of an RMS norm -------------------------------------------------------
+// rms_norm_mul_kernel (pkv_layer_ops.hip) and the norm prologue of the products (pkv_gemv.hip) must produce the same bits whatever their
+// workgroup shape.  ggml_compute_forward_rms_norm_f32 (/ref/ggml/src/ggml-cpu/ggml-cpu.c:8215-8260) adds (ggml_float)(x * x): f32 squares,
+// f64 sum, mean = (float)(sum / ne00), scale = 1 / sqrtf(mean + eps).  Same here, in a fixed order: per 256-element block (one wave, one
+// float4 per lane) x, y, z, w in order, an xor-shuffle tree over the wave, then the blocks in index order.
+#ifdef __HIPCC__
+__device__ __forceinline__ double block_sumsq(const float4 v) {
+    double s = (double) __fmul_rn(v.x, v.x);
+    s += (double) __fmul_rn(v.y, v.y);
+    s += (double) __fmul_rn(v.z, v.z);
+    s += (double) __fmul_rn(v.w, v.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+__device__ __forceinline__ float rms_scale(const double * block_sums, int n_blocks, int64_t ne0, float eps) {
+    double t = 0.0;
+    for (int b = 0; b < n_blocks; ++b) t += block_sums[b];
+    const float mean = (float) (t / (double) ne0);
+    return 1.0f / sqrtf(mean + eps);
+}
+#endif
+
 // ---- kernel launchers (pkv_kernels_*.hip) ---------------------------------------------------------
 struct RopeDev {  // pkv_rope_params resolved on the host (corr dims = ggml_rope_yarn_corr_dims, /ref/ggml/src/ggml.c:3739)
     int   n_dims, mode;
@@ -82,6 +105,8 @@ int launch_rms_norm_mul(const float * x, const float * res, float * x_out, const
 int launch_silu_mul(const float * g, const float * u, float * y_silu, float * y, int64_t n, hipStream_t st);
 int launch_binary(int op, const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, hipStream_t st);
 int launch_silu(const float * x, float * y, int64_t n, hipStream_t st);
+int launch_soft_max(const float * x, const void * mask, int mask_f16, float * y, int64_t ne00, int64_t ne01, int64_t ne02, int64_t ne03, float scale, float max_bias,
+                    hipStream_t st);
 int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st);
 int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                          hipStream_t st);

