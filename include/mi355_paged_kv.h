@@ -349,6 +349,15 @@ int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream);
 /* ggml_soft_max_ext (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10222-10318; the softmax of the non-flash-attention path, /ref/src/llama-graph.cpp:1201-1239):
  * y[i3][i2][i1][:] = softmax(x[...][:] * scale + slope(i2) * mask[i1][:]); x, y f32 contiguous [ne03][ne02][ne01][ne00] (y may alias x); mask NULL or
  * [>= ne01][ne00] rows of f32 (mask_f16 = 0) or f16 (1), broadcast over i2, i3; slope = ALiBi (max_bias > 0: m0^(h+1) / m1^(2(h-n_head_log2)+1), h = i2) else 1 */
+/* The two generic ops a non-flash-attention graph needs beside the softmax (`-fa 0`: /ref/src/llama-graph.cpp:1201-1239, transposed V store :1387-1394).
+ * Shapes / strides as ggml's ne[4] / nb[4] (elements / BYTES, dimension 0 first).
+ *   pkv_cpy_strided     : ggml_cpy / ggml_cont between strided f32 / f16 tensors of equal element count (element i of src in its index order -> element i of dst)
+ *   pkv_mul_mat_strided : ggml_mul_mat with a strided, batched, broadcast f16 / f32 first operand [K, M, b2, b3] (unit stride in K) and an f32 second operand
+ *                         [K, N, B2, B3] (unit stride in K; B2 % b2 == 0, B3 % b3 == 0); y f32 contiguous [M, N, B2, B3] */
+int pkv_cpy_strided(const void * src, int src_type, const int64_t * ne_src, const int64_t * nb_src, void * dst, int dst_type, const int64_t * ne_dst, const int64_t * nb_dst,
+                    void * stream);
+int pkv_mul_mat_strided(const void * w, int type_w, const int64_t * ne_w, const int64_t * nb_w, const float * x, const int64_t * ne_x, const int64_t * nb_x, float * y,
+                        void * stream);
 int pkv_soft_max_ext_f32(const float * x, const void * mask, int mask_f16, float * y, int64_t ne00, int64_t ne01, int64_t ne02, int64_t ne03, float scale,
                          float max_bias, void * stream);
 int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream);

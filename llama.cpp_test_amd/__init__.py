@@ -447,6 +447,41 @@ def silu(x, out=None, stream=None):
     return out
 
 
+def _ggml_dims(t):
+    """(ne[4], nb[4]) of a torch tensor in ggml's order: dimension 0 = the last torch dimension, strides in BYTES"""
+    sh, st = list(t.shape)[::-1], [x * t.element_size() for x in t.stride()][::-1]
+    while len(sh) < 4:
+        sh.append(1)
+        st.append(st[-1] * sh[-2] if st else t.element_size())
+    return (C.c_int64 * 4)(*sh), (C.c_int64 * 4)(*st)
+
+
+def _plain_type(t):
+    import torch
+    return {torch.float32: F32, torch.float16: F16}[t.dtype]
+
+
+def cpy_strided(src, dst, stream=None):
+    """ggml_cpy / ggml_cont between strided f32 / f16 tensors (any torch views) of equal element count"""
+    ns, bs = _ggml_dims(src)
+    nd, bd = _ggml_dims(dst)
+    check(lib().pkv_cpy_strided(C.c_void_p(_ptr(src)), _plain_type(src), ns, bs, C.c_void_p(_ptr(dst)), _plain_type(dst), nd, bd, C.c_void_p(_stream(stream))))
+    return dst
+
+
+def mul_mat_strided(w, x, out=None, stream=None):
+    """ggml_mul_mat on strided / batched / broadcast operands: w f16 / f32 [b3][b2][M][K], x f32 [B3][B2][N][K] (any torch views with unit stride in K)
+    -> f32 [B3][B2][N][M] contiguous"""
+    import torch
+    w4 = w.reshape((1,) * (4 - w.dim()) + tuple(w.shape)) if w.dim() < 4 else w
+    x4 = x.reshape((1,) * (4 - x.dim()) + tuple(x.shape)) if x.dim() < 4 else x
+    out = torch.empty((x4.shape[0], x4.shape[1], x4.shape[2], w4.shape[2]), dtype=torch.float32, device=x.device) if out is None else out
+    nw, bw = _ggml_dims(w4)
+    nx, bx = _ggml_dims(x4)
+    check(lib().pkv_mul_mat_strided(C.c_void_p(_ptr(w4)), _plain_type(w4), nw, bw, C.c_void_p(_ptr(x4)), nx, bx, C.c_void_p(_ptr(out)), C.c_void_p(_stream(stream))))
+    return out
+
+
 def soft_max_ext(x, mask=None, scale: float = 1.0, max_bias: float = 0.0, out=None, stream=None):
     """ggml_soft_max_ext over the last dimension of x f32 [ne3][ne2][ne1][ne0] (fewer dimensions: leading ones); mask f32 / f16 [>= ne1][ne0]"""
     import torch

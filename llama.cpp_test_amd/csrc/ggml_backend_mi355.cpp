@@ -307,13 +307,21 @@ ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
     return GGML_STATUS_SUCCESS;
 }
 
+bool plain_type(ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
+// ggml_cpy / ggml_cont between strided f32 / f16 tensors (the V store into the transposed v cache of a -fa 0 graph, /ref/src/llama-graph.cpp:1387-1394;
+// kqv_merged -> cont, :1232-1234): the generic element-by-element copy
+bool supports_cpy_strided(const ggml_tensor * s, const ggml_tensor * d) {
+    return s && d && plain_type(s->type) && plain_type(d->type) && ggml_nelements(s) == ggml_nelements(d);
+}
 bool supports_cpy(const ggml_tensor * op) {
     const ggml_tensor * s = op->src[0], * d = op->src[1];
     // the KV store of build_attn copies k_cur [head_dim, n_head_kv, n_tokens] into a 1-D view of the cache
     // (/ref/src/llama-graph.cpp:1375-1397): shapes differ, the element order does not; rows of 64/128 keep quant blocks whole
-    return s && d && s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) &&
-           ggml_nelements(s) == ggml_nelements(d) && s->ne[0] % 64 == 0;
+    if (s && d && s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) &&
+        ggml_nelements(s) == ggml_nelements(d) && s->ne[0] % 64 == 0) return true;
+    return supports_cpy_strided(s, d);
 }
+bool supports_cont(const ggml_tensor * op) { return supports_cpy_strided(op->src[0], op) && op->src[0]->type == op->type; }
 // the paged mirror a KV-store CPY can write directly: dst is a view into a cache tensor of this buffer type whose mirror exists, the
 // copy covers whole cells [*cell0, *cell0 + *n_cells) of it
 const kv_mirror * store_mirror(const ggml_tensor * cpy, int64_t * cell0, int64_t * n_cells) {
@@ -332,9 +340,18 @@ const kv_mirror * store_mirror(const ggml_tensor * cpy, int64_t * cell0, int64_t
     *n_cells = n_el / per_cell;
     return &m;
 }
+ggml_status run_cpy_strided(backend_ctx * bc, const ggml_tensor * s, ggml_tensor * d) {
+    int64_t nbs[4], nbd[4];
+    for (int i = 0; i < 4; ++i) { nbs[i] = (int64_t) s->nb[i]; nbd[i] = (int64_t) d->nb[i]; }
+    const int rc = pkv_cpy_strided(bc->src_data(s), s->type, s->ne, nbs, d->data, d->type, d->ne, nbd, bc->stream);
+    if (rc) { MI355_LOG("strided cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+    note_write_all(d);
+    return GGML_STATUS_SUCCESS;
+}
 ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     const ggml_tensor * s = op->src[0];
     ggml_tensor * d = op->src[1];
+    if (!(s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) && s->ne[0] % 64 == 0)) return run_cpy_strided(bc, s, d);
     // the KV store of a step into a cache tensor that already has its paged mirror: flat bytes and mirror rows in ONE launch (same
     // quantized bits), nothing left to re-scatter at the next attention call
     int64_t cell0, n_cells;
@@ -374,13 +391,24 @@ bool supports_soft_max(const ggml_tensor * op) {
     return true;
 }
 bool supports_silu(const ggml_tensor * op) { return ggml_get_unary_op(op) == GGML_UNARY_OP_SILU && f32c(op->src[0]) && f32c(op); }
-bool supports_mul_mat(const ggml_tensor * op) {
+bool mul_mat_2d(const ggml_tensor * op) {
     const ggml_tensor * w = op->src[0], * x = op->src[1];
     if (!w || !f32c(x) || !f32c(op) || !ggml_is_contiguous(w)) return false;
-    if (w->type != GGML_TYPE_F32 && w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q8_0 && w->type != GGML_TYPE_Q4_K) return false;
+    if (w->type != GGML_TYPE_F32 && w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q8_0 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K) return false;
     if (w->ne[2] != 1 || w->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1) return false;   // plain 2-D products only
-    return w->ne[0] == x->ne[0] && w->ne[0] % (w->type == GGML_TYPE_F32 ? 4 : (w->type == GGML_TYPE_F16 ? 8 : (w->type == GGML_TYPE_Q4_K ? 256 : 32))) == 0;
+    if (w->type == GGML_TYPE_Q6_K && (w->ne[0] % 256 != 0 || (x->ne[1] == 1 && w->ne[1] % 2 != 0))) return false;   // q6_K: the decode product (row pairs) or the MFMA product
+    return w->ne[0] == x->ne[0] && w->ne[0] % (w->type == GGML_TYPE_F32 ? 4 : (w->type == GGML_TYPE_F16 ? 8 : ((w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) ? 256 : 32))) == 0;
 }
+// kq = mul_mat(k, q) and kqv = mul_mat(v, kq) of a -fa 0 graph: f16 views of the cache (permuted / transposed, broadcast over the query heads of a kv
+// head) against permuted f32 activations (/ref/src/llama-graph.cpp:1201-1230)
+bool mul_mat_strided(const ggml_tensor * op) {
+    const ggml_tensor * w = op->src[0], * x = op->src[1];
+    if (!w || !x || !plain_type(w->type) || x->type != GGML_TYPE_F32 || !f32c(op)) return false;
+    if (w->nb[0] != ggml_type_size(w->type) || x->nb[0] != sizeof(float) || w->ne[0] != x->ne[0]) return false;
+    if (w->ne[2] <= 0 || w->ne[3] <= 0 || x->ne[2] % w->ne[2] != 0 || x->ne[3] % w->ne[3] != 0 || x->ne[2] * x->ne[3] > 65535) return false;
+    return op->ne[0] == w->ne[1] && op->ne[1] == x->ne[1] && op->ne[2] == x->ne[2] && op->ne[3] == x->ne[3];
+}
+bool supports_mul_mat(const ggml_tensor * op) { return mul_mat_2d(op) || mul_mat_strided(op); }
 ggml_status run_layer_op(backend_ctx * bc, ggml_tensor * op) {
     int rc = PKV_ERR_UNSUPPORTED;
     const ggml_tensor * a = op->src[0], * b = op->src[1];
@@ -397,7 +425,14 @@ ggml_status run_layer_op(backend_ctx * bc, ggml_tensor * op) {
                                       scale, max_bias, bc->stream);
         } break;
         case GGML_OP_UNARY: rc = pkv_silu_f32((const float *) a->data, (float *) op->data, ggml_nelements(a), bc->stream); break;
-        case GGML_OP_MUL_MAT: rc = pkv_mul_mat(a->data, a->type, (const float *) b->data, (float *) op->data, a->ne[1], a->ne[0], b->ne[1], bc->stream); break;
+        case GGML_OP_MUL_MAT:
+            if (mul_mat_2d(op)) rc = pkv_mul_mat(a->data, a->type, (const float *) b->data, (float *) op->data, a->ne[1], a->ne[0], b->ne[1], bc->stream);
+            else {
+                int64_t nba[4], nbb[4];
+                for (int i = 0; i < 4; ++i) { nba[i] = (int64_t) a->nb[i]; nbb[i] = (int64_t) b->nb[i]; }
+                rc = pkv_mul_mat_strided(a->data, a->type, a->ne, nba, (const float *) bc->src_data(b), b->ne, nbb, (float *) op->data, bc->stream);
+            }
+            break;
         default: break;
     }
     if (rc) { MI355_LOG("%s failed: %s\n", ggml_op_name(op->op), pkv_last_error()); return GGML_STATUS_FAILED; }
@@ -632,6 +667,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             case GGML_OP_ROPE:           st = run_rope(bc, n, false); break;
             case GGML_OP_ROPE_BACK:      st = run_rope(bc, n, true); break;
             case GGML_OP_CPY:            st = run_cpy(bc, n); break;
+            case GGML_OP_CONT:           st = run_cpy_strided(bc, n->src[0], n); break;
             case GGML_OP_RMS_NORM: case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_UNARY: case GGML_OP_MUL_MAT: case GGML_OP_SOFT_MAX: st = run_layer_op(bc, n); break;
             default: MI355_LOG("op %s reached graph_compute but is not supported\n", ggml_op_name(n->op)); return GGML_STATUS_FAILED;
         }
@@ -689,6 +725,7 @@ bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
         case GGML_OP_FLASH_ATTN_EXT: return supports_flash_attn(op);
         case GGML_OP_ROPE: case GGML_OP_ROPE_BACK: return supports_rope(op);
         case GGML_OP_CPY: return supports_cpy(op);
+        case GGML_OP_CONT: return supports_cont(op);
         case GGML_OP_RMS_NORM: return supports_rms_norm(op);
         case GGML_OP_ADD: case GGML_OP_MUL: return supports_binary(op);
         case GGML_OP_UNARY: return supports_silu(op);

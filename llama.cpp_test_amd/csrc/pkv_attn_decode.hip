@@ -304,17 +304,15 @@ __device__ __forceinline__ void v_row_to_lds(VCur<D> & sv, int lane, const Q2 & 
     if (VT != PKV_TYPE_F16 && (lane & 15) == 0) sv.d[e0 / PKV_QK] = h_val(v.d);
 }
 
-template <int KT, int VT, int D>
+template <int KT, int VT, int D, int TPWQ = 16>
 struct Geo {
     using KT_ = KTr<KT, D>;
     static constexpr int K_LPR = KT_::LPR, K_RPL = 64 / K_LPR;
     static constexpr int V_LPR = D / 4, V_TL = VTr<VT>::TL, V_RPL = (64 / V_LPR) * V_TL;
-#ifndef PKV_TPW_Q
-#define PKV_TPW_Q 16
-#endif
     // quantized tiles are 2-4x fewer bytes per token: a wave that owns 16 tokens spends more instructions on its fixed work (softmax, reductions, the
-    // strip, the merge) than on the dots — PKV_TPW_Q tokens per wave for them
-    static constexpr int TPW = imax((KT != PKV_TYPE_F16 || VT != PKV_TYPE_F16) ? PKV_TPW_Q : 16, imax(K_RPL, V_RPL));   // tokens per wave
+    // strip, the merge) than on the dots.  TPWQ = 32 tokens per wave for them when the launch has workgroups to spare (many sequences: q8_0 0.56 -> 0.62,
+    // q4_0 0.31 -> 0.36 of HBM peak at 32 sequences); at one sequence the 8-wave workgroup hides more latency (4.8 vs 5.1 us) and stays
+    static constexpr int TPW = imax((KT != PKV_TYPE_F16 || VT != PKV_TYPE_F16) ? TPWQ : 16, imax(K_RPL, V_RPL));   // tokens per wave
     static constexpr int NW  = WG_TOK / TPW;                   // waves per workgroup
     static constexpr int K_NL = TPW / K_RPL, V_NL = TPW / V_RPL;
 };
@@ -379,12 +377,12 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int off) 
 #ifndef PKV_OCC
 #define PKV_OCC 1
 #endif
-template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0>
-__global__ void __launch_bounds__((64 * Geo<KT, VT, D>::NW), PKV_OCC) attn_decode_kernel(const DecodeArgs a) {
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0, int TPWQ = 16>
+__global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn_decode_kernel(const DecodeArgs a) {
     Stamps<STAMP> ts;
     ts.real(0);
     ts.at(1);
-    using GE = Geo<KT, VT, D>;
+    using GE = Geo<KT, VT, D, TPWQ>;
     using KT_ = KTr<KT, D>;
     constexpr int K_LPR = GE::K_LPR, K_RPL = GE::K_RPL, K_NL = GE::K_NL;
     constexpr int V_LPR = GE::V_LPR, V_TL = GE::V_TL, V_RPL = GE::V_RPL, V_NL = GE::V_NL;
@@ -1015,6 +1013,10 @@ template <int KT, int VT, int D, int G>
 int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     dim3 grid(da.n_splits, da.n_head_kv, n_seq);
     const dim3 block(64 * Geo<KT, VT, D>::NW);
+    // quantized KV with workgroups to spare: 32 tokens per wave (4-wave workgroups)
+    constexpr bool QKV = KT != PKV_TYPE_F16 || VT != PKV_TYPE_F16;
+    const bool wide = QKV && (long) da.n_splits * da.n_head_kv * n_seq >= 1024;
+    const dim3 block32(64 * Geo<KT, VT, D, 32>::NW);
     const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr || da.mask != nullptr;
     if (da.k_cur && da.counters) {   // the whole decode step of a layer in ONE launch
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, true>, grid, block, st, da);
@@ -1028,12 +1030,15 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
             }
         }
         if (da.stamps) { set_error("pkv_attn_decode_stamps: f16 KV, head_dim 128, gqa 4 or 8 only"); return PKV_ERR_UNSUPPORTED; }
-        launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
+        if constexpr (QKV) { if (wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, 32>, grid, block32, st, da); }
+        if (!wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
         if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
     } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, false>, grid, block, st, da);
     } else {
-        if (!cap && !sp)      launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false>, grid, block, st, da);
+        if constexpr (QKV) { if (wide && !cap && !sp) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false, 0, 32>, grid, block32, st, da); }
+        if (wide && !cap && !sp) {}
+        else if (!cap && !sp) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false>, grid, block, st, da);
         else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false, false>, grid, block, st, da);
         else if (cap && !sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, false, false, false>, grid, block, st, da);
         else                  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, true, false, false>, grid, block, st, da);

@@ -512,6 +512,18 @@ int pkv_silu_f32(const float * x, float * y, int64_t n, void * stream) {
     PKV_REQUIRE(x && y && n >= 0, "pkv_silu_f32: bad arguments");
     return launch_silu(x, y, n, (hipStream_t) stream);
 }
+int pkv_cpy_strided(const void * src, int src_type, const int64_t * ne_src, const int64_t * nb_src, void * dst, int dst_type, const int64_t * ne_dst, const int64_t * nb_dst,
+                    void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(src && dst && ne_src && nb_src && ne_dst && nb_dst, "pkv_cpy_strided: null pointer");
+    return launch_cpy_strided(src, src_type, ne_src, nb_src, dst, dst_type, ne_dst, nb_dst, (hipStream_t) stream);
+}
+int pkv_mul_mat_strided(const void * w, int type_w, const int64_t * ne_w, const int64_t * nb_w, const float * x, const int64_t * ne_x, const int64_t * nb_x, float * y,
+                        void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(w && x && y && ne_w && nb_w && ne_x && nb_x, "pkv_mul_mat_strided: null pointer");
+    return launch_mul_mat_strided(w, type_w, ne_w, nb_w, x, ne_x, nb_x, y, (hipStream_t) stream);
+}
 int pkv_soft_max_ext_f32(const float * x, const void * mask, int mask_f16, float * y, int64_t ne00, int64_t ne01, int64_t ne02, int64_t ne03, float scale,
                          float max_bias, void * stream) {
     if (int rc = ensure_device()) return rc;
@@ -521,8 +533,8 @@ int pkv_soft_max_ext_f32(const float * x, const void * mask, int mask_f16, float
 int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0, "pkv_mul_mat: bad arguments");
-    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : (type_w == PKV_TYPE_Q4_K ? 256 : PKV_QK))) == 0 &&
-                ((uintptr_t) x % 16) == 0 && ((uintptr_t) w % (type_w == PKV_TYPE_Q8_0 ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
+    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : ((type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K) ? 256 : PKV_QK))) == 0 &&
+                ((uintptr_t) x % 16) == 0 && ((uintptr_t) w % ((type_w == PKV_TYPE_Q8_0 || type_w == PKV_TYPE_Q6_K) ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
     return launch_mul_mat(w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
 }
 int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,

@@ -105,11 +105,17 @@ int launch_rms_norm_mul(const float * x, const float * res, float * x_out, const
 int launch_silu_mul(const float * g, const float * u, float * y_silu, float * y, int64_t n, hipStream_t st);
 int launch_binary(int op, const float * a, const float * b, float * y, int64_t n_rows, int64_t ne0, int64_t b_rows, hipStream_t st);
 int launch_silu(const float * x, float * y, int64_t n, hipStream_t st);
+int launch_cpy_strided(const void * src, int src_type, const int64_t * ne_s, const int64_t * nb_s, void * dst, int dst_type, const int64_t * ne_d, const int64_t * nb_d, hipStream_t st);
+int launch_mul_mat_strided(const void * w, int type_w, const int64_t * ne_w, const int64_t * nb_w, const float * x, const int64_t * ne_x, const int64_t * nb_x, float * y,
+                           hipStream_t st);
 int launch_soft_max(const float * x, const void * mask, int mask_f16, float * y, int64_t ne00, int64_t ne01, int64_t ne02, int64_t ne03, float scale, float max_bias,
                     hipStream_t st);
 int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st);
 int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                          hipStream_t st);
+// batched products on the matrix cores (pkv_gemm.hip)
+bool gemm_supported(int type_w, int64_t M, int64_t K);
+int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st);
 int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);
 // decode-step products for K-quant weights (pkv_gemv.hip)
 size_t act_image_bytes(int64_t K);

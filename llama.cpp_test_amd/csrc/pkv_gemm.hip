@@ -1,0 +1,182 @@
+// pkv_gemm.hip — batched weight products (prompt processing: many activation columns) on the matrix cores of gfx950.
+//
+// SURVEY §8(f) row 1, "MFMA batched products": ggml_mul_mat of a llama layer at n_tokens > 1 (/ref/src/llama-model.cpp:4070-4160; harness sweep
+// /ref/tests/test-backend-ops.cpp:4436-4442; CPU kernel ggml_compute_forward_mul_mat, /ref/ggml/src/ggml-cpu/ggml-cpu.c:7467-7640):
+//     y[n][m] = sum_k W[m][k] x[n][k],   W = M rows of K elements in f16 / q8_0 / q4_K / q6_K (the reference's row formats), x = N rows of K f32.
+// The decode-step kernels (pkv_gemv.hip, pkv_layer_ops.hip) stream W once per activation column; here every weight tile is read ONCE per 128 columns,
+// dequantized to f16 on its way into LDS, and multiplied by v_mfma_f32_32x32x16_f16 with f32 accumulation (the activations are rounded to f16: the
+// reference's CPU backend rounds them to q8_K / q8_0 integers or f16 — both are ~1e-3 relative per element; the harness bar NMSE 5e-4 holds).
+//
+//   workgroup = 128 (m) x 128 (n) outputs, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers);
+//   K in steps of 64: thread t stages row t >> 1, 32-element half t & 1 of BOTH operands — one q4_K / q6_K sub-block (or q8_0 block, or 32 halfs)
+//   of W, 32 floats of x — raw loads issued one step ahead of the conversion (issue early / write late), two barriers per step;
+//   LDS rows of 64 f16 padded to 144 B: the 16-byte fragment reads (lane = row r, k = 8 h + ..) are conflict-free;
+//   fragments per cdna_hip_programming.md §3: A[row r][k = 8 h + j], B[k = 8 h + j][col r]; C col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h,
+//   so a lane owns 4 consecutive m of one token n per register group: float4 stores into y[n][m].
+#include "pkv_common.h"
+
+namespace pkv {
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64, LDR = BK + 8;   // LDS row = 72 halfs = 144 B
+
+__device__ __forceinline__ float hf(uint16_t b) { return (float) *reinterpret_cast<const _Float16 *>(&b); }
+__device__ __forceinline__ uint4 ldu(const unsigned char * p) { return *reinterpret_cast<const uint4 *>(p); }
+
+// raw bytes of 32 consecutive weights of one row (k0 a multiple of 32), and their conversion to 32 halfs
+template <int T> struct RawW;
+template <> struct RawW<PKV_TYPE_F16> {
+    uint4 q[4];
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + k0 * 2;
+        q[0] = ldu(p); q[1] = ldu(p + 16); q[2] = ldu(p + 32); q[3] = ldu(p + 48); }
+    __device__ __forceinline__ void to_half(_Float16 * o, int64_t) const { uint4 * d = reinterpret_cast<uint4 *>(o); d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3]; }
+};
+template <> struct RawW<PKV_TYPE_Q8_0> {   // block_q8_0: f16 d, int8 qs[32] (/ref/ggml/src/ggml-common.h:197-203)
+    uint4 q[2]; uint16_t d;
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 5) * 34;
+        d = *reinterpret_cast<const uint16_t *>(p); q[0] = ldu(p + 2); q[1] = ldu(p + 18); }
+    __device__ __forceinline__ void to_half(_Float16 * o, int64_t) const {
+        const float df = hf(d);
+        const signed char * b = reinterpret_cast<const signed char *>(q);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) o[i] = (_Float16) (df * (float) b[i]);
+    }
+};
+template <> struct RawW<PKV_TYPE_Q4_K> {   // block_q4_K (:279-290): sub-block j = (k0 % 256) / 32: qs[32 (j / 2) + l] nibble j & 1
+    uint4 h, q[2];
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 8) * 144; const int j = (int) (k0 & 255) >> 5;
+        h = ldu(p); q[0] = ldu(p + 16 + 32 * (j >> 1)); q[1] = ldu(p + 32 + 32 * (j >> 1)); }
+    __device__ __forceinline__ void to_half(_Float16 * o, int64_t k0) const {
+        const int j = (int) (k0 & 255) >> 5;
+        const float d = hf((uint16_t) (h.x & 0xFFFF)), dmin = hf((uint16_t) (h.x >> 16));
+        const int sh = 8 * (j & 3);
+        const int b0 = (int) ((h.y >> sh) & 0xFF), b1 = (int) ((h.z >> sh) & 0xFF), b2 = (int) ((h.w >> sh) & 0xFF);   // get_scale_min_k4
+        const int sc = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4)), mn = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
+        const float d1 = d * (float) sc, m1 = dmin * (float) mn;
+        const unsigned char * b = reinterpret_cast<const unsigned char *>(q);
+        const int s4 = 4 * (j & 1);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) o[i] = (_Float16) (d1 * (float) ((b[i] >> s4) & 0xF) - m1);
+    }
+};
+template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 256, n = e0 / 128, j = (e0 % 128) / 32: ql[64 n + 32 (j & 1) + l] nibble j >> 1, qh[32 n + l] bits 2 j
+    uint4 ql[2], qh[2]; uint16_t sc2, d;
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 8) * 210; const int e0 = (int) (k0 & 255), n = e0 >> 7, j = (e0 & 127) >> 5;
+        ql[0] = ldu(p + 64 * n + 32 * (j & 1)); ql[1] = ldu(p + 64 * n + 32 * (j & 1) + 16); qh[0] = ldu(p + 128 + 32 * n); qh[1] = ldu(p + 128 + 32 * n + 16);
+        sc2 = *reinterpret_cast<const uint16_t *>(p + 192 + 8 * n + 2 * j); d = *reinterpret_cast<const uint16_t *>(p + 208); }
+    __device__ __forceinline__ void to_half(_Float16 * o, int64_t k0) const {
+        const int j = ((int) (k0 & 127)) >> 5;
+        const float df = hf(d), s0 = df * (float) (signed char) (sc2 & 0xFF), s1 = df * (float) (signed char) (sc2 >> 8);
+        const unsigned char * l = reinterpret_cast<const unsigned char *>(ql), * hh = reinterpret_cast<const unsigned char *>(qh);
+        const int s4 = 4 * (j >> 1), s2 = 2 * j;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int qv = (int) (((l[i] >> s4) & 0xF) | (((hh[i] >> s2) & 3) << 4)) - 32;
+            o[i] = (_Float16) ((i < 16 ? s0 : s1) * (float) qv);
+        }
+    }
+};
+
+struct GemmArgs { const unsigned char * w; const float * x; float * y; int64_t M, N, K, row_bytes; };
+
+template <int T>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 sA[BM * LDR], sB[BN * LDR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
+    // staging role: row srow, 32-element half shalf of both tiles (rows past the end re-read the last row; their outputs are never stored)
+    const int srow = tid >> 1, shalf = tid & 1;
+    const unsigned char * wrow = a.w + (size_t) min(m0 + srow, a.M - 1) * a.row_bytes;
+    const float * xrow = a.x + (size_t) min(n0 + srow, a.N - 1) * a.K;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    RawW<T> rw;
+    float4 rx[8];
+    auto load_raw = [&](int64_t k0) {
+        rw.load(wrow, k0 + 32 * shalf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rx[i] = reinterpret_cast<const float4 *>(xrow + k0 + 32 * shalf)[i];
+    };
+    load_raw(0);
+    for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
+        {   // conversion of the staged step into LDS
+            __attribute__((aligned(16))) _Float16 tmp[32];
+            rw.to_half(tmp, k0 + 32 * shalf);
+            uint4 * da = reinterpret_cast<uint4 *>(sA + srow * LDR + 32 * shalf);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) da[i] = reinterpret_cast<const uint4 *>(tmp)[i];
+            __attribute__((aligned(16))) _Float16 tb[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { tb[4 * i] = (_Float16) rx[i].x; tb[4 * i + 1] = (_Float16) rx[i].y; tb[4 * i + 2] = (_Float16) rx[i].z; tb[4 * i + 3] = (_Float16) rx[i].w; }
+            uint4 * db = reinterpret_cast<uint4 *>(sB + srow * LDR + 32 * shalf);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) db[i] = reinterpret_cast<const uint4 *>(tb)[i];
+        }
+        __syncthreads();
+        if (k0 + BK < a.K) load_raw(k0 + BK);            // the next step's raw bytes fly under this step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            half8_t af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const half8_t *>(sA + (wm * 64 + i * 32 + r) * LDR + 16 * ks + 8 * h);
+                bf[i] = *reinterpret_cast<const half8_t *>(sB + (wn * 64 + i * 32 + r) * LDR + 16 * ks + 8 * h);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C: col (token) = lane & 31, row (m) = (reg & 3) + 8 (reg >> 2) + 4 h
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t n = n0 + wn * 64 + j * 32 + r;
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t m = m0 + wm * 64 + i * 32 + 8 * g + 4 * h;
+                if ((a.M & 3) == 0 && m + 3 < a.M) *reinterpret_cast<float4 *>(a.y + (size_t) n * a.M + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                else
+                    for (int e = 0; e < 4; ++e) if (m + e < a.M) a.y[(size_t) n * a.M + m + e] = acc[i][j][4 * g + e];
+            }
+    }
+}
+
+}  // namespace
+
+bool gemm_supported(int type_w, int64_t M, int64_t K) {
+    if (type_w != PKV_TYPE_F16 && type_w != PKV_TYPE_Q8_0 && type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q6_K) return false;
+    return M > 0 && K > 0 && K % BK == 0 && (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K ? K % 256 == 0 : true);
+}
+
+int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st) {
+    if (M == 0 || n_cols == 0) return PKV_OK;
+    if (!gemm_supported(type_w, M, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
+    PKV_REQUIRE(((uintptr_t) x % 16) == 0 && ((uintptr_t) y % 16) == 0, "pkv_mul_mat (batched): x and y must be 16-byte aligned");
+    GemmArgs a = {(const unsigned char *) w, x, y, M, n_cols, K, (int64_t) row_size(type_w, K)};
+    const dim3 grid((unsigned) ((M + BM - 1) / BM), (unsigned) ((n_cols + BN - 1) / BN));
+    switch (type_w) {
+        case PKV_TYPE_F16:  hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_F16>, grid, dim3(256), 0, st, a); break;
+        case PKV_TYPE_Q8_0: hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_Q8_0>, grid, dim3(256), 0, st, a); break;
+        case PKV_TYPE_Q4_K: hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_Q4_K>, grid, dim3(256), 0, st, a); break;
+        case PKV_TYPE_Q6_K: hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_Q6_K>, grid, dim3(256), 0, st, a); break;
+    }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+
+}  // namespace pkv

@@ -48,20 +48,24 @@ __device__ __forceinline__ int sum8(int x) {               // sum over aligned g
 // The reference takes `max` = the signed value of largest magnitude, so the sign of (d, q) follows that element's sign; here max = +amax
 // always: where the reference's max is negative, d and every q of the block come out negated TOGETHER — the products q * d, d * bsum and
 // with them every dot are the same bits (the GEMV only ever multiplies d with sums of q).
-__device__ __forceinline__ void quant_block_q8k(const float4 v, int lane, uint32_t & packed, float & d, int & bsum32) {
+__device__ __forceinline__ void quant_block_q8k(const float4 v, int lane, uint32_t & packed, float & d, int & bsum32, int & bsum16) {
     const float am = wave_amax(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     const float iscale = am != 0.0f ? -127.0f / am : 0.0f;
     const int q0 = (int) __builtin_rintf(iscale * v.x), q1 = (int) __builtin_rintf(iscale * v.y), q2 = (int) __builtin_rintf(iscale * v.z),
               q3 = (int) __builtin_rintf(iscale * v.w);
     packed = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
     d = am != 0.0f ? 1.0f / iscale : 0.0f;
-    bsum32 = sum8(q0 + q1 + q2 + q3);
+    int x = q0 + q1 + q2 + q3;
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+    bsum16 = x;                                                          // the quad's 16 elements
+    bsum32 = x + __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);   // row_half_mirror: the other quad of the 8 lanes
 }
 __global__ void __launch_bounds__(256) quant_act_kernel(const float * x, char * img, int64_t K) {
     const int64_t i4 = (int64_t) blockIdx.x * 256 + threadIdx.x;            // float4 index; K % 256 == 0: a wave never straddles the end
     if (i4 * 4 >= K) return;
-    uint32_t packed; float d; int bs;
-    quant_block_q8k(reinterpret_cast<const float4 *>(x)[i4], threadIdx.x & 63, packed, d, bs);
+    uint32_t packed; float d; int bs, bs16;
+    quant_block_q8k(reinterpret_cast<const float4 *>(x)[i4], threadIdx.x & 63, packed, d, bs, bs16);
     reinterpret_cast<uint32_t *>(img)[i4] = packed;
     if ((i4 & 63) == 0) reinterpret_cast<float *>(img + K)[i4 >> 6] = d;
     if ((i4 & 7) == 0) reinterpret_cast<int *>(img + K + (K >> 8) * 4)[i4 >> 3] = bs;
@@ -83,28 +87,35 @@ struct GemvArgs {
     int          gpr, gs;                // 64-element groups per row, LDS row stride (odd)
 };
 
-// dynamic LDS: sq[16][gs] dwords (dword wi of group g at wi * gs + g), sd[2][gs] (scale of the group's first / second 32), ss[2][gs]
+// dynamic LDS: one 80-byte RECORD per 64-element group of the column: 16 dwords of int8 quants, then a 4-dword tail
+//   TAIL 0 (q4_K rows only):  { sum of the first 32 quants, sum of the second 32, f32 scale d of the group's 256-block, - }
+//   TAIL 1 (q6_K rows about): { sums of the four runs of 16 as int16 x 4 in two dwords,            f32 scale d, - }
+// A lane reads its group with five 16-byte LDS loads at immediate offsets from ONE address (r02's first layout, dword wi of group g at
+// wi * gs + g, cost an address add and a 4-byte ds_read per dword: 38 of the product's ~210 vector instructions per 32 weight bytes); the
+// 20-dword stride keeps ds_read_b128 conflict-free over each of its 16-lane groups (MI355X_MICROARCH.md, LDS table).
+constexpr int REC = 20;
 extern __shared__ __attribute__((aligned(16))) uint32_t g_lds[];
 
 // one 64-element group of a block_q4_K row against the staged column; lane-private
-__device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, const uint4 & qb, int p, const uint32_t * sq, const float * sd, const float * ss, int gs, int g) {
-    uint32_t xq[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) xq[i] = sq[i * gs + g];
-    const float dx = sd[g];                                                     // the column's scale for this 256-block
-    const int   b0 = reinterpret_cast<const int *>(ss)[g], b1 = reinterpret_cast<const int *>(ss)[gs + g];   // sums of its quants, per 32
+template <int TAIL>
+__device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, const uint4 & qb, int p, const uint32_t * rec) {
+    const uint4 x0 = *reinterpret_cast<const uint4 *>(rec), x1 = *reinterpret_cast<const uint4 *>(rec + 4), x2 = *reinterpret_cast<const uint4 *>(rec + 8),
+                x3 = *reinterpret_cast<const uint4 *>(rec + 12), tl = *reinterpret_cast<const uint4 *>(rec + 16);
+    const uint32_t xq[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+    const float dx = __uint_as_float(tl.z);                                     // the column's scale for this 256-block
+    int b0, b1;                                                                 // sums of its quants, per 32
+    if constexpr (TAIL == 0) { b0 = (int) tl.x; b1 = (int) tl.y; }
+    else { b0 = ((int) (tl.x << 16) >> 16) + ((int) tl.x >> 16); b1 = ((int) (tl.y << 16) >> 16) + ((int) tl.y >> 16); }
     const float d = h2f((uint16_t) (hdr.x & 0xFFFF)) * dx, dmin = h2f((uint16_t) (hdr.x >> 16)) * dx;       // as ggml_vec_dot_q4_K_q8_K forms them
-    // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638) for sub-blocks j = 2 p, 2 p + 1, with shifts only (selecting one of hdr.y / .z / .w
-    // by a runtime index sends the header through scratch memory): byte jj = j & 3 of the three scale dwords
-    auto scale_min = [&](int j, int & s_, int & m_) {
-        const int sh = 8 * (j & 3);
-        const int b0 = (int) ((hdr.y >> sh) & 0xFF), b1 = (int) ((hdr.z >> sh) & 0xFF), b2 = (int) ((hdr.w >> sh) & 0xFF);
-        s_ = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4));
-        m_ = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
-    };
-    int s1, m1, s2, m2;
-    scale_min(2 * p, s1, m1);
-    scale_min(2 * p + 1, s2, m2);
+    // get_scale_min_k4 (/ref/ggml/src/ggml-quants.c:631-638) for sub-blocks j = 2 p, 2 p + 1, both at once in the two low bytes of a dword and
+    // without a branch: j < 4: sc = q[j] & 63, m = q[j + 4] & 63; j >= 4: sc = (q[j + 4] & 15) | (q[j - 4] >> 6 << 4), m = (q[j + 4] >> 4) | (q[j] >> 6 << 4)
+    // (q[0..3] = hdr.y, q[4..7] = hdr.z, q[8..11] = hdr.w; the pair sits at bit 16 (p & 1) of each)
+    const uint32_t sh = 16u * (uint32_t) (p & 1);
+    const uint32_t ty = hdr.y >> sh, tz = hdr.z >> sh, tw = hdr.w >> sh;
+    const uint32_t sc_lo = ty & 0x3F3Fu, mn_lo = tz & 0x3F3Fu;
+    const uint32_t sc_hi = (tw & 0x0F0Fu) | ((ty >> 2) & 0x3030u), mn_hi = ((tw >> 4) & 0x0F0Fu) | ((tz >> 2) & 0x3030u);
+    const uint32_t sc = p < 2 ? sc_lo : sc_hi, mn = p < 2 ? mn_lo : mn_hi;
+    const int s1 = (int) (sc & 0xFF), s2 = (int) (sc >> 8), m1 = (int) (mn & 0xFF), m2 = (int) (mn >> 8);
     const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
     int ilo = 0, ihi = 0;
 #pragma unroll
@@ -119,30 +130,40 @@ __device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, co
 // block_q6_K (210 bytes: every other block sits 2 bytes off a dword boundary — the 16-byte loads below are misaligned, which gfx950 global
 // loads serve correctly, probes/unaligned_probe.hip): quarter `qt` = (n, is) of the block -> elements n*128 + 32 j + 16 is + [0, 16), j = 0..3,
 // scale index 8 n + is + 2 j (dequantize_row_q6_K, /ref/ggml/src/ggml-quants.c:1690-1719).  la = ql[16 is ..], lb = ql[32 + 16 is ..],
-// hh = qh[16 is ..] of half n; sc16 = the block's 16 scales; dbits = its f16 d.
-__device__ __forceinline__ float dot_q6k(const uint4 & la4, const uint4 & lb4, const uint4 & hh4, const uint4 & sc16, uint16_t dbits, int qt,
-                                         const uint32_t * sq, const float * sd, int gs, int g64) {
+// hh = qh[16 is ..] of half n; sc16 = the block's 16 scales; dbits = its f16 d.  rec = the record of 64-group 4 b + 2 n (TAIL 1).  The 6-bit
+// quants enter the dots as they are (0..63); the -32 of the format leaves through the column's sums of 16: sum (u - 32) x = u . x - 32 sum x.
+__device__ __forceinline__ float dot_q6k(const uint4 & la4, const uint4 & lb4, const uint4 & hh4, const uint4 & sc16, uint16_t dbits, int qt, const uint32_t * rec) {
     const int n = qt >> 1, is = qt & 1;
     const uint32_t la[4] = {la4.x, la4.y, la4.z, la4.w}, lb[4] = {lb4.x, lb4.y, lb4.z, lb4.w}, hh[4] = {hh4.x, hh4.y, hh4.z, hh4.w};
     const uint32_t scw[4] = {sc16.x, sc16.y, sc16.z, sc16.w};
     int acc = 0;
+    float dx = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // the run's activations: elements n*128 + 32 j + 16 is + [0, 16) = 64-group (2 n + j / 2), dwords 8 (j & 1) + 4 is + [0, 4)
-        const int g = g64 + (j >> 1), wi0 = 8 * (j & 1) + 4 * is;
-        int idot = 0;
+    for (int gg = 0; gg < 2; ++gg) {           // the two 64-groups of this half of the block: j = 2 gg, 2 gg + 1
+        const uint32_t * r = rec + gg * REC;
+        const uint4 tl = *reinterpret_cast<const uint4 *>(r + 16);
+        if (gg == 0) dx = __uint_as_float(tl.z);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t lo = ((j & 1) ? lb[w] : la[w]) >> (4 * (j >> 1));
-            const uint32_t u  = (lo & 0x0F0F0F0Fu) | (((hh[w] >> (2 * j)) & 0x03030303u) << 4);      // 6-bit quants 0..63
-            const uint32_t v  = ((u | 0x80808080u) - 0x20202020u) ^ 0x80808080u;                     // per byte: q - 32 as int8
-            idot = __builtin_amdgcn_sdot4((int) v, (int) sq[(wi0 + w) * gs + g], idot, false);
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * gg + jj;
+            // the run's activations: elements n*128 + 32 j + 16 is + [0, 16) = dwords 8 jj + 4 is + [0, 4) of the group
+            const uint4 xv = *reinterpret_cast<const uint4 *>(r + 8 * jj + 4 * is);
+            const uint32_t x[4] = {xv.x, xv.y, xv.z, xv.w};
+            int idot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t lo = (jj ? lb[w] : la[w]) >> (4 * gg);
+                const uint32_t u  = (lo & 0x0F0F0F0Fu) | (((hh[w] >> (2 * j)) & 0x03030303u) << 4);      // 6-bit quants 0..63
+                idot = __builtin_amdgcn_sdot4((int) u, (int) x[w], idot, false);
+            }
+            const uint32_t sw = jj ? tl.y : tl.x;                                                        // sums of the runs 2 jj, 2 jj + 1 of this group
+            idot -= 32 * ((int) (sw << (16 * (1 - is))) >> 16);
+            const int si = 8 * n + is + 2 * j;                                                           // scale of this run of 16
+            const int scv = (int) (signed char) ((scw[si >> 2] >> (8 * (si & 3))) & 0xFF);
+            acc += scv * idot;
         }
-        const int si = 8 * n + is + 2 * j;                                                           // scale of this run of 16
-        const int scv = (int) (signed char) ((scw[si >> 2] >> (8 * (si & 3))) & 0xFF);
-        acc += scv * idot;
     }
-    return h2f(dbits) * sd[g64] * (float) acc;                  // ggml_vec_dot_q6_K_q8_K: d = x.d * y.d, sum_is scale * (q6 . q8)
+    return h2f(dbits) * dx * (float) acc;                      // ggml_vec_dot_q6_K_q8_K: d = x.d * y.d, sum_is scale * (q6 . q8)
 }
 
 // wave-wide sum without LDS: DPP inside the rows of 16, permlane swaps across them
@@ -162,6 +183,9 @@ __device__ __forceinline__ float wsum_dpp(float x) {
 // Plain named registers per pipeline stage (a struct handed to lambdas by reference ended up in scratch memory: 368 bytes per lane and
 // every weight load doubled by a scratch store — rocprofv3 Scratch_Size column).
 // Weight rows are read once by one CU: non-temporal loads (MI355X_MICROARCH.md price list, row nt-weights).
+#ifndef PKV_GEMV_ABLATE
+#define PKV_GEMV_ABLATE 0   // timing-only builds (results wrong): 1 = no dots (loads + reduce), 2 = no column prologue
+#endif
 typedef unsigned gv_u4 __attribute__((ext_vector_type(4)));
 #ifndef PKV_GEMV_NT
 #define PKV_GEMV_NT 0
@@ -174,17 +198,17 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
     return *reinterpret_cast<const uint4 *>(p);
 #endif
 }
-#define PKV_UNIT_DECL(S) uint4 S##r0[2], S##r1[2], S##r2[2], S##r3[2]; uint16_t S##dh[2]; int S##g[2], S##p[2], S##ty[2], S##rs[2]; bool S##ok[2];
-#define PKV_UNIT_LOAD(S, IT)                                                                                                                   \
+#define PKV_UNIT_DECL(S) uint4 S##r0[2], S##r1[2], S##r2[2], S##r3[2]; uint16_t S##dh[2]; int S##g[2], S##p[2], S##ty[2], S##rs[2]; bool S##ok[2]; int S##mi; int64_t S##m0;
+#define PKV_UNIT_LOAD(S, RPI, FI)                                                                                                              \
     {                                                                                                                                          \
-        const int it_ = (IT);                                                                                                                  \
-        const int rp_ = first + (it_ / n_f0) * stride, f0_ = (it_ % n_f0) * 128;                                                               \
+        const int rp_ = first + __builtin_amdgcn_readfirstlane(RPI) * stride, f0_ = __builtin_amdgcn_readfirstlane(FI) * 128;                  \
         const char * q0_, * q1_; int t0_, t1_, mi_; int64_t m0_;                                                                               \
         rows_of(rp_, q0_, q1_, t0_, t1_, mi_, m0_);                                                                                            \
+        S##mi = mi_; S##m0 = m0_;                                                                                                              \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                                        \
-            const int f = f0_ + 64 * u + lane;                                                                                                 \
-            S##ok[u] = f < 2 * gpr;                                                                                                            \
-            const int fc = S##ok[u] ? f : 2 * gpr - 1;                                                                                         \
+            const int f = f_lo + f0_ + 64 * u + lane;                                                                                          \
+            S##ok[u] = f < f_hi;                                                                                                               \
+            const int fc = S##ok[u] ? f : f_hi - 1;                                                                                            \
             S##rs[u] = fc >= gpr;                                                                                                              \
             S##g[u] = fc - S##rs[u] * gpr;                                                                                                     \
             S##p[u] = S##g[u] & 3;                                                                                                             \
@@ -207,23 +231,27 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
             }                                                                                                                                  \
         }                                                                                                                                      \
     }
-#define PKV_UNIT_COMPUTE(S, IT)                                                                                                                \
+#define PKV_UNIT_COMPUTE(S, RPI, FI)                                                                                                           \
     {                                                                                                                                          \
-        const int it_ = (IT);                                                                                                                  \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                                        \
             float part;                                                                                                                        \
-            if (S##ty[u] == PKV_TYPE_Q4_K) part = dot_q4k(S##r0[u], S##r1[u], S##r2[u], S##p[u], sq, sd, ss, gs, S##g[u]);                     \
-            else part = dot_q6k(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##dh[u], S##p[u], sq, sd, gs, (S##g[u] & ~3) + 2 * (S##p[u] >> 1));  \
+            if (PKV_GEMV_ABLATE == 1) { part = __uint_as_float((S##r0[u].x ^ S##r1[u].y ^ S##r2[u].z ^ S##r3[u].w ^ S##r1[u].w ^ S##r2[u].x) & 0x3fffffffu); } else \
+            if (S##ty[u] == PKV_TYPE_Q4_K) part = dot_q4k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##p[u], sq + S##g[u] * REC);                             \
+            else part = dot_q6k(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##dh[u], S##p[u], sq + ((S##g[u] & ~3) + 2 * (S##p[u] >> 1)) * REC);            \
             if (!S##ok[u]) part = 0.0f;                                                                                                        \
             acc0 += S##rs[u] ? 0.0f : part;                                                                                                    \
             acc1 += S##rs[u] ? part : 0.0f;                                                                                                    \
         }                                                                                                                                      \
-        if ((it_ + 1) % n_f0 == 0) { /* the row pair is complete */                                                                            \
-            const int rp_ = first + (it_ / n_f0) * stride;                                                                                     \
-            const char * q0_, * q1_; int t0_, t1_, mi_; int64_t m0_;                                                                           \
-            rows_of(rp_, q0_, q1_, t0_, t1_, mi_, m0_);                                                                                        \
-            const float s0 = wsum_dpp(acc0), s1 = wsum_dpp(acc1);                                                                              \
-            if (lane == 0 && live) {                                                                                                           \
+        if (__builtin_amdgcn_readfirstlane(FI) == n_f0 - 1) { /* the row pair is complete (its matrix and first row: noted when the unit was requested) */ \
+            const int mi_ = S##mi; const int64_t m0_ = S##m0;                                                                                  \
+            float s0 = wsum_dpp(acc0), s1 = wsum_dpp(acc1);                                                                                    \
+            if constexpr (KS == 2) { /* the two waves of a row pair: the second hands its sums over, the first adds (a + b: one order) */      \
+                if (kpart == 1 && lane == 0) sPart[wv >> 1] = make_float2(s0, s1);                                                             \
+                __syncthreads();                                                                                                               \
+                const float2 o_ = sPart[wv >> 1];                                                                                              \
+                s0 += o_.x; s1 += o_.y;                                                                                                        \
+            }                                                                                                                                  \
+            if (lane == 0 && live && kpart == 0) {                                                                                             \
                 if (a.silu_mul) {                                                                                                              \
                     a.y[0][m0_] = s0 / (1.0f + expf(-s0)) * s1;                                                                                \
                 } else {                                                                                                                       \
@@ -241,26 +269,34 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
 // workgroup b owns row pairs b + grid * (wv + NWV k), k = 0, 1, ...: at any moment the chip streams one contiguous band of grid * NWV row pairs and
 // every CU has the same number of busy waves.  SHORT (at most two units per wave: wq / wk / wv, wo at Llama-3-8B sizes): no loop, everything
 // the wave will ever read is requested before the column is touched.
-template <int MODE, int NWV, bool SHORT>
+// KS = 2 (ffn_down at Llama-3-8B sizes: 2048 row pairs of 3.5 units): the two halves of a row pair's groups go to two waves of the workgroup, so that
+// all 16 waves of every CU stream (and quantize the 14336-element column) and every wave is SHORT; their sums meet in LDS behind one barrier.
+template <int MODE, int NWV, bool SHORT, int KS = 1>
 __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
+    static_assert(KS == 1 || (KS == 2 && SHORT), "the split form has no loop: one barrier, reached once by every wave");
     constexpr int NT = 64 * NWV;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int gs = a.gs, gpr = a.gpr;
-    uint32_t * sq = g_lds;
-    float *    sd = reinterpret_cast<float *>(g_lds + 16 * gs);
-    float *    ss = sd + 2 * gs;
+    constexpr int TAIL = MODE == PKV_TYPE_Q4_K ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
+    const int gpr = a.gpr;
+    uint32_t * sq = g_lds;                                           // gpr records of REC dwords
     __shared__ double sred[32];                                       // sums of squares per 256-element block (norm prologue)
     const int total_rp = a.rp_end[0] > a.rp_end[1] ? (a.rp_end[0] > a.rp_end[2] ? a.rp_end[0] : a.rp_end[2]) : (a.rp_end[1] > a.rp_end[2] ? a.rp_end[1] : a.rp_end[2]);
-    const int grid = (int) gridDim.x, stride = grid * NWV;
-    const int mine = (int) blockIdx.x + grid * wv;
+    __shared__ float2 sPart[NWV / 2];
+    const int grid = (int) gridDim.x, stride = grid * (NWV / KS);
+    const int kpart = KS == 2 ? (wv & 1) : 0;
+    const int mine = (int) blockIdx.x + grid * (KS == 2 ? (wv >> 1) : wv);
     const bool live = mine < total_rp;                                // a surplus wave shadows the last row pair up to the stores: no early exit before the barriers
     const int first = min(mine, total_rp - 1);
     const int n_rp = (total_rp - first + stride - 1) / stride;       // row pairs of this wave
-    const int n_f0 = (2 * gpr + 127) / 128;                          // units per row pair
+    // (row, group) items of a row pair this wave owns: all 2 gpr of them, or one half (rounded to whole 64-lane strides)
+    const int f_half = KS == 2 ? ((gpr + 63) / 64) * 64 : 2 * gpr;
+    const int f_lo = kpart * f_half, f_hi = (KS == 2 && kpart == 0) ? f_half : 2 * gpr;
+    const int n_f0 = (f_half + 127) / 128;                           // units per row pair (per half)
     const int n_it = n_rp * n_f0;
     // kernel-argument arrays are only ever indexed with constants (a dynamic index would move the struct to scratch)
     const int e0 = a.rp_end[0], e1 = a.rp_end[1];
     auto rows_of = [&](int rp, const char *& r0, const char *& r1, int & type0, int & type1, int & mi, int64_t & m0) {
+        rp = __builtin_amdgcn_readfirstlane(rp);                      // wave-uniform by construction: the pointer arithmetic stays on the scalar unit
         mi = rp < e0 ? 0 : (rp < e1 ? 1 : 2);
         const int rpl = rp - (mi == 0 ? 0 : (mi == 1 ? e0 : e1));
         const char * w0, * w1;
@@ -275,30 +311,61 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
     };
     float acc0 = 0.0f, acc1 = 0.0f;
     PKV_UNIT_DECL(A) PKV_UNIT_DECL(B)
-    PKV_UNIT_LOAD(A, 0)                                               // the first weight loads fly while the column is prepared
-    PKV_UNIT_LOAD(B, min(1, n_it - 1))
+    // unit cursors (row pair of this wave, unit inside the pair) without divisions: l* = the next unit to request, c* = the next to consume; past
+    // the end a request re-reads the wave's last unit (the load count stays static: a load behind a branch drains the queue at the join)
+    int lr = 0, lf = 0, cr = 0, cf = 0;
+    auto step = [&](int & r, int & f) { if (++f == n_f0) { f = 0; ++r; } };
+#define PKV_LOAD_NEXT(S) { const bool past_ = lr >= n_rp; PKV_UNIT_LOAD(S, past_ ? n_rp - 1 : lr, past_ ? n_f0 - 1 : lf) step(lr, lf); }
+#define PKV_COMPUTE_NEXT(S) { PKV_UNIT_COMPUTE(S, cr, cf) step(cr, cf); }
+    PKV_LOAD_NEXT(A)                                                  // the first weight loads fly while the column is prepared
+    PKV_LOAD_NEXT(B)
     __builtin_amdgcn_sched_barrier(0);
 
+    // tail of a group's record from the quantizer's registers: lane = float4 i of the column (dword i & 15 of group i >> 4)
+    auto put_tail = [&](int i, float d, int bs32, int bs16) {
+        uint32_t * r = sq + (i >> 4) * REC + 16;
+        if constexpr (TAIL == 0) { if ((i & 7) == 0) r[(i >> 3) & 1] = (uint32_t) bs32; }
+        else                     { if ((i & 3) == 0) reinterpret_cast<uint16_t *>(r)[(i >> 2) & 3] = (uint16_t) bs16; }
+        if ((i & 15) == 0) r[2] = __float_as_uint(d);                 // the 256-block's scale, once per 64-group
+    };
+    if (PKV_GEMV_ABLATE == 2) {} else
     if (a.img) {
-        // the column image was made by a launch of its own: copy K / 4 dwords of int8, the 256-block scales, the per-32 sums
-        for (int i = threadIdx.x; i < (int) (a.K >> 2); i += NT) sq[(i & 15) * gs + (i >> 4)] = reinterpret_cast<const uint32_t *>(a.img)[i];
+        // the column image was made by a launch of its own: K / 4 dwords of int8, the 256-block scales, the per-32 sums
+        const uint32_t * qi = reinterpret_cast<const uint32_t *>(a.img);
         const float * dd = reinterpret_cast<const float *>(a.img + a.K);
         const int *   bb = reinterpret_cast<const int *>(a.img + a.K + (a.K >> 8) * 4);
-        for (int g = threadIdx.x; g < gpr; g += NT) sd[g] = dd[g >> 2];                               // the 256-block's scale, once per 64-group
-        for (int b = threadIdx.x; b < (int) (a.K >> 5); b += NT) reinterpret_cast<int *>(ss)[(b & 1) * gs + (b >> 1)] = bb[b];
+        for (int i = threadIdx.x; i < (int) (a.K >> 2); i += NT) {
+            const uint32_t w = qi[i];
+            sq[(i >> 4) * REC + (i & 15)] = w;
+            if constexpr (TAIL == 1) {                                // per-16 sums are not in the image: from the quants (4 lanes = one run of 16)
+                int x = __builtin_amdgcn_sdot4((int) w, 0x01010101, 0, false);
+                x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+                x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+                if ((i & 3) == 0) reinterpret_cast<uint16_t *>(sq + (i >> 4) * REC + 16)[(i >> 2) & 3] = (uint16_t) x;
+            }
+        }
+        for (int g = threadIdx.x; g < gpr; g += NT) sq[g * REC + 18] = __float_as_uint(dd[g >> 2]);
+        if constexpr (TAIL == 0)
+            for (int b = threadIdx.x; b < (int) (a.K >> 5); b += NT) sq[(b >> 1) * REC + 16 + (b & 1)] = (uint32_t) bb[b];
     } else {
         // ... or here: [rms_norm(x) * w ->] q8_K straight into LDS.  float4 index i = tid + NT j: the 64 lanes of a wave hold one 256-block.
         // The sum of squares is the canonical one of pkv_common.h (f32 squares accumulated in f64 per 256-block, blocks added in order), the same
         // bits whatever the workgroup shape: the fused launch and the norm + quantize + product launches produce the same image.
         const int n4 = (int) (a.K >> 2);
-        float scale = 1.0f;
-        constexpr int NV = 2048 / NT;                                 // norm: K <= 8192 (checked on the host)
-        float4 v[NV];
+        auto put = [&](int i, const float4 o) {
+            uint32_t packed; float d; int bs, bs16;
+            quant_block_q8k(o, lane, packed, d, bs, bs16);
+            sq[(i >> 4) * REC + (i & 15)] = packed;
+            put_tail(i, d, bs, bs16);
+        };
         if (a.norm_w) {
+            constexpr int NV = 2048 / NT;                             // norm: K <= 8192 (checked on the host)
+            float4 v[NV], w4[NV];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
+            for (int j = 0; j < NV; ++j) {                            // the column AND the norm weights in one memory round trip
                 const int i = threadIdx.x + NT * j;
-                v[j] = i < n4 ? reinterpret_cast<const float4 *>(a.x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[j]  = i < n4 ? reinterpret_cast<const float4 *>(a.x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                w4[j] = i < n4 ? reinterpret_cast<const float4 *>(a.norm_w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
@@ -309,39 +376,34 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
                 }
             }
             __syncthreads();
-            scale = rms_scale(sred, (n4 + 63) >> 6, a.K, a.eps);
-        }
-        auto put = [&](int i, const float4 o) {
-            uint32_t packed; float d; int bs;
-            quant_block_q8k(o, lane, packed, d, bs);
-            sq[(i & 15) * gs + (i >> 4)] = packed;
-            if ((i & 15) == 0) sd[i >> 4] = d;                        // the block's scale, once per 64-group
-            if ((i & 7) == 0) reinterpret_cast<int *>(ss)[((i >> 3) & 1) * gs + (i >> 4)] = bs;
-        };
-        if (a.norm_w) {
+            const float scale = rms_scale(sred, (n4 + 63) >> 6, a.K, a.eps);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = threadIdx.x + NT * j;                   // n4 % 64 == 0: a wave is in or out as a whole
-                if (i - lane < n4) {
-                    const float4 w4 = reinterpret_cast<const float4 *>(a.norm_w)[i];
-                    put(i, make_float4(v[j].x * scale * w4.x, v[j].y * scale * w4.y, v[j].z * scale * w4.z, v[j].w * scale * w4.w));
-                }
+                if (i - lane < n4) put(i, make_float4(v[j].x * scale * w4[j].x, v[j].y * scale * w4[j].y, v[j].z * scale * w4[j].z, v[j].w * scale * w4[j].w));
             }
         } else {
-            for (int i = threadIdx.x; i - lane < n4; i += NT) put(i, reinterpret_cast<const float4 *>(a.x)[i]);
+            constexpr int NB8 = 8;                                    // batches of 8 float4 per thread: the loads of a batch share one round trip
+            for (int i0 = threadIdx.x; i0 - lane < n4; i0 += NT * NB8) {
+                float4 v[NB8];
+#pragma unroll
+                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; v[j] = reinterpret_cast<const float4 *>(a.x)[i - lane < n4 ? i : i0]; }
+#pragma unroll
+                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; if (i - lane < n4) put(i, v[j]); }
+            }
         }
     }
     __syncthreads();
 
     if constexpr (SHORT) {
-        PKV_UNIT_COMPUTE(A, 0)
-        if (n_it > 1) PKV_UNIT_COMPUTE(B, 1)
+        PKV_COMPUTE_NEXT(A)
+        if (n_it > 1) PKV_COMPUTE_NEXT(B)
     } else {
-        for (int it = 0; it < n_it; it += 2) {           // two units in flight behind the one being consumed; past the end: a harmless re-read of the
-            PKV_UNIT_COMPUTE(A, it)                      // last unit (the load count stays static: a load behind a branch drains the queue at the join)
-            PKV_UNIT_LOAD(A, min(it + 2, n_it - 1))
-            if (it + 1 < n_it) PKV_UNIT_COMPUTE(B, it + 1)
-            PKV_UNIT_LOAD(B, min(it + 3, n_it - 1))
+        for (int it = 0; it < n_it; it += 2) {           // two units in flight behind the one being consumed
+            PKV_COMPUTE_NEXT(A)
+            PKV_LOAD_NEXT(A)
+            if (it + 1 < n_it) PKV_COMPUTE_NEXT(B)
+            PKV_LOAD_NEXT(B)
         }
     }
 }
@@ -419,19 +481,26 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     for (int i = g.n; i < PKV_GEMV_MAX; ++i) { a.rp_end[i] = tot; a.w[i] = a.w[0]; a.y[i] = a.y[0]; a.M[i] = 0; a.type[i] = a.type[0]; }
     a.n = g.n; a.silu_mul = g.silu_mul; a.residual = g.residual; a.img = (const char *) g.xq; a.K = g.K;
     a.x = g.x; a.norm_w = g.xq ? nullptr : g.norm_w; a.eps = g.eps;
-    a.gpr = (int) (g.K / 64); a.gs = a.gpr | 1;
-    const size_t lds = (size_t) 20 * a.gs * 4;
+    a.gpr = (int) (g.K / 64); a.gs = 0;
+    const size_t lds = (size_t) REC * a.gpr * 4;
     // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)
-    const int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
-    const int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
+    int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
+    int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
     const int n_f0 = (2 * a.gpr + 127) / 128;
-    const bool shrt = (int64_t) ((tot + grid * nwv - 1) / (grid * nwv)) * n_f0 <= 2;
+    bool shrt = (int64_t) ((tot + grid * nwv - 1) / (grid * nwv)) * n_f0 <= 2;
+    // long rows, few of them (ffn_down): two waves per row pair
+    const int f_half = ((a.gpr + 63) / 64) * 64;
+    bool all4_ = true;
+    for (int i = 0; i < g.n; ++i) all4_ = all4_ && g.type_w[i] == PKV_TYPE_Q4_K;
+    // (q6_K rows: measured slower split — 22.8 vs 20.2 us for ffn_down; its 16-wave form spills)
+    const bool split = all4_ && nwv == 8 && grid * 8 >= tot && n_f0 >= 3 && (f_half + 127) / 128 <= 2;
+    if (split) { nwv = 16; shrt = true; }
     bool all4 = true, all6 = true;
     for (int i = 0; i < g.n; ++i) { all4 = all4 && g.type_w[i] == PKV_TYPE_Q4_K; all6 = all6 && g.type_w[i] == PKV_TYPE_Q6_K; }
     const int mode = all4 ? PKV_TYPE_Q4_K : (all6 ? PKV_TYPE_Q6_K : 0);
 #define PKV_GEMV_LAUNCH(MODE_, NWV_, SHORT_) hipLaunchKernelGGL((gemv_kernel<MODE_, NWV_, SHORT_>), dim3((unsigned) grid), dim3(64 * NWV_), lds, st, a)
 #define PKV_GEMV_PICK_S(MODE_, NWV_) do { if (shrt) PKV_GEMV_LAUNCH(MODE_, NWV_, true); else PKV_GEMV_LAUNCH(MODE_, NWV_, false); } while (0)
-#define PKV_GEMV_PICK_W(MODE_) do { if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8); else PKV_GEMV_PICK_S(MODE_, 4); } while (0)
+#define PKV_GEMV_PICK_W(MODE_) do { if (split) hipLaunchKernelGGL((gemv_kernel<MODE_, 16, true, 2>), dim3((unsigned) grid), dim3(1024), lds, st, a); else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8); else PKV_GEMV_PICK_S(MODE_, 4); } while (0)
     if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_W(PKV_TYPE_Q4_K);
     else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_W(PKV_TYPE_Q6_K);
     else                            PKV_GEMV_PICK_W(0);

@@ -8,6 +8,8 @@
 // binary ops with row broadcast (:4560-4700), ggml_compute_forward_mul_mat (:7467-7640; dst[m][n] = sum_k src0[m][k] src1[n][k]).
 #include "pkv_common.h"
 
+#include <algorithm>
+
 namespace pkv {
 namespace {
 
@@ -169,6 +171,49 @@ __global__ void __launch_bounds__(256) soft_max_kernel(const float * x, const MT
     __syncthreads();
     const float inv = (float) (1.0 / (ss[0] + ss[1] + ss[2] + ss[3]));
     for (int64_t i = threadIdx.x; i < ne00; i += 256) yr[i] *= inv;
+}
+// ---- the two generic ops of the non-flash-attention graphs (`-fa 0`, /ref/src/llama-graph.cpp:1201-1239, :1387-1394): NOT a hot path — correct,
+// coalesced where the layout allows, nothing more.
+// ggml_cpy / ggml_cont between strided tensors of equal element count (the V store into the TRANSPOSED v cache: src = transpose(v_cur), dst = a
+// 2-D strided f16 view; kqv_merged -> cont): element i of the source, in its own index order, becomes element i of the destination in ITS order
+// (ggml_compute_forward_dup_f32, /ref/ggml/src/ggml-cpu/ggml-cpu.c:3550-3800)
+struct Strided4 { int64_t ne[4], nb[4]; };
+__device__ __forceinline__ int64_t offset_of(int64_t i, const Strided4 & t) {
+    const int64_t i0 = i % t.ne[0]; i /= t.ne[0];
+    const int64_t i1 = i % t.ne[1]; i /= t.ne[1];
+    const int64_t i2 = i % t.ne[2], i3 = i / t.ne[2];
+    return i0 * t.nb[0] + i1 * t.nb[1] + i2 * t.nb[2] + i3 * t.nb[3];
+}
+template <typename ST, typename DT>
+__global__ void __launch_bounds__(256) cpy_strided_kernel(const char * src, char * dst, int64_t n, const Strided4 s, const Strided4 d) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256)
+        *reinterpret_cast<DT *>(dst + offset_of(i, d)) = (DT) (float) *reinterpret_cast<const ST *>(src + offset_of(i, s));
+}
+// ggml_mul_mat on strided / batched operands (kq = k . q over permuted views of the cache and of Qcur; kqv = v^T . kq): y[b3][b2][n][m] =
+// sum_k w[b3 / r3][b2 / r2][m][k] x[b3][b2][n][k], w f16 or f32 with unit stride in k, x f32 with unit stride in k, y contiguous
+// (ggml_compute_forward_mul_mat, /ref/ggml/src/ggml-cpu/ggml-cpu.c:7467-7640; f32 accumulation).  One wave per output row m, 4 columns at a time.
+template <typename WT>
+__global__ void __launch_bounds__(256) mul_mat_strided_kernel(const char * w, const char * x, float * y, const Strided4 sw, const Strided4 sx, int64_t r2, int64_t r3) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.z, b2 = b % sx.ne[2], b3 = b / sx.ne[2];
+    const int64_t K = sw.ne[0], M = sw.ne[1], N = sx.ne[1];
+    if (m >= M) return;
+    const char * wr = w + m * sw.nb[1] + (b2 / r2) * sw.nb[2] + (b3 / r3) * sw.nb[3];
+    for (int64_t n0 = (int64_t) blockIdx.y * 4; n0 < N; n0 += (int64_t) gridDim.y * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const char * xr = x + b2 * sx.nb[2] + b3 * sx.nb[3];
+        for (int64_t k = lane; k < K; k += 64) {
+            const float wv = (float) reinterpret_cast<const WT *>(wr)[k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (n0 + c < N) acc[c] = fmaf(wv, reinterpret_cast<const float *>(xr + (n0 + c) * sx.nb[1])[k], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float v = wave_sum_f(acc[c]);
+            if (lane == 0 && n0 + c < N) y[((b3 * sx.ne[2] + b2) * N + n0 + c) * M + m] = v;
+        }
+    }
 }
 // SiLU(gate) * up (the SwiGLU product of the FFN): one launch for the pair
 __global__ void __launch_bounds__(256) silu_mul_kernel(const float * g, const float * u, float * y_silu, float * y, int64_t n) {
@@ -470,6 +515,37 @@ int launch_soft_max(const float * x, const void * mask, int mask_f16, float * y,
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
+int launch_cpy_strided(const void * src, int src_type, const int64_t * ne_s, const int64_t * nb_s, void * dst, int dst_type, const int64_t * ne_d, const int64_t * nb_d, hipStream_t st) {
+    Strided4 s, d;
+    int64_t n = 1, nd = 1;
+    for (int i = 0; i < 4; ++i) { s.ne[i] = ne_s[i]; s.nb[i] = nb_s[i]; d.ne[i] = ne_d[i]; d.nb[i] = nb_d[i]; n *= ne_s[i]; nd *= ne_d[i]; }
+    PKV_REQUIRE(n == nd, "pkv_cpy_strided: element counts differ");
+    if (n == 0) return PKV_OK;
+    const unsigned grid = (unsigned) std::min<int64_t>((n + 255) / 256, 65535);
+    if (src_type == PKV_TYPE_F32 && dst_type == PKV_TYPE_F32)      hipLaunchKernelGGL((cpy_strided_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
+    else if (src_type == PKV_TYPE_F32 && dst_type == PKV_TYPE_F16) hipLaunchKernelGGL((cpy_strided_kernel<float, _Float16>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
+    else if (src_type == PKV_TYPE_F16 && dst_type == PKV_TYPE_F16) hipLaunchKernelGGL((cpy_strided_kernel<_Float16, _Float16>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
+    else if (src_type == PKV_TYPE_F16 && dst_type == PKV_TYPE_F32) hipLaunchKernelGGL((cpy_strided_kernel<_Float16, float>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
+    else { set_error("pkv_cpy_strided: types %d -> %d not supported (f32 / f16)", src_type, dst_type); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
+int launch_mul_mat_strided(const void * w, int type_w, const int64_t * ne_w, const int64_t * nb_w, const float * x, const int64_t * ne_x, const int64_t * nb_x, float * y,
+                           hipStream_t st) {
+    Strided4 sw, sx;
+    for (int i = 0; i < 4; ++i) { sw.ne[i] = ne_w[i]; sw.nb[i] = nb_w[i]; sx.ne[i] = ne_x[i]; sx.nb[i] = nb_x[i]; }
+    PKV_REQUIRE(ne_w[0] == ne_x[0] && ne_w[2] > 0 && ne_w[3] > 0 && ne_x[2] % ne_w[2] == 0 && ne_x[3] % ne_w[3] == 0, "pkv_mul_mat_strided: shapes do not broadcast");
+    PKV_REQUIRE(nb_x[0] == 4 && nb_w[0] == (type_w == PKV_TYPE_F16 ? 2 : 4), "pkv_mul_mat_strided: unit stride along k required");
+    const int64_t M = ne_w[1], N = ne_x[1], nb = ne_x[2] * ne_x[3];
+    if (M == 0 || N == 0 || nb == 0) return PKV_OK;
+    PKV_REQUIRE(nb <= 65535, "pkv_mul_mat_strided: too many batches");
+    const dim3 grid((unsigned) ((M + 3) / 4), (unsigned) std::min<int64_t>((N + 3) / 4, 64), (unsigned) nb);
+    if (type_w == PKV_TYPE_F16)      hipLaunchKernelGGL(mul_mat_strided_kernel<_Float16>, grid, dim3(256), 0, st, (const char *) w, (const char *) x, y, sw, sx, ne_x[2] / ne_w[2], ne_x[3] / ne_w[3]);
+    else if (type_w == PKV_TYPE_F32) hipLaunchKernelGGL(mul_mat_strided_kernel<float>, grid, dim3(256), 0, st, (const char *) w, (const char *) x, y, sw, sx, ne_x[2] / ne_w[2], ne_x[3] / ne_w[3]);
+    else { set_error("pkv_mul_mat_strided: weight type %d not supported (f16, f32)", type_w); return PKV_ERR_UNSUPPORTED; }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
 int launch_silu_mul(const float * g, const float * u, float * y_silu, float * y, int64_t n, hipStream_t st) {
     if (n == 0) return PKV_OK;
     hipLaunchKernelGGL(silu_mul_kernel, dim3(grid_for(n)), dim3(256), 0, st, g, u, y_silu, y, n);
@@ -489,8 +565,17 @@ int launch_silu(const float * x, float * y, int64_t n, hipStream_t st) {
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
+// one column of K-quant weights: the decode-step product of pkv_gemv.hip (the column quantized to q8_K in its prologue)
+static bool gemv_shape(int type_w, int64_t M, int64_t K) { return (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K) && K % 256 == 0 && K <= 49152 && M % 2 == 0; }
+constexpr int64_t GEMM_MIN_COLS = 16;   // from here on a weight tile read once per 128 columns beats a stream per column
 int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st) {
     if (M == 0 || n_cols == 0) return PKV_OK;
+    if (n_cols == 1 && gemv_shape(type_w, M, K)) {
+        pkv_gemv g = {};
+        g.n = 1; g.type_w[0] = type_w; g.w[0] = w; g.y[0] = y; g.M[0] = M; g.K = K; g.x = x;
+        return launch_gemv(g, st);
+    }
+    if ((n_cols >= GEMM_MIN_COLS || type_w == PKV_TYPE_Q6_K) && gemm_supported(type_w, M, K)) return launch_gemm(w, type_w, x, y, M, K, n_cols, st);
     const int rows_wg = type_w == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
     const dim3 grid((unsigned) ((M + rows_wg - 1) / rows_wg));
     const size_t rb = row_size(type_w, K);
@@ -507,7 +592,17 @@ int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64
 
 int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                          hipStream_t st) {
-    if (type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q8_0) {       // one launch each for the other weight types
+    if (n_cols == 1 && n <= PKV_GEMV_MAX) {                           // decode: the products that share the column in ONE pkv_gemv.hip launch
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok = ok && gemv_shape(type_w, M[i], K) && M[i] > 0;
+        if (ok) {
+            pkv_gemv g = {};
+            g.n = n; g.K = K; g.x = x;
+            for (int i = 0; i < n; ++i) { g.type_w[i] = type_w; g.w[i] = w[i]; g.y[i] = y[i]; g.M[i] = M[i]; }
+            return launch_gemv(g, st);
+        }
+    }
+    if ((n_cols >= GEMM_MIN_COLS && gemm_supported(type_w, 1, K)) || (type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q8_0)) {       // one launch each
         for (int i = 0; i < n; ++i) if (int rc = launch_mul_mat(w[i], type_w, x, y[i], M[i], K, n_cols, st)) return rc;
         return PKV_OK;
     }

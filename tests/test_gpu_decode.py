@@ -46,6 +46,27 @@ def test_decode_matches_oracle(pkv, O, tk, tv, D, n_head, n_head_kv):
         assert e_gpu <= max(2.0 * e_ref, 2e-4), (s, n, e_gpu, e_ref)
 
 
+@pytest.mark.parametrize("tk,tv", [("q8_0", "q8_0"), ("q4_0", "q4_0"), ("f16", "q8_0"), ("q4_0", "f16")])
+def test_decode_many_sequences_quantized(pkv, O, tk, tv):
+    """launches with workgroups to spare (>= 1024) run the quantized-KV kernel with 32 tokens per wave (4-wave workgroups): same bars"""
+    tk, tv = TYPES[tk], TYPES[tv]
+    rng = np.random.default_rng(77 + tk + 3 * tv)
+    D, n_head, n_head_kv = 128, 32, 8
+    lens = [int(x) for x in rng.integers(1, 520, 36)] + [512, 385, 1, 129]           # 40 sequences x 5 splits x 8 kv heads = 1600 workgroups
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=n_head, n_head_kv=n_head_kv, type_k=tk, type_v=tv)
+    q = rng.uniform(-1, 1, (len(lens), n_head, D)).astype(np.float32)
+    got = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=n_head_kv, tk=tk, tv=tv)
+    ref = O.attn_paged(q[:, :, None, :], kp, vp, bt, sl, n_q=1, type_k=tk, type_v=tv, block_size=128, scale=D ** -0.5, n_threads=8)[:, 0]
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-3 and nmse(got, ref) <= 5e-4
+    for s in (0, 7, 36, 38):
+        n = lens[s]
+        kc = O.pool_gather(kp, tk, 0, bt[s], n, D=D, block_size=128)
+        vc = O.pool_gather(vp, tv, 1, bt[s], n, D=D, block_size=128)
+        exact = O.flash_attn_f64(q[s][:, None, :], kc, vc, None, type_k=tk, type_v=tv, scale=D ** -0.5)[0]
+        assert np.abs(got[s] - exact).max() <= max(2.0 * np.abs(ref[s] - exact).max(), 2e-4), (s, n)
+
+
 def test_decode_golden_vectors(pkv, O, golden):
     """the reference's own outputs (tests/golden/flash_attn_ext.npz) for the single-query cases, K/V paged on the fly"""
     g = golden["flash_attn_ext"]
@@ -172,20 +193,23 @@ def test_decode_fused_merge_matches_two_launch(pkv, O, tk):
     kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
     q = rng.uniform(-1, 1, (len(lens), nh, D)).astype(np.float32)
     base = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=nkv, tk=tk, tv=tk)
+    # quantized KV: a launch of this size (1536 workgroups) runs the two-launch kernel with 32 tokens per wave, the in-kernel merge keeps 16 — other wave
+    # maxima, so the f16 weights P * d_V round differently (both within the oracle bars, tests above); f16 KV: the same partition, f32 sums only
+    tol = 2e-6 if tk == 1 else 1e-4
     ws = pkv.attn_workspace(len(lens), nh, D, int(sl.max()), 128)
     dq, dk, dv, dbt, dsl = dev(q), dev(kp), dev(vp), dev(bt), dev(sl)
     for it in range(4):                                           # same workspace, back to back
         out = pkv.attn_decode(dq, dk, dv, dbt, dsl, n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5,
                               max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
         torch.cuda.synchronize()
-        assert np.abs(out.cpu().numpy() - base).max() <= 2e-6, it
+        assert np.abs(out.cpu().numpy() - base).max() <= tol, it
     # shorter sequences afterwards: fewer arrivals per ticket, still consistent
     sl2 = np.minimum(sl, 200).astype(np.int32)
     base2 = run_decode(pkv, q, kp, vp, bt, sl2, n_head_kv=nkv, tk=tk, tv=tk)
     out2 = pkv.attn_decode(dq, dk, dv, dbt, dev(sl2), n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5,
                            max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
     torch.cuda.synchronize()
-    assert np.abs(out2.cpu().numpy() - base2).max() <= 2e-6
+    assert np.abs(out2.cpu().numpy() - base2).max() <= tol
 
 
 def test_decode_matches_non_flash_attention_path(pkv, O):

@@ -147,7 +147,9 @@ def test_step_with_in_kernel_merge(pkv, O, tk, tv, D, nh, nkv):
                                    block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
         torch.cuda.synchronize()
         assert np.array_equal(dkp.cpu().numpy(), base[1]) and np.array_equal(dvp.cpu().numpy(), base[2]), it
-        assert np.abs(out.cpu().numpy() - base[0]).max() <= 2e-6, it
+        # quantized KV in a launch with >= 1024 workgroups: the two-launch kernel gives a wave 32 tokens, the in-kernel merge keeps 16 (other wave
+        # maxima -> the f16 weights P * d_V round differently; both inside the oracle bars)
+        assert np.abs(out.cpu().numpy() - base[0]).max() <= (2e-6 if (tk == 1 and tv == 1) else 1e-4), it
 
 
 def test_step_rejects_unsupported(pkv, O):

@@ -68,9 +68,20 @@ def test_mul_mat(pkv, O, tname, M, K, N):
     y = pkv.mul_mat(dev(np.ascontiguousarray(wb).reshape(-1)), t, M, K, dev(x)).cpu().numpy()
     ref = x.astype(np.float64) @ wd.T
     assert y.shape == (N, M)
+    if N >= 16 and t in (1, 8, 12):
+        # many columns: the MFMA product (csrc/pkv_gemm.hip) — weights and activations as f16, f32 accumulation: far inside the harness bar (NMSE 5e-4)
+        assert float(((y - ref) ** 2).sum() / (ref ** 2).sum()) <= 2e-6
+        return
+    if t == 12 and N == 1 and M % 2 == 0 and K % 256 == 0:
+        # ONE column of K-quant rows: the decode-step product (csrc/pkv_gemv.hip) — the column as the reference's q8_K integers (per 256), integer dots
+        from test_gpu_gemv import quant_act_ref
+        ref_q = wd @ quant_act_ref(x[0])[2]
+        assert np.abs(y[0] - ref_q).max() <= 3e-6 * max(1.0, np.abs(ref_q).max()) * np.sqrt(K / 256)
+        assert float(((y - ref) ** 2).sum() / (ref ** 2).sum()) <= 5e-4
+        return
     if t == 12:
-        # the q4_K product quantizes the activations to int8 per 32-element sub-block (d = amax / 127, round-to-nearest-even) and
-        # runs integer dots — the reference's CPU backend does the same with coarser q8_K blocks of 256.  Tight against that
+        # a few columns of q4_K rows: the activations quantized to int8 per 32-element sub-block (d = amax / 127, round-to-nearest-even), integer
+        # dots — the reference's CPU backend does the same with coarser q8_K blocks of 256.  Tight against that
         # arithmetic in f64, and within the harness bar (NMSE 5e-4, we ask 1e-4) of the unquantized product.
         xb = x.reshape(N, K // 32, 32)
         amax = np.abs(xb).max(-1, keepdims=True)
@@ -125,3 +136,66 @@ def test_soft_max_ext(pkv):
         assert np.abs(got - ref).max() <= 2e-6 and abs(got.sum(-1) - 1).max() <= 1e-5
         xin = dev(x)
         assert torch.equal(pkv.soft_max_ext(xin, None if m is None else dev(m), scale, max_bias, out=xin), dev(got))   # in place
+
+
+def test_strided_cpy_and_mul_mat(pkv):
+    """the generic ops of a -fa 0 graph (/root/reference/src/llama-graph.cpp:1201-1239, :1387-1394): strided copies (the store into the transposed V
+    cache, kqv_merged -> cont) and batched / broadcast products over f16 views of the cache"""
+    rng = np.random.default_rng(11)
+    # V store of a -fa 0 step: transpose(v_cur [n_tok][n_embd]) -> view [n_embd][n_tok] of the [n_embd][n_ctx] f16 cache at column kv_head
+    n_tok, n_embd, n_ctx, head = 5, 256, 64, 17
+    v_cur = dev(rng.standard_normal((n_tok, n_embd)).astype(np.float32))
+    cache = torch.zeros((n_embd, n_ctx), dtype=torch.float16, device="cuda")
+    pkv.cpy_strided(v_cur.t(), cache[:, head:head + n_tok])
+    want = torch.zeros_like(cache)
+    want[:, head:head + n_tok] = v_cur.t().to(torch.float16)
+    assert torch.equal(cache, want)
+    # cont of a permuted f32 tensor, and f16 -> f32 of a strided slice
+    a = dev(rng.standard_normal((3, 4, 6, 10)).astype(np.float32))
+    out = torch.empty((3, 6, 4, 10), device="cuda")
+    assert torch.equal(pkv.cpy_strided(a.permute(0, 2, 1, 3), out), a.permute(0, 2, 1, 3).contiguous())
+    h = a.to(torch.float16)
+    o2 = torch.empty((3, 4, 6, 5), device="cuda")
+    assert torch.equal(pkv.cpy_strided(h[..., ::2], o2), h[..., ::2].float())
+    # kq = k . q: k = f16 cache view [n_head_kv][n_kv][D] with cell-major rows, q = permuted f32 [n_head][n_tok][D], gqa 4
+    D, n_kv, n_head, n_head_kv, n_tok = 64, 96, 8, 2, 7
+    kc = dev((rng.standard_normal((n_kv, n_head_kv, D)) / 8).astype(np.float16))           # cache rows: cell x (head, d)
+    qc = dev(rng.standard_normal((n_tok, n_head, D)).astype(np.float32))                   # Qcur: token x (head, d)
+    kq = pkv.mul_mat_strided(kc.permute(1, 0, 2), qc.permute(1, 0, 2))[0]                  # [n_head][n_tok][n_kv]
+    ref = np.einsum("hkd,htd->htk", kc.cpu().numpy().astype(np.float64).transpose(1, 0, 2)[np.arange(n_head) // (n_head // n_head_kv)],
+                    qc.cpu().numpy().astype(np.float64).transpose(1, 0, 2))
+    assert np.abs(kq.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    # kqv = v^T . p: v^T = transposed f16 cache [n_head_kv][D][n_ctx] restricted to n_kv columns, p f32 [n_head][n_tok][n_kv]
+    vt = dev((rng.standard_normal((n_head_kv, D, 128)) / 8).astype(np.float16))
+    p = torch.softmax(kq, -1)
+    kqv = pkv.mul_mat_strided(vt[:, :, :n_kv], p)[0]                                       # [n_head][n_tok][D]
+    ref2 = np.einsum("hdk,htk->htd", vt.cpu().numpy().astype(np.float64)[:, :, :n_kv][np.arange(n_head) // (n_head // n_head_kv)], p.cpu().numpy().astype(np.float64))
+    assert np.abs(kqv.cpu().numpy() - ref2).max() <= 1e-5
+
+
+@pytest.mark.parametrize("tname", ["f16", "q8_0", "q4_K", "q6_K"])
+def test_mul_mat_batched_mfma(pkv, O, tname):
+    """pkv_mul_mat with many activation columns (prompt processing) = the MFMA product of csrc/pkv_gemm.hip: weight tiles dequantized to f16 once per 128
+    columns, activations rounded to f16, f32 accumulation.  Against f64 arithmetic on the same stored weights: NMSE far inside the harness bar (5e-4),
+    every element within the f16 rounding of the activations; ragged M / N (tiles past the end), and the single-column / few-column paths agree with it."""
+    from llama_cpp_test_amd import gguf_synth as G
+    t = {"f16": 1, "q8_0": 8, "q4_K": 12, "q6_K": 14}[tname]
+    rng = np.random.default_rng(100 + t)
+    for M, K, N in [(256, 512, 16), (384, 4096, 200), (130, 1024, 129), (1024, 2048, 512)]:
+        if t in (12, 14):
+            raw = (G.random_q4_K if t == 12 else G.random_q6_K)(rng, M, K)
+            wb, wd = np.frombuffer(raw, np.uint8).copy(), (G.dequantize_q4_K if t == 12 else G.dequantize_q6_K)(raw, K).astype(np.float64).reshape(M, K)
+        else:
+            w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+            wb = O.from_float(t, w, variant="ref") if t == 8 else O.from_float(t, w)
+            wd = np.asarray(O.to_float(t, wb, K), np.float64).reshape(M, K)
+        x = rng.standard_normal((N, K)).astype(np.float32)
+        y = pkv.mul_mat(dev(np.ascontiguousarray(wb).reshape(-1)), t, M, K, dev(x)).cpu().numpy()
+        ref = x.astype(np.float64) @ wd.T
+        assert y.shape == (N, M) and np.isfinite(y).all()
+        err = float(((y - ref) ** 2).sum() / (ref ** 2).sum())
+        assert err <= 2e-6, (M, K, N, err)
+        # a handful of columns through the per-column kernels (or, q6_K, the same MFMA kernel): same product
+        if M % 2 == 0:
+            y1 = pkv.mul_mat(dev(np.ascontiguousarray(wb).reshape(-1)), t, M, K, dev(x[:1].copy())).cpu().numpy()
+            assert float(((y1 - ref[:1]) ** 2).sum() / (ref[:1] ** 2).sum()) <= 5e-4

@@ -20,7 +20,7 @@ PLUGIN = os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so")
                                        # first slice of the rest of the layer: harness bars 1e-7 / 5e-4 (MUL_MAT)
                                        ("RMS_NORM", 3), ("ADD", 10), ("MUL", 10), ("SILU", 2), ("MUL_MAT", 30),
                                        # the softmax of the non-flash-attention path (a13): mask f32 / f16, scale, ALiBi; harness bar 1e-6
-                                       ("SOFT_MAX", 40)])
+                                       ("SOFT_MAX", 40), ("CONT", 2)])
 def test_reference_harness(op, min_ok):
     env = dict(os.environ, GGML_BACKEND_PATH=PLUGIN)
     r = subprocess.run([TBO, "test", "-o", op], env=env, capture_output=True, text=True, timeout=900)

@@ -99,3 +99,36 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
             print("call", ci, "logits nmse %.3e" % nmse(logit_g, logit_c), flush=True)
             continue
         assert nmse(logit_g, logit_c) <= bar, (ci, bar)
+
+
+@pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
+@pytest.mark.parametrize("model", ["tiny", "llama3"])
+def test_llama_decode_without_flash_attention_on_the_plugin(pkv, tmp_path, model):
+    """a13: a `-fa 0` graph (llama-bench's default, /root/reference/examples/llama-bench/llama-bench.cpp:190-215) with the KV cache in the plugin's
+    buffers: kq = mul_mat(k, q) -> soft_max_ext(kq, mask, scale) -> mul_mat(v, kq) -> cont, V stored TRANSPOSED by a strided CPY
+    (/root/reference/src/llama-graph.cpp:1201-1239, :1387-1394) — every one of those nodes on the MI355X (pkv_mul_mat_strided, pkv_soft_max_ext_f32,
+    pkv_cpy_strided), checked against the CPU-only run of the same library like the flash-attention test above"""
+    from llama_cpp_test_amd import gguf_synth as G
+    MODEL = MODELS[model]
+    path = str(tmp_path / "m.gguf")
+    G.synth_llama(path, **MODEL)
+    rng = np.random.default_rng(6)
+    calls = [([0] * 90, list(range(90))), ([0] * 60 + [1] * 40, list(range(90, 150)) + list(range(40)))] + [([0, 1], [150 + i, 40 + i]) for i in range(3)]
+    toks = [rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
+
+    def run(gpu_layers):
+        R.set_gpu_layers(gpu_layers)
+        m = R.RefModel(path, n_ctx=512, n_batch=128, n_seq_max=2, flash_attn=False, type_k=1, type_v=1, n_threads=8)
+        outs = []
+        for (sid, pos), t in zip(calls, toks):
+            layers = m.decode(t, pos, sid)
+            outs.append(([layers[il]["out"].copy() for il in sorted(layers)], m.logits(MODEL["n_vocab"]).copy()))
+        return outs
+    cpu = run(0)
+    R.load_backend(PLUGIN)
+    gpu = run(99)
+    R.set_gpu_layers(0)
+    for ci, ((lc, logit_c), (lg, logit_g)) in enumerate(zip(cpu, gpu)):
+        for il, (a, b) in enumerate(zip(lc, lg)):
+            assert np.isfinite(b).all() and nmse(b, a) <= 5e-4, (ci, il, nmse(b, a))
+        assert nmse(logit_g, logit_c) <= (2e-3 if MODEL.get("wtype") == 8 else 1e-4), ci
