@@ -102,6 +102,7 @@ int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64
  * (cell c = block c / block_size, offset c % block_size; K or V layout by is_v): dst gets the reference's bytes for cells
  * [cell0, cell0 + n_cells) — dst points at the first of them — and the pool gets the same quantized bits, in one launch.  What the
  * ggml-backend plugin runs for the KV-store CPY of a step once a cache tensor has its paged mirror. */
+/* (dst / k_dst / v_dst of the three *_paged entry points may be NULL: the paged rows are then the only copy — a cache tensor that IS its pool) */
 int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_cells, int n_head_kv, int head_dim,
                           int block_size, void * stream);
 

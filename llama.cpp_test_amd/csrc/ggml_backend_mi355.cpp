@@ -38,6 +38,12 @@ namespace {
 
 constexpr int BLOCK = 128;
 
+// r02: a KV cache tensor of a flash-attention context IS its paged pool.  The tile layout of "Pool layout" (include/mi355_paged_kv.h) has the
+// reference's bytes per token, so the first FLASH_ATTN_EXT over a cache tensor re-lays its memory out in place (one transient copy, once) and from
+// then on the KV-store CPY writes tiles only, attention reads them with the identity block table (cell c = block c / 128, offset c % 128 — the
+// placement is the reference runtime's: its own find_slot decides cells), the in-place K-shift RoPE runs on tiles (pkv_k_shift), and
+// ggml_backend_tensor_set / _get on the tensor (session files) translate whole cell rows through pkv_pool_scatter_rows / _gather_rows.  KV memory 1x.
+// Cache tensors whose cell count is not a multiple of 128, and GGML_MI355_KV_MIRROR=1, keep r01's separate mirror:
 // Persistent paged mirror of a KV cache tensor that lives in this buffer (the reference's flat `cache_k_l%d` / `cache_v_l%d`,
 // /ref/src/llama-kv-cache.cpp:100-103): the attention kernels read 128-token tiles, so instead of re-scattering all n_kv cells at
 // every FLASH_ATTN_EXT the plugin keeps a pool beside the flat tensor and re-scatters only the byte ranges written since the
@@ -45,6 +51,7 @@ constexpr int BLOCK = 128;
 // the whole tensor).  Identity block table: block b = cells [128 b, 128 b + 128).
 struct kv_mirror {
     void * pool = nullptr;
+    bool   in_place = false;   // the cache tensor's OWN memory holds the paged rows (r02): no flat copy exists, every access goes through the tile layout
     int    type = 0, is_v = 0, n_head_kv = 0, D = 0;
     int64_t n_cells = 0;
     std::vector<std::pair<size_t, size_t>> dirty;    // byte ranges [begin, end) of the flat tensor not yet in the pool
@@ -53,7 +60,7 @@ struct buffer_ctx {
     void * base;
     std::unordered_map<const void *, kv_mirror> mirrors;   // keyed by the flat tensor's data pointer
     std::unordered_map<const void *, size_t>    tracked;   // flat tensors we have seen as K/V roots -> their byte size
-    ~buffer_ctx() { for (auto & kv : mirrors) if (kv.second.pool) (void) hipFree(kv.second.pool); }
+    ~buffer_ctx() { for (auto & kv : mirrors) if (kv.second.pool && !kv.second.in_place) (void) hipFree(kv.second.pool); }
 };
 struct backend_ctx {
     hipStream_t stream = nullptr;
@@ -114,16 +121,64 @@ void note_write(const ggml_tensor * t, size_t off, size_t n) {
 }
 void note_write_all(const ggml_tensor * t) { note_write(t, 0, ggml_nbytes(t)); }
 void * buf_base(ggml_backend_buffer_t b) { return ((buffer_ctx *) b->context)->base; }
+// the in-place pool `t` (or the tensor it views) lives in, and t's byte offset inside that tensor
+kv_mirror * in_place_of(const ggml_tensor * t, size_t * off_out = nullptr) {
+    size_t off = 0;
+    const ggml_tensor * root = t;
+    while (root->view_src) { off += root->view_offs; root = root->view_src; }
+    if (!root->buffer || root->buffer->iface.free_buffer != buf_free) return nullptr;
+    auto * c = (buffer_ctx *) root->buffer->context;
+    auto it = c->mirrors.find(root->data);
+    if (it == c->mirrors.end() || !it->second.in_place) return nullptr;
+    if (off_out) *off_out = off;
+    return &it->second;
+}
+// whole cell rows [off, off + n) of an in-place cache tensor <-> reference-format rows in host memory
+bool in_place_rows(kv_mirror * m, size_t off, size_t n, void * host, bool to_pool) {
+    const size_t row_cell = ggml_row_size((ggml_type) m->type, m->D) * m->n_head_kv;
+    if (off % row_cell != 0 || n % row_cell != 0) { MI355_LOG("a write / read of a paged cache tensor must cover whole cells (offset %zu, %zu bytes, %zu per cell)\n", off, n, row_cell); return false; }
+    const int64_t c0 = (int64_t) (off / row_cell), nc = (int64_t) (n / row_cell);
+    if (nc == 0) return true;
+    std::vector<int32_t> slot(2 * (size_t) nc);
+    for (int64_t i = 0; i < nc; ++i) { slot[i] = (int32_t) ((c0 + i) / BLOCK); slot[nc + i] = (int32_t) ((c0 + i) % BLOCK); }
+    void * rows = nullptr; int32_t * dslot = nullptr;
+    bool ok = hipMalloc(&rows, n) == hipSuccess && hipMalloc((void **) &dslot, slot.size() * sizeof(int32_t)) == hipSuccess &&
+              hipMemcpy(dslot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && to_pool) ok = hipMemcpy(rows, host, n, hipMemcpyHostToDevice) == hipSuccess &&
+                            pkv_pool_scatter_rows(m->pool, m->type, m->is_v, rows, dslot, dslot + nc, (int) nc, m->n_head_kv, m->D, BLOCK, nullptr) == PKV_OK;
+    if (ok && !to_pool) ok = pkv_pool_gather_rows(m->pool, m->type, m->is_v, rows, dslot, dslot + nc, (int) nc, m->n_head_kv, m->D, BLOCK, nullptr) == PKV_OK &&
+                             hipDeviceSynchronize() == hipSuccess && hipMemcpy(host, rows, n, hipMemcpyDeviceToHost) == hipSuccess;
+    (void) hipDeviceSynchronize();
+    if (rows) (void) hipFree(rows);
+    if (dslot) (void) hipFree(dslot);
+    if (!ok) MI355_LOG("paged cache tensor row transfer failed: %s\n", pkv_last_error());
+    return ok;
+}
 void buf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t n) {
+    size_t toff = 0;
+    if (kv_mirror * m = in_place_of(t, &toff)) {
+        std::vector<uint8_t> h(n, v);
+        (void) hipDeviceSynchronize();
+        (void) in_place_rows(m, toff + off, n, h.data(), true);
+        return;
+    }
     (void) hipMemset((char *) t->data + off, v, n);
     note_write(t, off, n);
 }
 void buf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t n) {
+    size_t toff = 0;
+    if (kv_mirror * m = in_place_of(t, &toff)) {
+        (void) hipDeviceSynchronize();
+        (void) in_place_rows(m, toff + off, n, const_cast<void *>(d), true);
+        return;
+    }
     (void) hipMemcpy((char *) t->data + off, d, n, hipMemcpyHostToDevice);
     note_write(t, off, n);
 }
 void buf_get(ggml_backend_buffer_t, const ggml_tensor * t, void * d, size_t off, size_t n) {
     (void) hipDeviceSynchronize();
+    size_t toff = 0;
+    if (kv_mirror * m = in_place_of(t, &toff)) { (void) in_place_rows(m, toff + off, n, d, false); return; }
     (void) hipMemcpy(d, (const char *) t->data + off, n, hipMemcpyDeviceToHost);
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
@@ -187,11 +242,30 @@ char * mirror_sync(backend_ctx * bc, const ggml_tensor * t, int is_v, int n_kv, 
     auto * c = (buffer_ctx *) root->buffer->context;
     kv_mirror & m = c->mirrors[root->data];
     const int64_t n_cells = (int64_t) (ggml_nbytes(root) / row_cell);
+    if (m.in_place) {
+        if (m.type != (int) t->type || m.n_head_kv != n_head_kv || m.D != D || m.is_v != is_v) { MI355_LOG("a paged cache tensor is read with another geometry than it was laid out for\n"); return nullptr; }
+        return (char *) m.pool;
+    }
     if (!m.pool || m.type != (int) t->type || m.n_head_kv != n_head_kv || m.D != D || m.n_cells != n_cells) {
         if (m.pool) (void) hipFree(m.pool);
         m = kv_mirror();
         const int64_t nb = (n_cells + BLOCK - 1) / BLOCK;
         const size_t bytes = pkv_pool_bytes(t->type, (int) nb, n_head_kv, BLOCK, D);
+        static const bool keep_mirror = getenv("GGML_MI355_KV_MIRROR") != nullptr;
+        if (!keep_mirror && n_cells % BLOCK == 0 && bytes == ggml_nbytes(root)) {
+            // the tensor becomes its own pool: tiles built beside it once, copied over its flat rows, the transient freed
+            void * tmp = nullptr;
+            if (hipMalloc(&tmp, bytes) != hipSuccess) return nullptr;
+            int rc = hipMemsetAsync(tmp, 0, bytes, bc->stream) == hipSuccess ? 0 : -1;
+            if (!rc) rc = pkv_pool_scatter_rows_strided(tmp, t->type, is_v, root->data, (int64_t) row_cell, (int64_t) row_head, nullptr, nullptr, (int) n_cells, n_head_kv, D, BLOCK, bc->stream);
+            if (!rc) rc = hipMemcpyAsync(root->data, tmp, bytes, hipMemcpyDeviceToDevice, bc->stream) == hipSuccess ? 0 : -1;
+            (void) hipStreamSynchronize(bc->stream);
+            (void) hipFree(tmp);
+            if (rc) return nullptr;
+            m.pool = root->data; m.in_place = true;
+            m.type = t->type; m.is_v = is_v; m.n_head_kv = n_head_kv; m.D = D; m.n_cells = n_cells;
+            return (char *) m.pool;
+        }
         if (hipMalloc(&m.pool, bytes) != hipSuccess) { m.pool = nullptr; return nullptr; }
         (void) hipMemsetAsync(m.pool, 0, bytes, bc->stream);
         m.type = t->type; m.is_v = is_v; m.n_head_kv = n_head_kv; m.D = D; m.n_cells = n_cells;
@@ -296,6 +370,28 @@ ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
     const ggml_tensor * x = op->src[0];
     pkv_rope_params rp;
     rope_params(op, &rp);
+    size_t toff = 0;
+    if (kv_mirror * m = in_place_of(x, &toff)) {
+        // the K-shift of kv_self_update (/ref/src/llama-context.cpp:447-496): ggml_rope_ext_inplace over a [D, n_head_kv, n_cells] view of the K cache,
+        // src[1] = the per-cell position deltas.  The cache is its pool: rotate the tile rows in place (pkv_k_shift), cells = the view's
+        const size_t row_cell = ggml_row_size((ggml_type) m->type, m->D) * m->n_head_kv;
+        const int64_t nc = x->ne[2];
+        if (back || m->is_v || op->data != x->data || x->ne[0] != m->D || x->ne[1] != m->n_head_kv || toff % row_cell != 0 || x->nb[2] != row_cell) {
+            MI355_LOG("rope over a paged cache tensor: only the in-place K-shift of whole cells is supported\n");
+            return GGML_STATUS_FAILED;
+        }
+        const int64_t c0 = (int64_t) (toff / row_cell);
+        std::vector<int32_t> h(2 * (size_t) nc);
+        for (int64_t i = 0; i < nc; ++i) { h[i] = (int32_t) ((c0 + i) / BLOCK); h[nc + i] = (int32_t) ((c0 + i) % BLOCK); }
+        int32_t * d = (int32_t *) bc->arena(h.size() * sizeof(int32_t));
+        if (!d || hipMemcpyAsync(d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, bc->stream) != hipSuccess) return GGML_STATUS_ALLOC_FAILED;
+        (void) hipStreamSynchronize(bc->stream);
+        if (pkv_k_shift(m->pool, m->type, d, d + nc, (const int32_t *) op->src[1]->data, (int) nc, m->n_head_kv, m->D, BLOCK, &rp, bc->stream) != PKV_OK) {
+            MI355_LOG("k-shift on the paged cache failed: %s\n", pkv_last_error());
+            return GGML_STATUS_FAILED;
+        }
+        return GGML_STATUS_SUCCESS;
+    }
     const int64_t es = (int64_t) ggml_type_size(x->type);
     const int rc = x->type == GGML_TYPE_F32
         ? pkv_rope_f32_strided((const float *) bc->src_data(x), (int64_t) x->nb[2] / es, (int64_t) x->nb[1] / es, (const int32_t *) op->src[1]->data,
@@ -343,6 +439,7 @@ const kv_mirror * store_mirror(const ggml_tensor * cpy, int64_t * cell0, int64_t
 ggml_status run_cpy_strided(backend_ctx * bc, const ggml_tensor * s, ggml_tensor * d) {
     int64_t nbs[4], nbd[4];
     for (int i = 0; i < 4; ++i) { nbs[i] = (int64_t) s->nb[i]; nbd[i] = (int64_t) d->nb[i]; }
+    if (in_place_of(d) || in_place_of(s)) { MI355_LOG("a strided copy over a paged cache tensor is not supported (defrag / -fa 0 ops on a flash-attention cache)\n"); return GGML_STATUS_FAILED; }
     const int rc = pkv_cpy_strided(bc->src_data(s), s->type, s->ne, nbs, d->data, d->type, d->ne, nbd, bc->stream);
     if (rc) { MI355_LOG("strided cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
     note_write_all(d);
@@ -356,9 +453,10 @@ ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     // quantized bits), nothing left to re-scatter at the next attention call
     int64_t cell0, n_cells;
     if (const kv_mirror * m = store_mirror(op, &cell0, &n_cells)) {
-        if (pkv_convert_f32_paged((const float *) bc->src_data(s), d->data, d->type, m->pool, m->is_v, cell0, n_cells, m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK)
+        if (pkv_convert_f32_paged((const float *) bc->src_data(s), m->in_place ? nullptr : d->data, d->type, m->pool, m->is_v, cell0, n_cells, m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK)
             return GGML_STATUS_SUCCESS;
     }
+    if (in_place_of(d)) { MI355_LOG("KV store into a paged cache tensor that does not cover whole cells\n"); return GGML_STATUS_FAILED; }
     const int rc = pkv_convert_f32((const float *) bc->src_data(s), d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
     if (rc) { MI355_LOG("cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
     note_write_all(d);                                      // the KV store of the step: the next attention re-scatters just these cells
@@ -430,6 +528,7 @@ ggml_status run_layer_op(backend_ctx * bc, ggml_tensor * op) {
             else {
                 int64_t nba[4], nbb[4];
                 for (int i = 0; i < 4; ++i) { nba[i] = (int64_t) a->nb[i]; nbb[i] = (int64_t) b->nb[i]; }
+                if (in_place_of(a)) { MI355_LOG("mul_mat over a paged cache tensor is not supported\n"); return GGML_STATUS_FAILED; }
                 rc = pkv_mul_mat_strided(a->data, a->type, a->ne, nba, (const float *) bc->src_data(b), b->ne, nbb, (float *) op->data, bc->stream);
             }
             break;
@@ -626,8 +725,8 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                     a.q = (const float *) bc->src_data(xq); a.q_stride_tok = (int64_t) (xq->nb[2] / sizeof(float)); a.q_stride_head = (int64_t) (xq->nb[1] / sizeof(float));
                     a.q_out = (float *) n->data;
                     a.k = (const float *) bc->src_data(xk); a.k_stride_tok = (int64_t) (xk->nb[2] / sizeof(float)); a.k_stride_head = (int64_t) (xk->nb[1] / sizeof(float));
-                    a.k_dst = ck->src[1]->data; a.k_pool = mk->pool; a.k_cell0 = ck0;
-                    a.v = (const float *) bc->src_data(xv); a.v_dst = cv->src[1]->data; a.v_pool = mv->pool; a.v_cell0 = cv0;
+                    a.k_dst = mk->in_place ? nullptr : ck->src[1]->data; a.k_pool = mk->pool; a.k_cell0 = ck0;
+                    a.v = (const float *) bc->src_data(xv); a.v_dst = mv->in_place ? nullptr : cv->src[1]->data; a.v_pool = mv->pool; a.v_cell0 = cv0;
                     a.pos = (const int32_t *) n->src[1]->data; a.rope = &rp;
                     a.type_k = ck->src[1]->type; a.type_v = cv->src[1]->type; a.n_tok = (int32_t) xq->ne[2]; a.n_head = (int32_t) xq->ne[1];
                     a.n_head_kv = mk->n_head_kv; a.head_dim = mk->D; a.block_size = BLOCK;
@@ -652,7 +751,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 if (m && !m->is_v && x->ne[0] == m->D && x->ne[1] == m->n_head_kv && x->ne[2] == n_cells && x->ne[3] == 1 && ggml_is_contiguous(n) &&
                     ((rp.mode & 2) == 0 || rp.n_dims == m->D) &&
                     pkv_rope_convert_f32_paged((const float *) bc->src_data(x), (int64_t) (x->nb[2] / sizeof(float)), (int64_t) (x->nb[1] / sizeof(float)),
-                                               (const int32_t *) n->src[1]->data, &rp, (float *) n->data, nk->src[1]->data, nk->src[1]->type, m->pool, cell0, n_cells,
+                                               (const int32_t *) n->src[1]->data, &rp, (float *) n->data, m->in_place ? nullptr : nk->src[1]->data, nk->src[1]->type, m->pool, cell0, n_cells,
                                                m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK) {
                     done[k] = 1;
                     st = GGML_STATUS_SUCCESS;

@@ -135,7 +135,7 @@ int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64
 int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_cells, int n_head_kv, int head_dim,
                           int block_size, void * stream) {
     if (int rc = ensure_device()) return rc;
-    PKV_REQUIRE(x && dst && pool && kv_type_ok(type) && cell0 >= 0 && n_cells >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 32 == 0,
+    PKV_REQUIRE(x && pool && kv_type_ok(type) && cell0 >= 0 && n_cells >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 32 == 0,
                 "pkv_convert_f32_paged: bad arguments");
     return launch_convert_rows_mirror(x, dst, type, pool, is_v, cell0, n_cells * n_head_kv, n_head_kv, head_dim, block_size, (hipStream_t) stream);
 }
@@ -143,7 +143,7 @@ int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, in
 int pkv_rope_convert_f32_paged(const float * x, int64_t xs_tok, int64_t xs_head, const int32_t * pos, const pkv_rope_params * rope, float * roped, void * dst,
                                int type, void * pool, int64_t cell0, int64_t n_tok, int n_head_kv, int head_dim, int block_size, void * stream) {
     if (int rc = ensure_device()) return rc;
-    PKV_REQUIRE(x && pos && rope && dst && pool && kv_type_ok(type) && cell0 >= 0 && n_tok >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 32 == 0 &&
+    PKV_REQUIRE(x && pos && rope && pool && kv_type_ok(type) && cell0 >= 0 && n_tok >= 0 && n_head_kv > 0 && block_size > 0 && block_size % 32 == 0 &&
                 xs_tok >= 0 && xs_head >= 0, "pkv_rope_convert_f32_paged: bad arguments");
     PKV_REQUIRE((rope->mode & 2) == 0 || rope->n_dims == head_dim, "pkv_rope_convert_f32_paged: NEOX pairs need n_dims == head_dim");
     RopeDev r;
@@ -153,7 +153,7 @@ int pkv_rope_convert_f32_paged(const float * x, int64_t xs_tok, int64_t xs_head,
 
 int pkv_qkv_store_f32_paged(const pkv_qkv_store_args * a, void * stream) {
     if (int rc = ensure_device()) return rc;
-    PKV_REQUIRE(a && a->q && a->q_out && a->k && a->k_dst && a->k_pool && a->v && a->v_dst && a->v_pool && a->pos && a->rope, "pkv_qkv_store_f32_paged: null pointer");
+    PKV_REQUIRE(a && a->q && a->q_out && a->k && a->k_pool && a->v && a->v_pool && a->pos && a->rope, "pkv_qkv_store_f32_paged: null pointer");
     PKV_REQUIRE(kv_type_ok(a->type_k) && kv_type_ok(a->type_v) && a->n_tok >= 0 && a->n_head > 0 && a->n_head_kv > 0 && a->k_cell0 >= 0 && a->v_cell0 >= 0 &&
                 a->block_size > 0 && a->block_size % 32 == 0, "pkv_qkv_store_f32_paged: bad arguments");
     PKV_REQUIRE((a->rope->mode & 2) == 0 || a->rope->n_dims == a->head_dim, "pkv_qkv_store_f32_paged: NEOX pairs need n_dims == head_dim");

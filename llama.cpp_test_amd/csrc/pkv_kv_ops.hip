@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64) convert_rows_mirror_kernel(const float * x
     float2 v = make_float2(0.0f, 0.0f);
     if (2 * lane < D) v = *reinterpret_cast<const float2 *>(x + g * D + 2 * lane);
     const Q2 q = quantize<T>(v, lane);
-    ref_write<T>(dst + g * (int64_t) row_size(T, D), lane, q, D);
+    if (dst) ref_write<T>(dst + g * (int64_t) row_size(T, D), lane, q, D);   // dst == NULL: the paged rows are the only copy
     const int64_t cell = cell0 + g / n_head_kv;
     const int h = (int) (g % n_head_kv);
     char * tile = pool + ((size_t) (cell / BS) * n_head_kv + h) * tile_bytes(T, BS, D);
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64) rope_convert_mirror_kernel(const float * x
     v = rope_row<D>(v, lane, pos[t], r, 1.0f);
     if (roped && 2 * lane < D) *reinterpret_cast<float2 *>(roped + g * D + 2 * lane) = v;
     const Q2 q = quantize<T>(v, lane);
-    ref_write<T>(dst + g * (int64_t) row_size(T, D), lane, q, D);
+    if (dst) ref_write<T>(dst + g * (int64_t) row_size(T, D), lane, q, D);   // dst == NULL: the paged rows are the only copy
     const int64_t cell = cell0 + t;
     char * tile = pool + ((size_t) (cell / BS) * n_head_kv + h) * tile_bytes(T, BS, D);
     tile_write<T, false>(tile, (int) (cell % BS), lane, q, BS, D);
@@ -408,14 +408,14 @@ __global__ void __launch_bounds__(64) qkv_store_mirror_kernel(const QkvStoreArgs
         if (2 * lane < D) x = *reinterpret_cast<const float2 *>(a.k + t * a.k_s_tok + h * a.k_s_head + 2 * lane);
         x = rope_row<D>(x, lane, a.pos[t], a.rope, 1.0f);
         const Q2 q = quantize<KT>(x, lane);
-        ref_write<KT>(a.k_dst + g * (int64_t) row_size(KT, D), lane, q, D);
+        if (a.k_dst) ref_write<KT>(a.k_dst + g * (int64_t) row_size(KT, D), lane, q, D);
         const int64_t cell = a.k_cell0 + t;
         tile_write<KT, false>(a.k_pool + ((size_t) (cell / a.BS) * a.n_head_kv + h) * tile_bytes(KT, a.BS, D), (int) (cell % a.BS), lane, q, a.BS, D);
     } else {
         float2 x = make_float2(0.0f, 0.0f);
         if (2 * lane < D) x = *reinterpret_cast<const float2 *>(a.v + g * D + 2 * lane);
         const Q2 q = quantize<VT>(x, lane);
-        ref_write<VT>(a.v_dst + g * (int64_t) row_size(VT, D), lane, q, D);
+        if (a.v_dst) ref_write<VT>(a.v_dst + g * (int64_t) row_size(VT, D), lane, q, D);
         const int64_t cell = a.v_cell0 + t;
         tile_write<VT, true>(a.v_pool + ((size_t) (cell / a.BS) * a.n_head_kv + h) * tile_bytes(VT, a.BS, D), (int) (cell % a.BS), lane, q, a.BS, D);
     }

@@ -72,6 +72,19 @@ class RefModel:
             raise RuntimeError("no logits")
         return out
 
+    def state_seq_get(self, seq_id: int) -> bytes:
+        L = _lib()
+        L.refmodel_state_seq_get.restype = C.c_size_t
+        n = L.refmodel_state_seq_get(self.h, None, C.c_size_t(0), seq_id)
+        buf = C.create_string_buffer(n)
+        got = L.refmodel_state_seq_get(self.h, buf, C.c_size_t(n), seq_id)
+        return buf.raw[:got]
+
+    def state_seq_set(self, blob: bytes, seq_id: int) -> int:
+        L = _lib()
+        L.refmodel_state_seq_set.restype = C.c_size_t
+        return int(L.refmodel_state_seq_set(self.h, blob, C.c_size_t(len(blob)), seq_id))
+
     def seq_rm(self, s, p0, p1): _lib().refmodel_seq_rm(self.h, s, p0, p1)
     def seq_cp(self, a, b, p0, p1): _lib().refmodel_seq_cp(self.h, a, b, p0, p1)
     def seq_add(self, s, p0, p1, d): _lib().refmodel_seq_add(self.h, s, p0, p1, d)

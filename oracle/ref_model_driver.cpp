@@ -209,6 +209,13 @@ void refmodel_detach_capture(void * h) {
 size_t refmodel_state_seq_set(void * h, const void * data, size_t size, int seq_id) {
     return llama_state_seq_set_data(((RefModel *) h)->ctx, (const uint8_t *) data, size, seq_id);
 }
+// llama_state_seq_get_data: one sequence's cells as a session blob (= llama_kv_cache_unified::state_write through ggml_backend_tensor_get); dst NULL = size only
+size_t refmodel_state_seq_get(void * h, void * dst, size_t cap, int seq_id) {
+    llama_context * ctx = ((RefModel *) h)->ctx;
+    const size_t n = llama_state_seq_get_size(ctx, seq_id);
+    if (!dst || cap < n) return n;
+    return llama_state_seq_get_data(ctx, (uint8_t *) dst, cap, seq_id);
+}
 void refmodel_seq_rm(void * h, int s, int p0, int p1) { llama_kv_self_seq_rm(((RefModel *) h)->ctx, s, p0, p1); }
 void refmodel_seq_add(void * h, int s, int p0, int p1, int d) { llama_kv_self_seq_add(((RefModel *) h)->ctx, s, p0, p1, d); }
 void refmodel_seq_cp(void * h, int a, int b, int p0, int p1) { llama_kv_self_seq_cp(((RefModel *) h)->ctx, a, b, p0, p1); }

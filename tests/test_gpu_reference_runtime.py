@@ -132,3 +132,49 @@ def test_llama_decode_without_flash_attention_on_the_plugin(pkv, tmp_path, model
         for il, (a, b) in enumerate(zip(lc, lg)):
             assert np.isfinite(b).all() and nmse(b, a) <= 5e-4, (ci, il, nmse(b, a))
         assert nmse(logit_g, logit_c) <= (2e-3 if MODEL.get("wtype") == 8 else 1e-4), ci
+
+
+@pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
+@pytest.mark.parametrize("tk", [1, 8])
+def test_cache_tensor_is_its_own_pool(pkv, tmp_path, tk):
+    """f3: inside the reference runtime the KV cache tensors of a flash-attention context ARE the paged pools (no second copy): the plugin re-lays a
+    cache tensor out as 128-token tiles at its first attention call, the KV store writes tiles, and ggml_backend_tensor_get / _set translate whole
+    cell rows.  Checked through the reference's own session API: a sequence saved with llama_state_seq_get_data after decoding on the plugin must be
+    the reference's byte format (its CPU context reads it and continues with the same logits as a CPU context that decoded the same tokens, up to the
+    kernels' rounding), and restoring it into a FRESH plugin context (flat rows written before the first attention call, then re-laid out) must
+    continue bit for bit like the context it was saved from.  (GGML_MI355_KV_MIRROR=1 keeps r01's duplicate pool for A/B.)"""
+    from llama_cpp_test_amd import gguf_synth as G
+    MODEL = MODELS["llama3"]
+    path = str(tmp_path / "m.gguf")
+    G.synth_llama(path, **MODEL)
+    rng = np.random.default_rng(12)
+    n_p = 150                                                          # beyond one 128-cell block
+    toks = rng.integers(0, MODEL["n_vocab"], n_p + 3)
+
+    def fresh(gpu_layers):
+        R.set_gpu_layers(gpu_layers)
+        return R.RefModel(path, n_ctx=512, n_batch=128, n_seq_max=1, flash_attn=True, type_k=tk, type_v=tk, n_threads=8)
+
+    def feed(m, lo, hi):
+        for a in range(lo, hi, 100):
+            b = min(hi, a + 100)
+            m.decode(toks[a:b], list(range(a, b)), [0] * (b - a))
+        return m.logits(MODEL["n_vocab"]).copy()
+
+    R.load_backend(PLUGIN)
+    g = fresh(99)
+    feed(g, 0, n_p)
+    blob = g.state_seq_get(0)                                          # tiles -> reference rows
+    cont = [feed(g, n_p + i, n_p + i + 1) for i in range(3)]
+    g2 = fresh(99)
+    assert g2.state_seq_set(blob, 0) == len(blob)                      # reference rows -> (flat, then) tiles
+    cont2 = [feed(g2, n_p + i, n_p + i + 1) for i in range(3)]
+    assert all(np.array_equal(a, b) for a, b in zip(cont, cont2))
+    assert len(g2.state_seq_get(0)) > len(blob)                        # three more cells
+    # the blob is the reference's format: a CPU context continues from it
+    c = fresh(0)
+    assert c.state_seq_set(blob, 0) == len(blob)
+    cpu_cont = [feed(c, n_p + i, n_p + i + 1) for i in range(3)]
+    for a, b in zip(cont, cpu_cont):
+        assert nmse(a, b) <= 2e-3
+    R.set_gpu_layers(0)
