@@ -594,6 +594,15 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     }
     const bool fuse = getenv("GGML_MI355_NO_FUSE") == nullptr;   // GGML_MI355_NO_FUSE=1: one launch per graph node, in graph order (read per graph: tests flip it)
     bc->moved.clear();
+    // The side buffer of redirected K / V products (below) is sized ONCE per graph, for every product that could be redirected, and handed out by a
+    // bump pointer: no reallocation while `moved` entries point into it, and no slot is reused before its ROPE / CPY consumers have run
+    size_t side_need = 0, side_used = 0;
+    if (fuse) for (int i = 0; i < n_nodes; ++i) {
+        const ggml_tensor * t = ggml_graph_node(g, i);
+        if (t->op == GGML_OP_MUL_MAT && t->src[0] && (t->src[0]->type == GGML_TYPE_Q4_K || t->src[0]->type == GGML_TYPE_Q8_0) && !(t->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+            consumers_take_moved(g, t)) side_need += (ggml_nbytes(t) + 255) / 256 * 256;
+    }
+    char * side_base = side_need && side_need <= ((size_t) 1 << 30) ? (char *) bc->side_buf(side_need) : nullptr;
     std::vector<char> done(n_nodes, 0);      // MUL_MAT nodes already run together with an earlier product on the same activations
     for (int i = 0; i < n_nodes; ++i) {
         ggml_tensor * n = ggml_graph_node(g, i);
@@ -618,15 +627,18 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 // Kcur / Vcur: ggml-alloc gives them Qcur's address (each is dead after its out-of-place ROPE / CPY).  They can still be
                 // computed now, into a side buffer, when everything that reads them is a ROPE or CPY of this backend (through view
                 // ops): those take their source through backend_ctx::src_data
-                if (!safe && consumers_take_moved(g, nk)) { redirect[ngp] = true; safe = true; }
+                // (a product that is a graph output, or whose consumers are not all in THIS scheduler split, keeps its own address: another
+                // split copies from nk->data)
+                if (!safe && side_base && !(nk->flags & GGML_TENSOR_FLAG_OUTPUT) && consumers_take_moved(g, nk)) { redirect[ngp] = true; safe = true; }
                 if (safe) grp[ngp++] = k;
             }
             if (ngp > 1) {
                 const void * wv[PKV_MUL_MAT_MAX]; float * yv[PKV_MUL_MAT_MAX]; int64_t mv[PKV_MUL_MAT_MAX];
                 size_t side_bytes = 0;
                 for (int q = 0; q < ngp; ++q) if (redirect[q]) side_bytes += (ggml_nbytes(ggml_graph_node(g, grp[q])) + 255) / 256 * 256;
-                char * side = side_bytes ? (char *) bc->side_buf(side_bytes) : nullptr;
-                if (side_bytes && !side) return GGML_STATUS_ALLOC_FAILED;
+                char * side = side_bytes ? side_base + side_used : nullptr;
+                if (side_bytes && side_used + side_bytes > side_need) { MI355_LOG("side buffer accounting broke (%zu + %zu > %zu)\n", side_used, side_bytes, side_need); return GGML_STATUS_FAILED; }
+                side_used += side_bytes;
                 for (int q = 0; q < ngp; ++q) {
                     const ggml_tensor * nq = ggml_graph_node(g, grp[q]);
                     wv[q] = nq->src[0]->data; yv[q] = (float *) nq->data; mv[q] = nq->src[0]->ne[1];

@@ -1016,7 +1016,11 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
     // quantized KV with workgroups to spare: 32 tokens per wave (4-wave workgroups)
     constexpr bool QKV = KT != PKV_TYPE_F16 || VT != PKV_TYPE_F16;
     const bool wide = QKV && (long) da.n_splits * da.n_head_kv * n_seq >= 1024;
-    const dim3 block32(64 * Geo<KT, VT, D, 32>::NW);
+#ifndef PKV_TPW_Q4
+#define PKV_TPW_Q4 32
+#endif
+    constexpr int TQ = (KT == PKV_TYPE_Q4_0 && VT == PKV_TYPE_Q4_0) ? PKV_TPW_Q4 : 32;   // tokens per wave of the wide form
+    const dim3 block32(64 * Geo<KT, VT, D, TQ>::NW);
     const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr || da.mask != nullptr;
     if (da.k_cur && da.counters) {   // the whole decode step of a layer in ONE launch
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, true>, grid, block, st, da);
@@ -1030,13 +1034,13 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
             }
         }
         if (da.stamps) { set_error("pkv_attn_decode_stamps: f16 KV, head_dim 128, gqa 4 or 8 only"); return PKV_ERR_UNSUPPORTED; }
-        if constexpr (QKV) { if (wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, 32>, grid, block32, st, da); }
+        if constexpr (QKV) { if (wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, TQ>, grid, block32, st, da); }
         if (!wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
         if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
     } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, false>, grid, block, st, da);
     } else {
-        if constexpr (QKV) { if (wide && !cap && !sp) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false, 0, 32>, grid, block32, st, da); }
+        if constexpr (QKV) { if (wide && !cap && !sp) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false, 0, TQ>, grid, block32, st, da); }
         if (wide && !cap && !sp) {}
         else if (!cap && !sp) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false>, grid, block, st, da);
         else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false, false>, grid, block, st, da);

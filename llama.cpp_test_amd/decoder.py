@@ -78,6 +78,7 @@ class LlamaDecoder:
         self.graph = None
         self.graph_len = 0
         self.trace = None
+        self.attn_flags = 0                 # e.g. ATTN_FUSED_COMBINE: the split-KV merge inside the decode launch (measured)
 
     # ---- model bytes ---------------------------------------------------------------------------------------------------------
     def weight_bytes(self) -> int:
@@ -136,7 +137,7 @@ class LlamaDecoder:
                            [self.q.reshape(-1), self.k_cur.reshape(-1), self.v_cur.reshape(-1)], self.h, norm=p + "attn_norm.weight")
             attn_decode_step(self.q, self.k_cur, self.v_cur, self.pos, self.rope, self.cache.k_pool(l), self.cache.v_pool(l), self.block_table,
                              self.seq_lens, n_head_kv=self.n_head_kv, type_k=self.tk, type_v=self.tv, block_size=self.BS, scale=self.scale,
-                             max_seq_len=msl, out=self.attn, workspace=self.ws, rope_cache=self.rope_cs)
+                             max_seq_len=msl, out=self.attn, workspace=self.ws, rope_cache=self.rope_cs, flags=self.attn_flags)
             if self.trace is not None:   # debugging aid (eager launches only): per-layer copies of the attention path's inputs and output
                 self.trace.append({k: getattr(self, k).detach().clone() for k in ("q", "k_cur", "v_cur", "attn")})
             self._products([p + "attn_output.weight"], [self.h], self.attn.reshape(-1), residual=self.h)

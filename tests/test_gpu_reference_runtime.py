@@ -178,3 +178,41 @@ def test_cache_tensor_is_its_own_pool(pkv, tmp_path, tk):
     for a, b in zip(cont, cpu_cont):
         assert nmse(a, b) <= 2e-3
     R.set_gpu_layers(0)
+
+
+@pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
+def test_q4_k_m_mix_through_the_plugin_against_exact_arithmetic(pkv, O, tmp_path):
+    """end-to-end Q4_K parity of the plugin path on REAL weights.  The model of tests/golden/make_decoder_golden.py — Gaussian weights quantized
+    by the compiled reference's own q4_K / q6_K quantizers in the tensor mix of a Q4_K_M file — decoded by the unmodified reference runtime with every
+    layer on the MI355X: the 150-token prompt goes through the MFMA products (pkv_gemm.hip, q4_K and q6_K tiles) and the MFMA prefill attention, the six
+    decode steps through the decode-step products (pkv_gemv.hip) and the paged decode kernel.  Bars as in tests/test_gpu_decoder.py: as close to exact
+    (f64, unquantized-activation) arithmetic as the reference's CPU backend is, within twice that distance of the reference's logits, the same greedy token wherever the margin is above the noise (the prompt's products round
+    the activations to f16 where the reference rounds them to q8_K: different noise of the same size)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_decoder_golden", os.path.join(ROOT, "tests", "golden", "make_decoder_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    path = str(tmp_path / "q4km.gguf")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "decoder_logits.npz"))
+    assert gen.build(path) == bytes(g["sha256"]).hex()
+    tok, want, exact = g["tokens"], g["f16__logits"], g["exact__logits"]
+    R.load_backend(PLUGIN)
+    R.set_gpu_layers(99)
+    m = R.RefModel(path, n_ctx=512, n_batch=256, n_seq_max=1, flash_attn=True, type_k=1, type_v=1, n_threads=8)
+    nv = gen.MODEL["n_vocab"]
+    got = []
+    m.decode(tok[:gen.N_PROMPT], list(range(gen.N_PROMPT)), [0] * gen.N_PROMPT)
+    got.append(m.logits(nv).copy())
+    for i in range(gen.N_DECODE):
+        p = gen.N_PROMPT + i
+        m.decode(tok[p:p + 1], [p], [0])
+        got.append(m.logits(nv).copy())
+    R.set_gpu_layers(0)
+    ref_noise = max(nmse(b, e) for b, e in zip(want, exact))
+    assert len(got) == len(want) and 2e-4 < ref_noise < 5e-3
+    assert max(nmse(a, e) for a, e in zip(got, exact)) <= 1.5 * ref_noise
+    assert max(nmse(a, b) for a, b in zip(got, want)) <= 2.0 * ref_noise
+    for a, b in zip(got, want):                                       # the same greedy token wherever the reference's own top-2 margin is above the noise
+        top = np.sort(b)[-2:]
+        if top[1] - top[0] > 6.0 * float(np.sqrt(np.mean((a - b) ** 2))):
+            assert int(np.argmax(a)) == int(np.argmax(b))
