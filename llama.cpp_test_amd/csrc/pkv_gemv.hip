@@ -198,14 +198,14 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
     return *reinterpret_cast<const uint4 *>(p);
 #endif
 }
-#define PKV_UNIT_DECL(S) uint4 S##r0[2], S##r1[2], S##r2[2], S##r3[2]; uint16_t S##dh[2]; int S##g[2], S##p[2], S##ty[2], S##rs[2]; bool S##ok[2]; int S##mi; int64_t S##m0;
+#define PKV_UNIT_DECL(S) uint4 S##r0[UI], S##r1[UI], S##r2[UI], S##r3[UI]; uint16_t S##dh[UI]; int S##g[UI], S##p[UI], S##ty[UI], S##rs[UI]; bool S##ok[UI]; int S##mi; int64_t S##m0;
 #define PKV_UNIT_LOAD(S, RPI, FI)                                                                                                              \
     {                                                                                                                                          \
-        const int rp_ = first + __builtin_amdgcn_readfirstlane(RPI) * stride, f0_ = __builtin_amdgcn_readfirstlane(FI) * 128;                  \
+        const int rp_ = first + __builtin_amdgcn_readfirstlane(RPI) * stride, f0_ = __builtin_amdgcn_readfirstlane(FI) * (64 * UI);            \
         const char * q0_, * q1_; int t0_, t1_, mi_; int64_t m0_;                                                                               \
         rows_of(rp_, q0_, q1_, t0_, t1_, mi_, m0_);                                                                                            \
         S##mi = mi_; S##m0 = m0_;                                                                                                              \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                                        \
+        _Pragma("unroll") for (int u = 0; u < UI; ++u) {                                                                                        \
             const int f = f_lo + f0_ + 64 * u + lane;                                                                                          \
             S##ok[u] = f < f_hi;                                                                                                               \
             const int fc = S##ok[u] ? f : f_hi - 1;                                                                                            \
@@ -233,7 +233,7 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
     }
 #define PKV_UNIT_COMPUTE(S, RPI, FI)                                                                                                           \
     {                                                                                                                                          \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                                        \
+        _Pragma("unroll") for (int u = 0; u < UI; ++u) {                                                                                        \
             float part;                                                                                                                        \
             if (PKV_GEMV_ABLATE == 1) { part = __uint_as_float((S##r0[u].x ^ S##r1[u].y ^ S##r2[u].z ^ S##r3[u].w ^ S##r1[u].w ^ S##r2[u].x) & 0x3fffffffu); } else \
             if (S##ty[u] == PKV_TYPE_Q4_K) part = dot_q4k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##p[u], sq + S##g[u] * REC);                             \
@@ -273,7 +273,9 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
 // all 16 waves of every CU stream (and quantize the 14336-element column) and every wave is SHORT; their sums meet in LDS behind one barrier.
 template <int MODE, int NWV, bool SHORT, int KS = 1>
 __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
-    static_assert(KS == 1 || (KS == 2 && SHORT), "the split form has no loop: one barrier, reached once by every wave");
+    // lane-loads of a unit: two (row, group) items per lane, or ONE where the q6_K item (4 x 16 bytes + header) would push a 16-wave workgroup past its
+    // 128 registers per lane (r02's first form spilled 72-112 bytes there)
+    constexpr int UI = (MODE != PKV_TYPE_Q4_K && NWV == 16) ? 1 : 2;
     constexpr int NT = 64 * NWV;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     constexpr int TAIL = MODE == PKV_TYPE_Q4_K ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
     // (row, group) items of a row pair this wave owns: all 2 gpr of them, or one half (rounded to whole 64-lane strides)
     const int f_half = KS == 2 ? ((gpr + 63) / 64) * 64 : 2 * gpr;
     const int f_lo = kpart * f_half, f_hi = (KS == 2 && kpart == 0) ? f_half : 2 * gpr;
-    const int n_f0 = (f_half + 127) / 128;                           // units per row pair (per half)
+    const int n_f0 = (f_half + 64 * UI - 1) / (64 * UI);              // units per row pair (per half)
     const int n_it = n_rp * n_f0;
     // kernel-argument arrays are only ever indexed with constants (a dynamic index would move the struct to scratch)
     const int e0 = a.rp_end[0], e1 = a.rp_end[1];
@@ -484,23 +486,21 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     a.gpr = (int) (g.K / 64); a.gs = 0;
     const size_t lds = (size_t) REC * a.gpr * 4;
     // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)
-    int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
-    int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
-    const int n_f0 = (2 * a.gpr + 127) / 128;
-    bool shrt = (int64_t) ((tot + grid * nwv - 1) / (grid * nwv)) * n_f0 <= 2;
-    // long rows, few of them (ffn_down): two waves per row pair
-    const int f_half = ((a.gpr + 63) / 64) * 64;
-    bool all4_ = true;
-    for (int i = 0; i < g.n; ++i) all4_ = all4_ && g.type_w[i] == PKV_TYPE_Q4_K;
-    // (q6_K rows: measured slower split — 22.8 vs 20.2 us for ffn_down; its 16-wave form spills)
-    const bool split = all4_ && nwv == 8 && grid * 8 >= tot && n_f0 >= 3 && (f_half + 127) / 128 <= 2;
-    if (split) { nwv = 16; shrt = true; }
     bool all4 = true, all6 = true;
     for (int i = 0; i < g.n; ++i) { all4 = all4 && g.type_w[i] == PKV_TYPE_Q4_K; all6 = all6 && g.type_w[i] == PKV_TYPE_Q6_K; }
     const int mode = all4 ? PKV_TYPE_Q4_K : (all6 ? PKV_TYPE_Q6_K : 0);
+    int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
+    int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
+    // long rows, few of them (ffn_down): two waves per row pair, 16 waves per CU
+    const int f_half = ((a.gpr + 63) / 64) * 64;
+    const bool split = nwv == 8 && grid * 8 >= tot && 2 * a.gpr > 256;
+    if (split) nwv = 16;
+    const int ui = (mode != PKV_TYPE_Q4_K && nwv == 16) ? 1 : 2;     // items per lane and unit (the kernel's UI)
+    const int n_f0 = ((split ? f_half : 2 * a.gpr) + 64 * ui - 1) / (64 * ui);
+    const bool shrt = (int64_t) (split ? 1 : (tot + grid * nwv - 1) / (grid * nwv)) * n_f0 <= 2;
 #define PKV_GEMV_LAUNCH(MODE_, NWV_, SHORT_) hipLaunchKernelGGL((gemv_kernel<MODE_, NWV_, SHORT_>), dim3((unsigned) grid), dim3(64 * NWV_), lds, st, a)
 #define PKV_GEMV_PICK_S(MODE_, NWV_) do { if (shrt) PKV_GEMV_LAUNCH(MODE_, NWV_, true); else PKV_GEMV_LAUNCH(MODE_, NWV_, false); } while (0)
-#define PKV_GEMV_PICK_W(MODE_) do { if (split) hipLaunchKernelGGL((gemv_kernel<MODE_, 16, true, 2>), dim3((unsigned) grid), dim3(1024), lds, st, a); else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8); else PKV_GEMV_PICK_S(MODE_, 4); } while (0)
+#define PKV_GEMV_PICK_W(MODE_) do { if (split) { if (shrt) hipLaunchKernelGGL((gemv_kernel<MODE_, 16, true, 2>), dim3((unsigned) grid), dim3(1024), lds, st, a); else hipLaunchKernelGGL((gemv_kernel<MODE_, 16, false, 2>), dim3((unsigned) grid), dim3(1024), lds, st, a); } else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8); else PKV_GEMV_PICK_S(MODE_, 4); } while (0)
     if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_W(PKV_TYPE_Q4_K);
     else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_W(PKV_TYPE_Q6_K);
     else                            PKV_GEMV_PICK_W(0);
