@@ -108,8 +108,9 @@ def lib() -> C.CDLL:
         L.pkv_row_size.argtypes = [C.c_int, C.c_int64]
         L.pkv_cache_create.restype = C.c_void_p
         L.pkv_attn_prefill_workspace_bytes.restype = C.c_size_t
-        L.pkv_act_image_bytes.restype = C.c_size_t
-        L.pkv_act_image_bytes.argtypes = [C.c_int64]
+        if hasattr(L, "pkv_act_image_bytes"):   # (absent only from the round-1 build that probes/ab_decode.py loads for A/B runs)
+            L.pkv_act_image_bytes.restype = C.c_size_t
+            L.pkv_act_image_bytes.argtypes = [C.c_int64]
         L.pkv_cache_state_size.restype = C.c_int64
         L.pkv_cache_state_write.restype = C.c_int64
         L.pkv_cache_create.argtypes = [C.POINTER(CacheParams)]

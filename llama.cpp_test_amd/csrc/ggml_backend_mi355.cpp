@@ -551,25 +551,37 @@ void be_free(ggml_backend_t b) {
 void be_sync(ggml_backend_t b) { (void) hipStreamSynchronize(((backend_ctx *) b->context)->stream); }
 // every reader of t in the graph is (through RESHAPE / VIEW / PERMUTE / TRANSPOSE) the src[0] of an f32 ROPE or of a CPY: the ops that
 // resolve their source through backend_ctx::src_data
-bool consumers_take_moved(ggml_cgraph * g, const ggml_tensor * t, int depth = 0) {
+// who reads a tensor in this graph, built once per graph_compute (r02: the per-tensor scan of every node cost the host ~0.3 ms per decode step)
+struct graph_users {
+    std::unordered_map<const ggml_tensor *, std::vector<int>> by_src, by_view;
+    explicit graph_users(ggml_cgraph * g) {
+        for (int j = 0; j < ggml_graph_n_nodes(g); ++j) {
+            const ggml_tensor * nj = ggml_graph_node(g, j);
+            for (int s_ = 0; s_ < GGML_MAX_SRC; ++s_) if (nj->src[s_]) by_src[nj->src[s_]].push_back(j);
+            if (nj->view_src) by_view[nj->view_src].push_back(j);
+        }
+    }
+};
+bool consumers_take_moved(ggml_cgraph * g, const graph_users & u, const ggml_tensor * t, int depth = 0) {
     if (depth > 3 || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
-    bool any = false;
-    for (int j = 0; j < ggml_graph_n_nodes(g); ++j) {
+    auto iv = u.by_view.find(t);
+    if (iv != u.by_view.end()) for (int j : iv->second) if (ggml_graph_node(g, j)->src[0] != t) return false;
+    auto is = u.by_src.find(t);
+    if (is == u.by_src.end()) return false;
+    for (int j : is->second) {
         const ggml_tensor * nj = ggml_graph_node(g, j);
         for (int s_ = 0; s_ < GGML_MAX_SRC; ++s_) {
             if (nj->src[s_] != t) continue;
-            any = true;
             if (s_ != 0) return false;
             if ((nj->op == GGML_OP_ROPE && nj->type == GGML_TYPE_F32) || nj->op == GGML_OP_CPY) continue;
             if (nj->op == GGML_OP_RESHAPE || nj->op == GGML_OP_VIEW || nj->op == GGML_OP_PERMUTE || nj->op == GGML_OP_TRANSPOSE) {
-                if (!consumers_take_moved(g, nj, depth + 1)) return false;
+                if (!consumers_take_moved(g, u, nj, depth + 1)) return false;
                 continue;
             }
             return false;
         }
-        if (nj->view_src == t && nj->src[0] != t) return false;
     }
-    return any;
+    return true;
 }
 ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     auto * bc = (backend_ctx *) b->context;
@@ -597,10 +609,11 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     // The side buffer of redirected K / V products (below) is sized ONCE per graph, for every product that could be redirected, and handed out by a
     // bump pointer: no reallocation while `moved` entries point into it, and no slot is reused before its ROPE / CPY consumers have run
     size_t side_need = 0, side_used = 0;
+    const graph_users users(g);
     if (fuse) for (int i = 0; i < n_nodes; ++i) {
         const ggml_tensor * t = ggml_graph_node(g, i);
         if (t->op == GGML_OP_MUL_MAT && t->src[0] && (t->src[0]->type == GGML_TYPE_Q4_K || t->src[0]->type == GGML_TYPE_Q8_0) && !(t->flags & GGML_TENSOR_FLAG_OUTPUT) &&
-            consumers_take_moved(g, t)) side_need += (ggml_nbytes(t) + 255) / 256 * 256;
+            consumers_take_moved(g, users, t)) side_need += (ggml_nbytes(t) + 255) / 256 * 256;
     }
     char * side_base = side_need && side_need <= ((size_t) 1 << 30) ? (char *) bc->side_buf(side_need) : nullptr;
     std::vector<char> done(n_nodes, 0);      // MUL_MAT nodes already run together with an earlier product on the same activations
@@ -629,7 +642,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 // ops): those take their source through backend_ctx::src_data
                 // (a product that is a graph output, or whose consumers are not all in THIS scheduler split, keeps its own address: another
                 // split copies from nk->data)
-                if (!safe && side_base && !(nk->flags & GGML_TENSOR_FLAG_OUTPUT) && consumers_take_moved(g, nk)) { redirect[ngp] = true; safe = true; }
+                if (!safe && side_base && !(nk->flags & GGML_TENSOR_FLAG_OUTPUT) && consumers_take_moved(g, users, nk)) { redirect[ngp] = true; safe = true; }
                 if (safe) grp[ngp++] = k;
             }
             if (ngp > 1) {

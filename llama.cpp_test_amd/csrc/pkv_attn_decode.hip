@@ -378,7 +378,11 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int off) 
 #define PKV_OCC 1
 #endif
 template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0, int TPWQ = 16>
-__global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn_decode_kernel(const DecodeArgs a) {
+__global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn_decode_kernel(const int32_t * p_table, const int32_t * p_lens, int p_max_blocks, int p_bs_shift,
+                                                                                                   const DecodeArgs a) {
+    // the four leading arguments (= a.block_table, a.seq_lens, a.max_blocks, a.bs_shift) are what the FIRST dependent loads need: as explicit kernel
+    // arguments they are preloaded into SGPRs at dispatch (-mllvm -amdgpu-kernarg-preload-count, csrc/Makefile), one scalar round trip less on the
+    // critical path to the KV addresses
     Stamps<STAMP> ts;
     ts.real(0);
     ts.at(1);
@@ -415,9 +419,9 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     // the two scalar loads every KV address depends on are independent of each other: issue both, then branch
     // (the table entry of a split past the end of the sequence is in bounds — grid.x <= max_blocks — and unused)
-    const int lb = split >> a.bs_shift, boff = (split & ((1 << a.bs_shift) - 1)) * WG_TOK;
-    const int phys    = a.block_table[(size_t) s * a.max_blocks + lb];
-    const int seq_len = a.seq_lens[s];
+    const int lb = split >> p_bs_shift, boff = (split & ((1 << p_bs_shift) - 1)) * WG_TOK;
+    const int phys    = p_table[(size_t) s * p_max_blocks + lb];
+    const int seq_len = p_lens[s];
 
     // ---- row jobs, loads: they need kernel arguments only, so they go out while the table entry is still on its way, and —
     //      barrier 0 below — before ANY wave of the workgroup has put a K load into the CU's memory queue: a 512-byte row that
@@ -1005,8 +1009,8 @@ thread_local int g_stamp_mode = 1;   // pkv_attn_decode_stamps: where the diagno
 
 template <typename K>
 void launch_kernel(K kernel, dim3 grid, dim3 block, hipStream_t st, const DecodeArgs & da) {
-    if (g_prof_start) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, g_prof_start, g_prof_stop, 0, da);
-    else              hipLaunchKernelGGL(kernel, grid, block, 0, st, da);
+    if (g_prof_start) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, g_prof_start, g_prof_stop, 0, da.block_table, da.seq_lens, da.max_blocks, da.bs_shift, da);
+    else              hipLaunchKernelGGL(kernel, grid, block, 0, st, da.block_table, da.seq_lens, da.max_blocks, da.bs_shift, da);
 }
 
 template <int KT, int VT, int D, int G>

@@ -49,16 +49,38 @@ inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 |
 // rms_norm_mul_kernel (pkv_layer_ops.hip) and the norm prologue of the products (pkv_gemv.hip) must produce the same bits whatever their
 // workgroup shape.  ggml_compute_forward_rms_norm_f32 (/ref/ggml/src/ggml-cpu/ggml-cpu.c:8215-8260) adds (ggml_float)(x * x): f32 squares,
 // f64 sum, mean = (float)(sum / ne00), scale = 1 / sqrtf(mean + eps).  Same here, in a fixed order: per 256-element block (one wave, one
-// float4 per lane) x, y, z, w in order, an xor-shuffle tree over the wave, then the blocks in index order.
+// float4 per lane) x, y, z, w in order, a butterfly over the wave (partners 1, 2, 4, 8, 16, 32 lanes apart), then the blocks in index order.
 #ifdef __HIPCC__
+// all-reduce sum of a double over the wave without LDS (__shfl_xor on a double is two ds_bpermute round trips per step: 0.6 us per block on the
+// critical path of every norm): DPP inside the rows of 16, permlane swaps across them; lanes 1, 2, 4, 8, 16, 32 apart in that order
+template <int CTRL> __device__ __forceinline__ double dpp_d(double x) {
+    const unsigned long long u = __double_as_longlong(x);
+    const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) (u >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long) hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_d(double x) {
+    x += dpp_d<0xB1>(x); x += dpp_d<0x4E>(x); x += dpp_d<0x141>(x); x += dpp_d<0x140>(x);
+    {
+        const unsigned long long u = __double_as_longlong(x);
+        auto l = __builtin_amdgcn_permlane16_swap((unsigned) u, (unsigned) u, false, false);
+        auto h = __builtin_amdgcn_permlane16_swap((unsigned) (u >> 32), (unsigned) (u >> 32), false, false);
+        x = __longlong_as_double(((unsigned long long) h[0] << 32) | l[0]) + __longlong_as_double(((unsigned long long) h[1] << 32) | l[1]);
+    }
+    {
+        const unsigned long long u = __double_as_longlong(x);
+        auto l = __builtin_amdgcn_permlane32_swap((unsigned) u, (unsigned) u, false, false);
+        auto h = __builtin_amdgcn_permlane32_swap((unsigned) (u >> 32), (unsigned) (u >> 32), false, false);
+        x = __longlong_as_double(((unsigned long long) h[0] << 32) | l[0]) + __longlong_as_double(((unsigned long long) h[1] << 32) | l[1]);
+    }
+    return x;
+}
 __device__ __forceinline__ double block_sumsq(const float4 v) {
     double s = (double) __fmul_rn(v.x, v.x);
     s += (double) __fmul_rn(v.y, v.y);
     s += (double) __fmul_rn(v.z, v.z);
     s += (double) __fmul_rn(v.w, v.w);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    return s;
+    return wave_sum_d(s);
 }
 __device__ __forceinline__ float rms_scale(const double * block_sums, int n_blocks, int64_t ne0, float eps) {
     double t = 0.0;

@@ -21,7 +21,7 @@ namespace {
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 64, LDR = BK + 8;   // LDS row = 72 halfs = 144 B
+constexpr int BN = 128, BK = 64, LDR = BK + 8;   // LDS row = 72 halfs = 144 B; BM (weight rows per workgroup) = 128, or 64 when 128 would leave CUs idle
 
 __device__ __forceinline__ float hf(uint16_t b) { return (float) *reinterpret_cast<const _Float16 *>(&b); }
 __device__ __forceinline__ uint4 ldu(const unsigned char * p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -82,39 +82,43 @@ template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 2
 
 struct GemmArgs { const unsigned char * w; const float * x; float * y; int64_t M, N, K, row_bytes; };
 
-template <int T>
+template <int T, int BM>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
+    constexpr int WM = BM / 64, WN = 4 / WM, TN = BN / WN / 32;      // waves along m / n, MFMA tiles along n per wave (2 along m always)
     __shared__ __attribute__((aligned(16))) _Float16 sA[BM * LDR], sB[BN * LDR];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave % WM, wn = wave / WM;
     const int r = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
     // staging role: row srow, 32-element half shalf of both tiles (rows past the end re-read the last row; their outputs are never stored)
     const int srow = tid >> 1, shalf = tid & 1;
-    const unsigned char * wrow = a.w + (size_t) min(m0 + srow, a.M - 1) * a.row_bytes;
+    const bool stage_a = srow < BM;
+    const unsigned char * wrow = a.w + (size_t) min(m0 + (stage_a ? srow : 0), a.M - 1) * a.row_bytes;
     const float * xrow = a.x + (size_t) min(n0 + srow, a.N - 1) * a.K;
-    floatx16 acc[2][2];
+    floatx16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     RawW<T> rw;
     float4 rx[8];
     auto load_raw = [&](int64_t k0) {
-        rw.load(wrow, k0 + 32 * shalf);
+        if (stage_a) rw.load(wrow, k0 + 32 * shalf);
 #pragma unroll
         for (int i = 0; i < 8; ++i) rx[i] = reinterpret_cast<const float4 *>(xrow + k0 + 32 * shalf)[i];
     };
     load_raw(0);
     for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
         {   // conversion of the staged step into LDS
-            __attribute__((aligned(16))) _Float16 tmp[32];
-            rw.to_half(tmp, k0 + 32 * shalf);
-            uint4 * da = reinterpret_cast<uint4 *>(sA + srow * LDR + 32 * shalf);
+            if (stage_a) {
+                __attribute__((aligned(16))) _Float16 tmp[32];
+                rw.to_half(tmp, k0 + 32 * shalf);
+                uint4 * da = reinterpret_cast<uint4 *>(sA + srow * LDR + 32 * shalf);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) da[i] = reinterpret_cast<const uint4 *>(tmp)[i];
+                for (int i = 0; i < 4; ++i) da[i] = reinterpret_cast<const uint4 *>(tmp)[i];
+            }
             __attribute__((aligned(16))) _Float16 tb[32];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { tb[4 * i] = (_Float16) rx[i].x; tb[4 * i + 1] = (_Float16) rx[i].y; tb[4 * i + 2] = (_Float16) rx[i].z; tb[4 * i + 3] = (_Float16) rx[i].w; }
@@ -126,23 +130,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
         if (k0 + BK < a.K) load_raw(k0 + BK);            // the next step's raw bytes fly under this step's MFMAs
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            half8_t af[2], bf[2];
+            half8_t af[2], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const half8_t *>(sA + (wm * 64 + i * 32 + r) * LDR + 16 * ks + 8 * h);
-                bf[i] = *reinterpret_cast<const half8_t *>(sB + (wn * 64 + i * 32 + r) * LDR + 16 * ks + 8 * h);
-            }
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8_t *>(sA + (wm * 64 + i * 32 + r) * LDR + 16 * ks + 8 * h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8_t *>(sB + (wn * 32 * TN + j * 32 + r) * LDR + 16 * ks + 8 * h);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
     // C: col (token) = lane & 31, row (m) = (reg & 3) + 8 (reg >> 2) + 4 h
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t n = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn * 32 * TN + j * 32 + r;
         if (n >= a.N) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -168,13 +171,19 @@ int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t 
     if (!gemm_supported(type_w, M, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
     PKV_REQUIRE(((uintptr_t) x % 16) == 0 && ((uintptr_t) y % 16) == 0, "pkv_mul_mat (batched): x and y must be 16-byte aligned");
     GemmArgs a = {(const unsigned char *) w, x, y, M, n_cols, K, (int64_t) row_size(type_w, K)};
-    const dim3 grid((unsigned) ((M + BM - 1) / BM), (unsigned) ((n_cols + BN - 1) / BN));
+    // 128 weight rows per workgroup, or 64 where that would leave CUs without a tile
+    const int64_t nt = (n_cols + BN - 1) / BN;
+    const bool small = ((M + 127) / 128) * nt < 256;
+    const int bm = small ? 64 : 128;
+    const dim3 grid((unsigned) ((M + bm - 1) / bm), (unsigned) nt);
+#define PKV_GEMM(T_) do { if (small) hipLaunchKernelGGL((gemm_kernel<T_, 64>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_kernel<T_, 128>), grid, dim3(256), 0, st, a); } while (0)
     switch (type_w) {
-        case PKV_TYPE_F16:  hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_F16>, grid, dim3(256), 0, st, a); break;
-        case PKV_TYPE_Q8_0: hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_Q8_0>, grid, dim3(256), 0, st, a); break;
-        case PKV_TYPE_Q4_K: hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_Q4_K>, grid, dim3(256), 0, st, a); break;
-        case PKV_TYPE_Q6_K: hipLaunchKernelGGL(gemm_kernel<PKV_TYPE_Q6_K>, grid, dim3(256), 0, st, a); break;
+        case PKV_TYPE_F16:  PKV_GEMM(PKV_TYPE_F16); break;
+        case PKV_TYPE_Q8_0: PKV_GEMM(PKV_TYPE_Q8_0); break;
+        case PKV_TYPE_Q4_K: PKV_GEMM(PKV_TYPE_Q4_K); break;
+        case PKV_TYPE_Q6_K: PKV_GEMM(PKV_TYPE_Q6_K); break;
     }
+#undef PKV_GEMM
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
