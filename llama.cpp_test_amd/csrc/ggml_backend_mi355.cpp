@@ -617,10 +617,129 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     }
     char * side_base = side_need && side_need <= ((size_t) 1 << 30) ? (char *) bc->side_buf(side_need) : nullptr;
     std::vector<char> done(n_nodes, 0);      // MUL_MAT nodes already run together with an earlier product on the same activations
+    // RMS_NORM n1 -> MUL n2 of ONE row whose only readers are K-quant products on that single column (the decode-chain rule takes all of it)
+    auto norm_feeds_decode_chain = [&](const ggml_tensor * n1, const ggml_tensor * n2) {
+        if (n1->op != GGML_OP_RMS_NORM || n2->op != GGML_OP_MUL || n2->src[0] != n1 || ggml_nrows(n1) != 1 || n1->ne[0] > 8192 || n1->ne[0] % 256 != 0) return false;
+        auto i1 = users.by_src.find(n1), i2 = users.by_src.find(n2);
+        if (i1 == users.by_src.end() || i1->second.size() != 1 || i2 == users.by_src.end() || i2->second.empty() || i2->second.size() > 3) return false;
+        for (int k : i2->second) {
+            const ggml_tensor * t = ggml_graph_node(g, k);
+            if (t->op != GGML_OP_MUL_MAT || t->src[1] != n2 || !t->src[0] || (t->src[0]->type != GGML_TYPE_Q4_K && t->src[0]->type != GGML_TYPE_Q6_K) || t->src[0]->ne[1] % 2 != 0) return false;
+        }
+        return true;
+    };
     for (int i = 0; i < n_nodes; ++i) {
         ggml_tensor * n = ggml_graph_node(g, i);
         ggml_status st = GGML_STATUS_SUCCESS;
         if (done[i]) continue;
+        // ---- decode-step chains (ONE activation column): [RMS_NORM -> MUL(norm weight) ->] {K-quant products on that column} [-> ADD(residual) |
+        //      SILU(gate) * up]  =  ONE pkv_gemv_q launch (csrc/pkv_gemv.hip: the norm and the q8_K column in the product's prologue, the residual add or
+        //      the SwiGLU in its epilogue) — a llama layer's decode step is then 7 launches (norm+qkv, rope/store, attention, merge, wo+add,
+        //      norm+gate+up+swiglu, down+add) instead of r01's 10.  Same arithmetic as the per-node launches (GGML_MI355_NO_FUSE=1), bit for bit.
+        if (fuse && (n->op == GGML_OP_RMS_NORM || n->op == GGML_OP_MUL_MAT)) {
+            auto kq_col = [&](const ggml_tensor * t, const ggml_tensor * col) {   // t = MUL_MAT of K-quant rows with the single column `col`
+                const ggml_tensor * w = t->src[0], * x = t->src[1];
+                return t->op == GGML_OP_MUL_MAT && x == col && w && (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) && ggml_is_contiguous(w) && f32c(x) && f32c(t) &&
+                       ggml_nrows(x) == 1 && w->ne[2] == 1 && w->ne[3] == 1 && w->ne[0] == x->ne[0] && w->ne[0] % 256 == 0 && w->ne[0] <= 49152 && w->ne[1] % 2 == 0 &&
+                       !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
+            };
+            auto only_user = [&](const ggml_tensor * t) -> int {                  // index of t's single consumer in this graph, or -1
+                auto it = users.by_src.find(t);
+                if (it == users.by_src.end() || it->second.size() != 1 || users.by_view.count(t) || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) return -1;
+                return it->second[0];
+            };
+            const ggml_tensor * col = nullptr, * xsrc = nullptr, * nw = nullptr;
+            float eps = 0.0f;
+            int i_mul = -1;
+            if (n->op == GGML_OP_RMS_NORM && supports_rms_norm(n) && ggml_nrows(n) == 1 && n->ne[0] <= 8192 && n->ne[0] % 256 == 0) {
+                i_mul = only_user(n);
+                ggml_tensor * n1 = i_mul >= 0 ? ggml_graph_node(g, i_mul) : nullptr;
+                if (n1 && n1->op == GGML_OP_MUL && n1->src[0] == n && supports_binary(n1) && ggml_nrows(n1->src[1]) == 1 && !(n1->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+                    !users.by_view.count(n1) && ((uintptr_t) n->src[0]->data % 16) == 0 && ((uintptr_t) n1->src[1]->data % 16) == 0) {
+                    col = n1; xsrc = n->src[0]; nw = n1->src[1];
+                    memcpy(&eps, n->op_params, sizeof(float));
+                }
+            } else if (n->op == GGML_OP_MUL_MAT && ((uintptr_t) n->src[1]->data % 16) == 0) {
+                col = n->src[1]; xsrc = col;
+            }
+            int prod[3], np = 0;
+            bool ok = col != nullptr;
+            if (ok && nw) {        // the normalised column is never written: EVERY reader of it must be one of the products of this launch
+                auto it = users.by_src.find(col);
+                ok = it != users.by_src.end() && it->second.size() <= 3;
+                if (ok) for (int k : it->second) { if (!done[k] && kq_col(ggml_graph_node(g, k), col)) prod[np++] = k; else ok = false; }
+                std::sort(prod, prod + np);
+            } else if (ok) {       // a column that exists: this product and the ones that share it close by (as the grouping rule below finds them)
+                for (int k = i; k < n_nodes && k <= i + 16 && np < 3; ++k) if (!done[k] && kq_col(ggml_graph_node(g, k), col)) prod[np++] = k;
+                ok = np > 0 && prod[0] == i;
+            }
+            // epilogue of the chain
+            int i_silu = -1, i_mulgu = -1, i_add = -1;
+            const ggml_tensor * resid = nullptr;
+            float * yv[3] = {nullptr, nullptr, nullptr};
+            if (ok && np == 2) {   // gate, SILU(gate), up, MUL(silu, up): build_ffn's LLM_FFN_SILU + LLM_FFN_PAR
+                ggml_tensor * p0 = ggml_graph_node(g, prod[0]), * p1 = ggml_graph_node(g, prod[1]);
+                const int us0 = only_user(p0), us1 = only_user(p1);
+                ggml_tensor * sn = us0 >= 0 ? ggml_graph_node(g, us0) : nullptr;
+                const int um = sn ? only_user(sn) : -1;
+                ggml_tensor * mn = um >= 0 ? ggml_graph_node(g, um) : nullptr;
+                if (sn && mn && sn->op == GGML_OP_UNARY && supports_silu(sn) && sn->src[0] == p0 && mn->op == GGML_OP_MUL && us1 == um && !done[us0] && !done[um] &&
+                    ((mn->src[0] == sn && mn->src[1] == p1) || (mn->src[1] == sn && mn->src[0] == p1)) && f32c(mn) && ggml_nelements(mn) == p0->ne[0] && p0->ne[0] == p1->ne[0] &&
+                    !overlaps(mn, xsrc) && !(nw && overlaps(mn, nw))) { i_silu = us0; i_mulgu = um; yv[0] = (float *) mn->data; }
+            }
+            if (ok && np == 1) {   // attn_out / ffn_down + the residual stream
+                ggml_tensor * p0 = ggml_graph_node(g, prod[0]);
+                const int ua = only_user(p0);
+                ggml_tensor * an = ua >= 0 ? ggml_graph_node(g, ua) : nullptr;
+                if (an && an->op == GGML_OP_ADD && !done[ua] && supports_binary(an) && ggml_are_same_shape(an->src[0], an->src[1]) && (an->src[0] == p0) != (an->src[1] == p0)) {
+                    const ggml_tensor * r = an->src[0] == p0 ? an->src[1] : an->src[0];
+                    bool r_ready = true;                     // the other operand exists already: a leaf, or a node that has run
+                    for (int q = i; q < n_nodes && r_ready; ++q) if (ggml_graph_node(g, q) == r || (r->view_src && ggml_graph_node(g, q) == r->view_src)) r_ready = done[q] != 0;
+                    if (r_ready && !overlaps(an, xsrc) && alias_ok(an, r)) { i_add = ua; resid = r; yv[0] = (float *) an->data; }
+                }
+            }
+            size_t side_bytes = 0;
+            bool redirect[3] = {false, false, false};
+            if (ok && i_silu < 0 && i_add < 0) {
+                if (!nw && np == 1) ok = false;              // a lone product without norm or epilogue: nothing to merge, the rules below handle it
+                for (int q = 0; q < np && ok; ++q) {         // plain outputs: must not be written over the column other workgroups still read, nor over each other
+                    ggml_tensor * pq = ggml_graph_node(g, prod[q]);
+                    bool safe = !overlaps(pq, xsrc) && !(nw && overlaps(pq, nw));
+                    for (int r_ = 0; r_ < q && safe; ++r_) if (overlaps(pq, ggml_graph_node(g, prod[r_]))) safe = false;
+                    for (int k = i; k < prod[q] && safe; ++k) {          // pulled forward over the nodes in between (none of them may touch its output range)
+                        const ggml_tensor * nk = ggml_graph_node(g, k);
+                        if (k == i_mul || std::find(prod, prod + np, k) != prod + np) continue;
+                        if (overlaps(pq, nk)) safe = false;
+                        for (int s_ = 0; s_ < GGML_MAX_SRC && safe; ++s_) if (nk->src[s_] && overlaps(pq, nk->src[s_])) safe = false;
+                    }
+                    if (!safe && !overlaps(pq, xsrc) && side_base && consumers_take_moved(g, users, pq)) { redirect[q] = true; safe = true; side_bytes += (ggml_nbytes(pq) + 255) / 256 * 256; }
+                    ok = safe;
+                    yv[q] = (float *) pq->data;
+                }
+                if (ok && side_used + side_bytes > side_need) ok = false;
+            }
+            if (ok) {
+                pkv_gemv gv = {};
+                gv.n = np; gv.K = col->ne[0]; gv.x = (const float *) bc->src_data(xsrc); gv.norm_w = nw ? (const float *) nw->data : nullptr; gv.eps = eps;
+                gv.silu_mul = i_silu >= 0; gv.residual = resid ? (const float *) bc->src_data(resid) : nullptr;
+                char * side = side_base + side_used;
+                for (int q = 0; q < np; ++q) {
+                    ggml_tensor * pq = ggml_graph_node(g, prod[q]);
+                    gv.type_w[q] = (int32_t) pq->src[0]->type; gv.w[q] = pq->src[0]->data; gv.M[q] = pq->src[0]->ne[1];
+                    gv.y[q] = yv[q] ? yv[q] : yv[0];
+                    if (redirect[q]) { gv.y[q] = (float *) side; bc->moved[pq] = side; side += (ggml_nbytes(pq) + 255) / 256 * 256; }
+                }
+                if (pkv_gemv_q(&gv, bc->stream) == PKV_OK) {
+                    side_used += side_bytes;
+                    if (i_mul >= 0) done[i_mul] = 1;
+                    for (int q = 0; q < np; ++q) done[prod[q]] = 1;
+                    if (i_silu >= 0) { done[i_silu] = 1; done[i_mulgu] = 1; }
+                    if (i_add >= 0) done[i_add] = 1;
+                    continue;
+                }
+                for (int q = 0; q < np; ++q) if (redirect[q]) bc->moved.erase(ggml_graph_node(g, prod[q]));
+            }
+        }
         // q4_K products that read the SAME activation tensor (wq / wk / wv of a layer, gate / up of its FFN) run as one launch: the later
         // ones are pulled forward to the first, when their output does not alias anything the nodes in between read or write
         // (ggml-alloc hands freed ranges to later nodes, ggml-alloc.c:470-560)
@@ -693,7 +812,8 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         //   ADD(a, b) -> RMS_NORM -> MUL            (the residual add in front of a norm: ffn_inp / l_out; its sum is still written)
         if (fuse && i + 2 < n_nodes && n->op == GGML_OP_ADD && supports_binary(n) && ggml_are_same_shape(n->src[0], n->src[1])) {
             ggml_tensor * n1 = ggml_graph_node(g, i + 1), * n2 = ggml_graph_node(g, i + 2);
-            if (n1->op == GGML_OP_RMS_NORM && n1->src[0] == n && supports_rms_norm(n1) && n2->op == GGML_OP_MUL && n2->src[0] == n1 && supports_binary(n2) &&
+            if (norm_feeds_decode_chain(n1, n2)) {}   // one row whose norm goes into the products' own launch (above): the ADD runs by itself
+            else if (n1->op == GGML_OP_RMS_NORM && n1->src[0] == n && supports_rms_norm(n1) && n2->op == GGML_OP_MUL && n2->src[0] == n1 && supports_binary(n2) &&
                 ggml_nrows(n2->src[1]) == 1 && n1->data != n->data && n2->data != n->data &&   // the sum must survive: it is the next residual
                 !overlaps(n1, n) && !overlaps(n2, n) &&
                 alias_ok(n, n->src[0]) && alias_ok(n, n->src[1]) && alias_ok(n1, n->src[0]) && alias_ok(n1, n->src[1]) &&
