@@ -391,6 +391,8 @@ typedef struct pkv_gemv {
     const float * x;                   /* xq == NULL: the f32 activation column [K] (16-byte aligned); every workgroup quantizes   */
     const float * norm_w;              /*   it into LDS under its first weight loads — after rms_norm(x) * norm_w when norm_w != NULL */
     float         eps;                 /*   (build_norm feeding the product: no norm launch, no quantize launch; K <= 8192 then)   */
+    float *       norm_out;            /* optional, with norm_w: rms_norm(x) [K] and                                              */
+    float *       col_out;             /*   rms_norm(x) * norm_w [K] are ALSO written (by one workgroup): a graph that names them     */
 } pkv_gemv;
 size_t pkv_act_image_bytes(int64_t K);
 int pkv_quantize_act(const float * x, void * image, int64_t K, void * stream);

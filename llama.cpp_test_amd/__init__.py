@@ -81,7 +81,7 @@ class Gemv(C.Structure):
     """pkv_gemv"""
     _fields_ = [("n", C.c_int32), ("silu_mul", C.c_int32), ("type_w", C.c_int32 * 3), ("w", C.c_void_p * 3), ("y", C.c_void_p * 3),
                 ("M", C.c_int64 * 3), ("K", C.c_int64), ("xq", C.c_void_p), ("residual", C.c_void_p), ("x", C.c_void_p), ("norm_w", C.c_void_p),
-                ("eps", C.c_float)]
+                ("eps", C.c_float), ("norm_out", C.c_void_p), ("col_out", C.c_void_p)]
 
 
 class CacheParams(C.Structure):
@@ -541,7 +541,7 @@ def rms_norm_mul_q(x, w, eps: float, image, *, res=None, x_out=None, y=None, str
     return image
 
 
-def gemv_q(ws, types, Ms, K: int, image, outs, *, residual=None, silu_mul: bool = False, x=None, norm_w=None, eps: float = 0.0, stream=None):
+def gemv_q(ws, types, Ms, K: int, image, outs, *, residual=None, silu_mul: bool = False, x=None, norm_w=None, eps: float = 0.0, stream=None, norm_out=None, col_out=None):
     """pkv_gemv_q: up to three K-quant products on one activation column in one launch; outs = list of f32 [M_i] tensors
     (silu_mul: outs[0] = silu(W0 x) * (W1 x), outs[1] unused; residual: outs[0] = residual + W0 x).  image = the column's activation image,
     or None: the kernel quantizes the f32 column `x` itself, after rms_norm(x) * norm_w when norm_w is given."""
@@ -549,6 +549,7 @@ def gemv_q(ws, types, Ms, K: int, image, outs, *, residual=None, silu_mul: bool 
     g = Gemv()
     g.n, g.silu_mul, g.K, g.xq, g.residual = n, int(silu_mul), K, _ptr(image), _ptr(residual)
     g.x, g.norm_w, g.eps = _ptr(x), _ptr(norm_w), eps
+    g.norm_out, g.col_out = _ptr(norm_out), _ptr(col_out)
     for i in range(n):
         g.type_w[i], g.w[i], g.y[i], g.M[i] = int(types[i]), _ptr(ws[i]), _ptr(outs[i] if i < len(outs) else outs[0]), int(Ms[i])
     check(lib().pkv_gemv_q(C.byref(g), C.c_void_p(_stream(stream))))

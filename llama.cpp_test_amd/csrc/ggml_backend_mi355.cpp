@@ -619,6 +619,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
     std::vector<char> done(n_nodes, 0);      // MUL_MAT nodes already run together with an earlier product on the same activations
     // RMS_NORM n1 -> MUL n2 of ONE row whose only readers are K-quant products on that single column (the decode-chain rule takes all of it)
     auto norm_feeds_decode_chain = [&](const ggml_tensor * n1, const ggml_tensor * n2) {
+        if (getenv("GGML_MI355_CHAIN") && !(atoi(getenv("GGML_MI355_CHAIN")) & 1)) return false;
         if (n1->op != GGML_OP_RMS_NORM || n2->op != GGML_OP_MUL || n2->src[0] != n1 || ggml_nrows(n1) != 1 || n1->ne[0] > 8192 || n1->ne[0] % 256 != 0) return false;
         auto i1 = users.by_src.find(n1), i2 = users.by_src.find(n2);
         if (i1 == users.by_src.end() || i1->second.size() != 1 || i2 == users.by_src.end() || i2->second.empty() || i2->second.size() > 3) return false;
@@ -636,6 +637,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         //      SILU(gate) * up]  =  ONE pkv_gemv_q launch (csrc/pkv_gemv.hip: the norm and the q8_K column in the product's prologue, the residual add or
         //      the SwiGLU in its epilogue) — a llama layer's decode step is then 7 launches (norm+qkv, rope/store, attention, merge, wo+add,
         //      norm+gate+up+swiglu, down+add) instead of r01's 10.  Same arithmetic as the per-node launches (GGML_MI355_NO_FUSE=1), bit for bit.
+        static const int chain_mask = getenv("GGML_MI355_CHAIN") ? atoi(getenv("GGML_MI355_CHAIN")) : 7;   // debugging aid: 1 = norm chains, 2 = residual epilogue, 4 = SwiGLU epilogue
         if (fuse && (n->op == GGML_OP_RMS_NORM || n->op == GGML_OP_MUL_MAT)) {
             auto kq_col = [&](const ggml_tensor * t, const ggml_tensor * col) {   // t = MUL_MAT of K-quant rows with the single column `col`
                 const ggml_tensor * w = t->src[0], * x = t->src[1];
@@ -651,11 +653,11 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             const ggml_tensor * col = nullptr, * xsrc = nullptr, * nw = nullptr;
             float eps = 0.0f;
             int i_mul = -1;
-            if (n->op == GGML_OP_RMS_NORM && supports_rms_norm(n) && ggml_nrows(n) == 1 && n->ne[0] <= 8192 && n->ne[0] % 256 == 0) {
+            if (n->op == GGML_OP_RMS_NORM && (chain_mask & 1) && supports_rms_norm(n) && ggml_nrows(n) == 1 && n->ne[0] <= 8192 && n->ne[0] % 256 == 0) {
                 i_mul = only_user(n);
                 ggml_tensor * n1 = i_mul >= 0 ? ggml_graph_node(g, i_mul) : nullptr;
                 if (n1 && n1->op == GGML_OP_MUL && n1->src[0] == n && supports_binary(n1) && ggml_nrows(n1->src[1]) == 1 && !(n1->flags & GGML_TENSOR_FLAG_OUTPUT) &&
-                    !users.by_view.count(n1) && ((uintptr_t) n->src[0]->data % 16) == 0 && ((uintptr_t) n1->src[1]->data % 16) == 0) {
+                    ((uintptr_t) n->src[0]->data % 16) == 0 && ((uintptr_t) n1->src[1]->data % 16) == 0 && ((uintptr_t) n->data % 16) == 0 && ((uintptr_t) n1->data % 16) == 0) {
                     col = n1; xsrc = n->src[0]; nw = n1->src[1];
                     memcpy(&eps, n->op_params, sizeof(float));
                 }
@@ -664,11 +666,11 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             }
             int prod[3], np = 0;
             bool ok = col != nullptr;
-            if (ok && nw) {        // the normalised column is never written: EVERY reader of it must be one of the products of this launch
+            if (ok && nw) {        // the products of the normalised column that this graph holds (the column itself is still written: readers elsewhere are fine)
                 auto it = users.by_src.find(col);
-                ok = it != users.by_src.end() && it->second.size() <= 3;
-                if (ok) for (int k : it->second) { if (!done[k] && kq_col(ggml_graph_node(g, k), col)) prod[np++] = k; else ok = false; }
+                if (it != users.by_src.end()) for (int k : it->second) if (np < 3 && !done[k] && kq_col(ggml_graph_node(g, k), col)) prod[np++] = k;
                 std::sort(prod, prod + np);
+                ok = np > 0;
             } else if (ok) {       // a column that exists: this product and the ones that share it close by (as the grouping rule below finds them)
                 for (int k = i; k < n_nodes && k <= i + 16 && np < 3; ++k) if (!done[k] && kq_col(ggml_graph_node(g, k), col)) prod[np++] = k;
                 ok = np > 0 && prod[0] == i;
@@ -677,7 +679,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             int i_silu = -1, i_mulgu = -1, i_add = -1;
             const ggml_tensor * resid = nullptr;
             float * yv[3] = {nullptr, nullptr, nullptr};
-            if (ok && np == 2) {   // gate, SILU(gate), up, MUL(silu, up): build_ffn's LLM_FFN_SILU + LLM_FFN_PAR
+            if (ok && np == 2 && (chain_mask & 4)) {   // gate, SILU(gate), up, MUL(silu, up): build_ffn's LLM_FFN_SILU + LLM_FFN_PAR
                 ggml_tensor * p0 = ggml_graph_node(g, prod[0]), * p1 = ggml_graph_node(g, prod[1]);
                 const int us0 = only_user(p0), us1 = only_user(p1);
                 ggml_tensor * sn = us0 >= 0 ? ggml_graph_node(g, us0) : nullptr;
@@ -687,7 +689,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                     ((mn->src[0] == sn && mn->src[1] == p1) || (mn->src[1] == sn && mn->src[0] == p1)) && f32c(mn) && ggml_nelements(mn) == p0->ne[0] && p0->ne[0] == p1->ne[0] &&
                     !overlaps(mn, xsrc) && !(nw && overlaps(mn, nw))) { i_silu = us0; i_mulgu = um; yv[0] = (float *) mn->data; }
             }
-            if (ok && np == 1) {   // attn_out / ffn_down + the residual stream
+            if (ok && np == 1 && (chain_mask & 2)) {   // attn_out / ffn_down + the residual stream
                 ggml_tensor * p0 = ggml_graph_node(g, prod[0]);
                 const int ua = only_user(p0);
                 ggml_tensor * an = ua >= 0 ? ggml_graph_node(g, ua) : nullptr;
@@ -722,6 +724,9 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 pkv_gemv gv = {};
                 gv.n = np; gv.K = col->ne[0]; gv.x = (const float *) bc->src_data(xsrc); gv.norm_w = nw ? (const float *) nw->data : nullptr; gv.eps = eps;
                 gv.silu_mul = i_silu >= 0; gv.residual = resid ? (const float *) bc->src_data(resid) : nullptr;
+                // the normalised column and the norm are still written (one workgroup): products of the same column that sit in ANOTHER graph of the
+                // scheduler (a split, or a cb_eval observer cutting the graph) read them
+                if (nw) { gv.norm_out = (float *) n->data; gv.col_out = (float *) col->data; }
                 char * side = side_base + side_used;
                 for (int q = 0; q < np; ++q) {
                     ggml_tensor * pq = ggml_graph_node(g, prod[q]);
@@ -729,6 +734,8 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                     gv.y[q] = yv[q] ? yv[q] : yv[0];
                     if (redirect[q]) { gv.y[q] = (float *) side; bc->moved[pq] = side; side += (ggml_nbytes(pq) + 255) / 256 * 256; }
                 }
+                if (trace) MI355_LOG("chain at node %d (%s): np %d types %d %d %d norm %d silu %d add %d redirect %d %d %d side %zu/%zu x %p\n", i, n->name, np, gv.type_w[0], gv.type_w[1], gv.type_w[2],
+                                     nw != nullptr, i_silu, i_add, redirect[0], redirect[1], redirect[2], side_used, side_need, (const void *) gv.x);
                 if (pkv_gemv_q(&gv, bc->stream) == PKV_OK) {
                     side_used += side_bytes;
                     if (i_mul >= 0) done[i_mul] = 1;

@@ -83,6 +83,7 @@ struct GemvArgs {
     const float * x;                     // img == NULL: quantize this column in the kernel (after rms_norm(x) * norm_w when norm_w != NULL)
     const float * norm_w;
     float        eps;
+    float *      norm_out, * col_out;     // optional: the normalised column (x * scale, and * norm_w), written by workgroup 0
     int64_t      K;
     int          gpr, gs;                // 64-element groups per row, LDS row stride (odd)
 };
@@ -382,7 +383,15 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = threadIdx.x + NT * j;                   // n4 % 64 == 0: a wave is in or out as a whole
-                if (i - lane < n4) put(i, make_float4(v[j].x * scale * w4[j].x, v[j].y * scale * w4[j].y, v[j].z * scale * w4[j].z, v[j].w * scale * w4[j].w));
+                if (i - lane < n4) {
+                    const float4 nn = make_float4(v[j].x * scale, v[j].y * scale, v[j].z * scale, v[j].w * scale);          // rms_norm(x): as rms_norm_mul_kernel rounds it
+                    const float4 oo = make_float4(nn.x * w4[j].x, nn.y * w4[j].y, nn.z * w4[j].z, nn.w * w4[j].w);
+                    if (blockIdx.x == 0 && i < n4) {
+                        if (a.norm_out) reinterpret_cast<float4 *>(a.norm_out)[i] = nn;
+                        if (a.col_out)  reinterpret_cast<float4 *>(a.col_out)[i] = oo;
+                    }
+                    put(i, oo);
+                }
             }
         } else {
             constexpr int NB8 = 8;                                    // batches of 8 float4 per thread: the loads of a batch share one round trip
@@ -483,6 +492,7 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     for (int i = g.n; i < PKV_GEMV_MAX; ++i) { a.rp_end[i] = tot; a.w[i] = a.w[0]; a.y[i] = a.y[0]; a.M[i] = 0; a.type[i] = a.type[0]; }
     a.n = g.n; a.silu_mul = g.silu_mul; a.residual = g.residual; a.img = (const char *) g.xq; a.K = g.K;
     a.x = g.x; a.norm_w = g.xq ? nullptr : g.norm_w; a.eps = g.eps;
+    a.norm_out = a.norm_w ? g.norm_out : nullptr; a.col_out = a.norm_w ? g.col_out : nullptr;
     a.gpr = (int) (g.K / 64); a.gs = 0;
     const size_t lds = (size_t) REC * a.gpr * 4;
     // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)

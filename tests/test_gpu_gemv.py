@@ -182,3 +182,21 @@ def test_gemv_in_kernel_column_equals_separate_launches(pkv, K, norm):
     y0 = torch.zeros(6, device="cuda")
     pkv.gemv_q([w_small], [12], [6], K, img, [y0])
     assert torch.equal(y1, r + y0)
+
+
+def test_gemv_norm_outputs_are_materialised(pkv):
+    """norm_out / col_out: the fused launch also writes rms_norm(x) and rms_norm(x) * w (one workgroup), the bits pkv_rms_norm_f32 / pkv_rms_norm_mul_f32 write —
+    what the plugin hands to readers of the normalised column that sit in another graph of the scheduler"""
+    from llama_cpp_test_amd import gguf_synth as G
+    rng = np.random.default_rng(21)
+    for K, M in ((512, 256), (4096, 1024), (8192, 64)):
+        w, _ = weights(G, rng, 12, M, K)
+        x = dev(rng.standard_normal(K).astype(np.float32) * 3)
+        nw = dev((1 + 0.2 * rng.standard_normal(K)).astype(np.float32))
+        y0, y1 = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
+        no, co = torch.zeros(K, device="cuda"), torch.zeros(K, device="cuda")
+        pkv.gemv_q([w], [12], [M], K, None, [y0], x=x, norm_w=nw, eps=1e-5)
+        pkv.gemv_q([w], [12], [M], K, None, [y1], x=x, norm_w=nw, eps=1e-5, norm_out=no, col_out=co)
+        assert torch.equal(y0, y1)
+        assert torch.equal(no, pkv.rms_norm(x.reshape(1, K), 1e-5).reshape(K))
+        assert torch.equal(co, pkv.rms_norm_mul(x.reshape(1, K), nw, 1e-5).reshape(K))
