@@ -5,11 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _load_pkg
 pkv = _load_pkg.load()
 H, HK, D, BS = (64, 8, 128, 128) if os.environ.get("PKV_PREFILL_GEOM") == "70b" else (32, 8, 128, 128)   # Llama-3-70B : 8B
-for kv_type in (("f16",) if os.environ.get("PKV_PREFILL_ONE") else ("f16", "q8_0")):
+for kv_type in (("f16",) if (os.environ.get("PKV_PREFILL_ONE") or os.environ.get("PKV_PREFILL_CASE")) else ("f16", "q8_0")):
     t = pkv.TYPE_BY_NAME[kv_type]
     CASES = ((32, 512, 0), (1, 512, 0), (4, 2048, 0), (1, 512, 3584), (1, 4096, 0), (1, 512, 15872))
     if os.environ.get("PKV_PREFILL_ONE"):
         CASES = CASES[:1]
+    if os.environ.get("PKV_PREFILL_CASE"):
+        CASES = [CASES[int(os.environ["PKV_PREFILL_CASE"])]]
     for n_seq, n_q, past in CASES:
         L = n_q + past
         bps = -(-L // BS)

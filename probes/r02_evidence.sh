@@ -42,6 +42,10 @@ timeout -k 10 400 python3 probes/gemv_shapes.py > $O/gemv_shapes.txt 2>&1; grep 
 timeout -k 10 300 python3 probes/gemm_bench.py > $O/gemm_bench.txt 2>&1; grep -v amdgpu.ids $O/gemm_bench.txt
 timeout -k 10 300 python3 probes/batched_bench.py > $O/batched_bench.txt 2>&1; tail -3 $O/batched_bench.txt
 timeout -k 10 300 python3 probes/bench_prefill.py > $O/bench_prefill.txt 2>&1; tail -6 $O/bench_prefill.txt
+step "prefill: PMC passes, timing ablations, phase stamps"
+O_DIR=$O/pmc_prefill bash probes/r02_pmc_prefill.sh r02_final/pmc_prefill > $O/prefill_pmc.txt 2>&1; tail -2 $O/prefill_pmc.txt
+O_ABL=$O bash probes/r02_p_abl.sh > /dev/null 2>&1; cat $O/ablate.txt
+timeout -k 10 120 python3 probes/stamp_prefill.py > $O/prefill_stamps.txt 2>&1; grep tile $O/prefill_stamps.txt
 step "reference runtime end to end through the plugin"
 timeout -k 10 600 python3 tests/evidence/ref_runtime_8b_q4k.py 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/e2e_8b_q4k_plugin.txt; tail -4 $O/e2e_8b_q4k_plugin.txt
 timeout -k 10 600 python3 tests/evidence/ref_cpu_tinyllama.py 32 --plugin 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/tinyllama_e2e_plugin.txt; tail -3 $O/tinyllama_e2e_plugin.txt

@@ -128,8 +128,9 @@ def test_prefill_general_mask_noncausal(pkv, O, tk, max_bias, softcap):
     """the ggml_flash_attn_ext contract as tests/test-backend-ops.cpp:3197-3272 exercises it: every query sees every cell,
     an additive f16 mask with arbitrary values (and -inf holes), ALiBi slopes (max_bias), logit soft-cap"""
     rng = np.random.default_rng(int(tk * 100 + max_bias + softcap))
-    D, nh, nkv, n_kv = 128, 8, 2, 512
-    for n_q in (1, 3, 35):
+    D, nh, nkv = 128, 8, 2
+    # n_kv 509: mask rows 1018 bytes apart — the kernel's one-cell-per-load path (rows off 8-byte boundaries); 512: its 8-byte loads
+    for n_q, n_kv in ((1, 512), (3, 512), (35, 512), (35, 509)):
         kp, vp, bt, sl = make_paged_case(O, rng, lens=[n_kv], D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
         q = rng.uniform(-1, 1, (n_q, nh, D)).astype(np.float32)
         mask = rng.uniform(-1, 1, (n_q, n_kv)).astype(np.float16)
