@@ -331,8 +331,10 @@ struct VStage<PKV_TYPE_F16, D, NT> {
     }
 };
 
-template <int KT, int VT, int D, int G, bool SOFTCAP, bool STAMP = false, bool MASKED = false>
-__global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t * __restrict__ p_table, const int32_t * __restrict__ p_lens,
+// QB = 32-query blocks per wave.  QB = 2 (G <= 4: one wave per SIMD, the whole 512-entry register file): every K / V^T fragment read from LDS
+// feeds TWO MFMAs, and a staged KV tile, a barrier and a table lookup serve 64 queries per head instead of 32.
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool STAMP = false, bool MASKED = false, int QB = 1>
+__global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(const int32_t * __restrict__ p_table, const int32_t * __restrict__ p_lens,
                                                                  const int32_t * __restrict__ p_qstart, const PrefillArgs a) {
     // the three leading arguments (= a.block_table, a.seq_lens, a.q_start) as explicit restrict-qualified parameters: hipcc reads them with
     // SCALAR loads.  Through the by-value struct it used a vector load + s_waitcnt vmcnt(0) + v_readfirstlane for every table entry, i.e.
@@ -340,6 +342,7 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
     unsigned long long t_begin = 0, t_q = 0, t_loop = 0, t_stage = 0, t_qk = 0, t_sm = 0, t_pv = 0, tt = 0;
     if constexpr (STAMP) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int NT = 64 * G, KS = D / 16, DT = D / 32;  // k-steps of QK^T, 32-row d tiles of O^T
+    constexpr int QTW = QT * QB;                          // query rows per wave = per workgroup tile
     constexpr bool PIN = !SOFTCAP && !MASKED;             // hand-placed operand reads (see the loop); the rare variants leave it to hipcc
     // two LDS images per operand: tile t+1 is written while slower waves still multiply tile t -> ONE barrier per tile
     constexpr int IMG = KVT * D * 2;                                  // one f16 tile image
@@ -353,29 +356,38 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
     const int xr   = gridDim.x - 1 - lin / nhs;                     // x = tile * n_split + split, longest tiles first
     const int tile = xr / a.n_split, sp = xr % a.n_split, hk = (lin % nhs) % gridDim.y, s = (lin % nhs) / gridDim.y;
     const int tok0 = p_qstart[s], n_q = p_qstart[s + 1] - tok0;
-    if (tile * QT >= n_q) return;
+    if (tile * QTW >= n_q) return;
     const int seq_len = p_lens[s];
     const int tid = threadIdx.x, g = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;   // g: wave-uniform, and known to be
     const int head = hk * G + g;
-    const int jr = tile * QT + r;            // this lane's query inside the sequence's new tokens
-    const bool q_ok = jr < n_q;
-    const int n_rows = min(QT, n_q - tile * QT);   // query rows of this tile that exist
-    // index of the last KV cell this query sees, and the workgroup-uniform bound of the KV loop
-    const int qpos   = a.causal ? seq_len - n_q + jr : seq_len - 1;
-    const int kv_all = a.causal ? min(seq_len, seq_len - n_q + tile * QT + QT) : seq_len;   // cells this query tile can see
+    int jr[QB], qpos[QB];                    // this lane's queries (one per block) inside the sequence's new tokens; the last KV cell each sees
+    bool q_ok[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        jr[b]   = tile * QTW + b * QT + r;
+        q_ok[b] = jr[b] < n_q;
+        qpos[b] = a.causal ? seq_len - n_q + jr[b] : seq_len - 1;
+    }
+    const int n_rows = min(QTW, n_q - tile * QTW);   // query rows of this tile that exist
+    // the workgroup-uniform bound of the KV loop
+    const int kv_all = a.causal ? min(seq_len, seq_len - n_q + tile * QTW + QTW) : seq_len;   // cells this query tile can see
     const int nkt    = (kv_all + KVT - 1) / KVT;                                             // ... in KV tiles
     const int kv_beg = (int) ((long long) nkt * sp / a.n_split) * KVT;                       // this workgroup's share
     const int kv_end = min(kv_all, (int) ((long long) nkt * (sp + 1) / a.n_split) * KVT);
 
-    floatx16 o[DT];
+    floatx16 o[QB][DT];
+    float m[QB], lsum[QB];              // lsum: this lane's share of l (its 32 of the tile's 64 cells), summed from the f16-rounded weights PV applies
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int b = 0; b < QB; ++b) {
+        m[b] = -INFINITY; lsum[b] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
-    float m = -INFINITY, lsum = 0.0f;   // lsum: this lane's share of l (its 32 of the tile's 64 cells), summed from the f16-rounded weights PV applies
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[b][dt][i] = 0.0f;
+    }
     const half2_t one2 = {(__fp16) 1.0f, (__fp16) 1.0f};
     const float cexp = ((SOFTCAP || MASKED) ? 1.0f : a.scale) * 1.44269504088896340736f;   // exp(x * scale) = exp2(x * cexp)
-    const int qpos_min = a.causal ? seq_len - n_q + tile * QT : seq_len - 1;                  // smallest last-visible cell in the tile
+    const int qpos_min = a.causal ? seq_len - n_q + tile * QTW : seq_len - 1;                  // smallest last-visible cell in the tile
     float slope = 1.0f;
     if constexpr (MASKED) {
         if (a.max_bias > 0.0f) {
@@ -385,9 +397,11 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
         }
     }
     // mask rows of this tile's queries: row = token index, column = kv cell; this lane reads row r (row 0 for a query that does not exist)
-    [[maybe_unused]] const rsrc_t rs_mask = mk_rsrc(MASKED ? a.mask + (size_t) (tok0 + tile * QT) * a.mask_stride : nullptr,
+    [[maybe_unused]] const rsrc_t rs_mask = mk_rsrc(MASKED ? a.mask + (size_t) (tok0 + tile * QTW) * a.mask_stride : nullptr,
                                                     MASKED ? ((long long) (n_rows - 1) * a.mask_stride + seq_len) * 2 : 0);
-    [[maybe_unused]] const int mask_vo = (int) ((q_ok ? r : 0) * a.mask_stride * 2) + 8 * h;
+    [[maybe_unused]] int mask_vo[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) mask_vo[b] = (int) ((q_ok[b] ? b * QT + r : 0) * a.mask_stride * 2) + 8 * h;
 
     const int vsw = vswz(r) ^ h;             // swizzle of this lane's V^T rows (d = 32 dt + r: the same for every dt), its k half folded in
     const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
@@ -431,32 +445,37 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
     // ---- Q^T fragments, rounded to f16 (GGML_FP32_TO_FP16 of the reference's q_to_vec_dot for f16 K).  Lane (r, h) needs 32 bytes of
     //      row r per k-step: fetched that way every load instruction touches 64 cache lines.  Instead the wave reads its 32 rows as
     //      whole rows (two 512-byte rows per instruction), converts, and turns them through an LDS strip (the tile images are free).
-    half8_t qf[KS];
+    half8_t qf[QB][KS];
     {
-        char * strip = smem + (QFREE ? IMG : 0) + g * (QT * D * 2);   // [32 rows][D halfs], 16-byte chunk c of row q at c ^ (q & 15)
+        char * strip = smem + (QFREE ? IMG : 0) + g * (QT * D * 2);   // [32 rows][D halfs], 16-byte chunk c of row q at c ^ (q & 15); one block at a time
         static_assert(G * QT * D * 2 <= 4 * IMG, "Q strips must fit the tile images");
         const long long qsb = (long long) a.q_stride_tok * 4;
-        const rsrc_t rq = mk_rsrc(a.q + (size_t) (tok0 + tile * QT) * a.q_stride_tok + (size_t) head * a.q_stride_head, (n_rows - 1) * qsb + D * 4);
         constexpr int LPR = D / 4, RPI = 64 / LPR, NQ = QT / RPI;   // lanes per row, rows per instruction, instructions
         const int lr = lane / LPR, lc = lane % LPR;                   // row inside the instruction's group, float4 column
 #pragma unroll
-        for (int b = 0; b < NQ; b += 8) {
-            u4_t x[8];
+        for (int qb = 0; qb < QB; ++qb) {
+            const rsrc_t rq = mk_rsrc(a.q + (size_t) (tok0 + tile * QTW + qb * QT) * a.q_stride_tok + (size_t) head * a.q_stride_head,
+                                      (long long) (n_rows - qb * QT - 1) * qsb + D * 4);   // (a block past the end of the tile: no bytes, reads as 0)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int) (((b + i) * RPI + lr) * qsb) + lc * 16, 0, 0);
+            for (int b = 0; b < NQ; b += 8) {
+                u4_t x[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = (b + i) * RPI + lr;
-                _Float16 hv[4] = {(_Float16) __uint_as_float(x[i].x), (_Float16) __uint_as_float(x[i].y),
-                                  (_Float16) __uint_as_float(x[i].z), (_Float16) __uint_as_float(x[i].w)};
-                *reinterpret_cast<uint2 *>(strip + row * D * 2 + (((lc >> 1) ^ (row & 15)) & (D / 8 - 1)) * 16 + (lc & 1) * 8) = *reinterpret_cast<const uint2 *>(hv);
+                for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int) (((b + i) * RPI + lr) * qsb) + lc * 16, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = (b + i) * RPI + lr;
+                    _Float16 hv[4] = {(_Float16) __uint_as_float(x[i].x), (_Float16) __uint_as_float(x[i].y),
+                                      (_Float16) __uint_as_float(x[i].z), (_Float16) __uint_as_float(x[i].w)};
+                    *reinterpret_cast<uint2 *>(strip + row * D * 2 + (((lc >> 1) ^ (row & 15)) & (D / 8 - 1)) * 16 + (lc & 1) * 8) = *reinterpret_cast<const uint2 *>(hv);
+                }
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is private to this wave
-        __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is private to this wave
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[ks] = *reinterpret_cast<const half8_t *>(strip + r * D * 2 + (((2 * ks + h) ^ (r & 15)) & (D / 8 - 1)) * 16);
+            for (int ks = 0; ks < KS; ++ks)
+                qf[qb][ks] = *reinterpret_cast<const half8_t *>(strip + r * D * 2 + (((2 * ks + h) ^ (r & 15)) & (D / 8 - 1)) * 16);
+            if (qb + 1 < QB) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // (LDS serves a wave in order)
+        }
     }
     __syncthreads();                           // every wave has its Q fragments: the strips become tile images
     if constexpr (KDMA && !QFREE) prefetch_k(kv_first, phys0, sKb(0));
@@ -499,16 +518,19 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
         if constexpr (STAMP) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_stage += t2 - tt; tt = t2; }
 
         // ---- S^T = K . Q^T : two 32-row kv tiles ---------------------------------------------------------------
-        floatx16 sacc[2];
+        floatx16 sacc[QB][2];
         const floatx16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // the chain's first MFMA takes C = 0 as an inline constant
 #pragma unroll
         for (int gi = 0; gi < NGK; ++gi) {
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (PKV_PREFILL_ABLATE & 8) { if (gi % KG == 0 && j == 0) sacc[gi / KG] = zero16; sacc[gi / KG][j] += (float) fb[gi & 1][j][0] * (float) qf[(gi % KG) * 4 + j][0]; }
-                else
-                sacc[gi / KG] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[gi & 1][j], qf[(gi % KG) * 4 + j], (gi % KG == 0 && j == 0) ? zero16 : sacc[gi / KG], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    if (PKV_PREFILL_ABLATE & 8) { if (gi % KG == 0 && j == 0) sacc[b][gi / KG] = zero16; sacc[b][gi / KG][j] += (float) fb[gi & 1][j][0] * (float) qf[b][(gi % KG) * 4 + j][0]; }
+                    else
+                    sacc[b][gi / KG] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[gi & 1][j], qf[b][(gi % KG) * 4 + j], (gi % KG == 0 && j == 0) ? zero16 : sacc[b][gi / KG], 0, 0, 0);
+                }
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             if (gi + 2 < NGK) kread(fb[gi & 1], gi + 2);
             else              vread(fb[gi & 1], gi + 2 - NGK);   // the first two V^T groups land under the softmax arithmetic
@@ -522,16 +544,19 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
         if constexpr (STAMP) { asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory"); const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_qk += t2 - tt; tt = t2; }
         // ---- causal mask (only tiles that reach the diagonal), running max; VALU kept to ~1 op per logit:
         //      the softmax scale rides in the exponent, p = exp2(c*s - c*m) = one v_fma + one v_exp -----------------------
+        float mc[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
         if constexpr (SOFTCAP) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[mt][i] = a.softcap * tanhf(sacc[mt][i] * a.scale);
+                for (int i = 0; i < 16; ++i) sacc[b][mt][i] = a.softcap * tanhf(sacc[b][mt][i] * a.scale);
         } else if constexpr (MASKED) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[mt][i] *= a.scale;
+                for (int i = 0; i < 16; ++i) sacc[b][mt][i] *= a.scale;
         }
         if constexpr (MASKED) {  // s += slope * mask (:12349-12365); -inf entries skip the cell
             // accumulator registers 4a .. 4a+3 are 4 consecutive cells: 8 eight-byte loads through a descriptor over the tile's mask rows
@@ -541,19 +566,19 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int a4 = 0; a4 < 4; ++a4) {
-                        const u2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs_mask, mask_vo, (kv0 + mt * 32 + 8 * a4) * 2, 0);
+                        const u2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs_mask, mask_vo[b], (kv0 + mt * 32 + 8 * a4) * 2, 0);
                         const _Float16 * mh = reinterpret_cast<const _Float16 *>(&w);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) sacc[mt][4 * a4 + e] += slope * (float) mh[e];
+                        for (int e = 0; e < 4; ++e) sacc[b][mt][4 * a4 + e] += slope * (float) mh[e];
                     }
             } else {                           // rows that are not 8-byte aligned: one cell per load, one half tile at a time
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     unsigned short mv[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) mv[i] = __builtin_amdgcn_raw_buffer_load_b16(rs_mask, mask_vo, (kv0 + mt * 32 + (i & 3) + 8 * (i >> 2)) * 2, 0);
+                    for (int i = 0; i < 16; ++i) mv[i] = __builtin_amdgcn_raw_buffer_load_b16(rs_mask, mask_vo[b], (kv0 + mt * 32 + (i & 3) + 8 * (i >> 2)) * 2, 0);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sacc[mt][i] += slope * (float) *reinterpret_cast<const _Float16 *>(&mv[i]);
+                    for (int i = 0; i < 16; ++i) sacc[b][mt][i] += slope * (float) *reinterpret_cast<const _Float16 *>(&mv[i]);
                 }
             }
         }
@@ -562,59 +587,67 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    sacc[mt][i] = kv0 + mt * 32 + crow(i, h) <= qpos ? sacc[mt][i] : -INFINITY;
+                    sacc[b][mt][i] = kv0 + mt * 32 + crow(i, h) <= qpos[b] ? sacc[b][mt][i] : -INFINITY;
         }
         // max(a, b) as med3(a, b, +inf): fmaxf on an MFMA result makes hipcc quiet it first (one v_max x, x per logit)
         float tmx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!(PKV_PREFILL_ABLATE & 2))
 #pragma unroll
         for (int c = 0; c < 4; ++c) {          // four independent chains
-            tmx[c] = __builtin_amdgcn_fmed3f(sacc[0][c], sacc[1][c], INFINITY);
+            tmx[c] = __builtin_amdgcn_fmed3f(sacc[b][0][c], sacc[b][1][c], INFINITY);
 #pragma unroll
-            for (int i = c + 4; i < 16; i += 4) tmx[c] = __builtin_amdgcn_fmed3f(tmx[c], __builtin_amdgcn_fmed3f(sacc[0][i], sacc[1][i], INFINITY), INFINITY);
+            for (int i = c + 4; i < 16; i += 4) tmx[c] = __builtin_amdgcn_fmed3f(tmx[c], __builtin_amdgcn_fmed3f(sacc[b][0][i], sacc[b][1][i], INFINITY), INFINITY);
         }
         float tmax = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(tmx[0], tmx[1], INFINITY), __builtin_amdgcn_fmed3f(tmx[2], tmx[3], INFINITY), INFINITY);
         {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
             tmax = __builtin_amdgcn_fmed3f(__uint_as_float(sw[0]), __uint_as_float(sw[1]), INFINITY);   // both halves of the row: lanes l and l ^ 32
         }
-        const float m_new = __builtin_amdgcn_fmed3f(m, tmax, INFINITY);   // in units of the raw (or soft-capped) logit
-        const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m - m_new) * cexp);
-        m = m_new;
+        const float m_new = __builtin_amdgcn_fmed3f(m[b], tmax, INFINITY);   // in units of the raw (or soft-capped) logit
+        const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f((m[b] - m_new) * cexp);
+        m[b] = m_new;
         if (__any(alpha != 1.0f)) {  // wave-uniform: after the first tiles the running max rarely moves
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
-            lsum *= alpha;
+                for (int i = 0; i < 16; ++i) o[b][dt][i] *= alpha;
+            lsum[b] *= alpha;
         }
-        const float mc = m == -INFINITY ? 0.0f : m * cexp;
+        mc[b] = m[b] == -INFINITY ? 0.0f : m[b] * cexp;
+        }
         if (more && !(PKV_PREFILL_ABLATE & (4 | 128))) vst.write(sVb((it + 1) & 1), v_wo, v_u0);
         if constexpr (STAMP) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_sm += t2 - tt; tt = t2; }
         // ---- O^T += V^T . P^T ; the row sums l are v_dot2 adds of the same f16-rounded weights PV applies.  Group gi = (mt, s2):
         //      its weights are exponentiated while group gi-1's MFMAs run -------------------------------------------------------
-        auto pgroup = [&](int gi) -> half8_t {
+        auto pgroup = [&](int b, int gi) -> half8_t {
             const int mt = gi >> 1, s2 = gi & 1;
             half2_t pp[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float p0 = (PKV_PREFILL_ABLATE & 2) ? sacc[mt][8 * s2 + 2 * j] : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[mt][8 * s2 + 2 * j], cexp, -mc));
-                const float p1 = (PKV_PREFILL_ABLATE & 2) ? sacc[mt][8 * s2 + 2 * j + 1] : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[mt][8 * s2 + 2 * j + 1], cexp, -mc));
+                const float p0 = (PKV_PREFILL_ABLATE & 2) ? sacc[b][mt][8 * s2 + 2 * j] : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][mt][8 * s2 + 2 * j], cexp, -mc[b]));
+                const float p1 = (PKV_PREFILL_ABLATE & 2) ? sacc[b][mt][8 * s2 + 2 * j + 1] : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][mt][8 * s2 + 2 * j + 1], cexp, -mc[b]));
                 pp[j] = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-                if (!(PKV_PREFILL_ABLATE & 2)) lsum = __builtin_amdgcn_fdot2(pp[j], one2, lsum, false);
+                if (!(PKV_PREFILL_ABLATE & 2)) lsum[b] = __builtin_amdgcn_fdot2(pp[j], one2, lsum[b], false);
             }
             return *reinterpret_cast<const half8_t *>(pp);
         };
-        half8_t pf = pgroup(0);
+        half8_t pf[QB];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) pf[b] = pgroup(b, 0);
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                if (PKV_PREFILL_ABLATE & 16) o[dt][gi] += (float) fb[gi & 1][dt][0] * (float) pf[0];
-                else o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[gi & 1][dt], pf, o[dt], 0, 0, 0);
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    if (PKV_PREFILL_ABLATE & 16) o[b][dt][gi] += (float) fb[gi & 1][dt][0] * (float) pf[b][0];
+                    else o[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[gi & 1][dt], pf[b], o[b][dt], 0, 0, 0);
+                }
+            if (gi + 1 < 4) {
+#pragma unroll
+                for (int b = 0; b < QB; ++b) pf[b] = pgroup(b, gi + 1);
             }
-            if (gi + 1 < 4) pf = pgroup(gi + 1);
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             if (gi + 2 < 4) vread(fb[gi & 1], gi + 2);
         }
@@ -636,50 +669,53 @@ __global__ void __launch_bounds__(64 * G, 2) attn_prefill_kernel(const int32_t *
         static_assert(32 * DH * 4 * G <= 4 * IMG, "per-wave output strips must fit the tile images");
         float * strip = reinterpret_cast<float *>(smem) + g * 32 * DH;
         const bool  partial = a.n_split > 1;
-        float l_all;
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
-            l_all = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);   // the two lane halves hold the two halves of every tile's cells
-        }
-        const float inv = partial ? 1.0f : 1.0f / l_all;
-        if (partial && q_ok && h == 0) {                       // (m, l) of this share; an empty share leaves (-inf, 0)
-            float * ml = a.part_ml + (((size_t) (tok0 + jr) * a.n_head + head) * a.n_split + sp) * 2;
-            ml[0] = m == -INFINITY ? -INFINITY : m * cexp;
-            ml[1] = l_all;
-        }
-        const size_t th0 = (size_t) (tok0 + tile * QT) * a.n_head + head;           // (token, head) row of the tile's first query
         const long long rowb = (long long) a.n_head * (partial ? a.n_split : 1) * D * 4;   // bytes between two tokens' rows
-        const rsrc_t ro = mk_rsrc(partial ? a.part_o + (th0 * a.n_split + sp) * D : a.out + th0 * D, (n_rows - 1) * rowb + D * 4);
         __syncthreads();                                       // every wave is done reading the last K/V tile
 #pragma unroll
-        for (int pass = 0; pass < D / DH; ++pass) {
-#pragma unroll
-            for (int dt = pass * (DH / 32); dt < (pass + 1) * (DH / 32); ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; i += 4) {
-                    const int c = ((dt * 32 - pass * DH) + crow(i, h)) / 4;   // registers i..i+3 are 4 consecutive d
-                    *reinterpret_cast<float4 *>(strip + r * DH + ((c ^ (r & 7)) * 4)) =
-                        make_float4(o[dt][i] * inv, o[dt][i + 1] * inv, o[dt][i + 2] * inv, o[dt][i + 3] * inv);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is private to this wave
-            __builtin_amdgcn_wave_barrier();
-            constexpr int NS = 32 * CPRW / 64;                 // store instructions per pass
-#pragma unroll
-            for (int b = 0; b < NS; b += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int e = (b + i) * 64 + lane, row = e / CPRW, c = e % CPRW;
-                    v[i] = *reinterpret_cast<const float4 *>(strip + row * DH + ((c ^ (row & 7)) * 4));
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int e = (b + i) * 64 + lane, row = e / CPRW, c = e % CPRW;
-                    u4_t w; w.x = __float_as_uint(v[i].x); w.y = __float_as_uint(v[i].y); w.z = __float_as_uint(v[i].z); w.w = __float_as_uint(v[i].w);
-                    __builtin_amdgcn_raw_buffer_store_b128(w, ro, (int) (row * rowb) + (pass * DH + c * 4) * 4, 0, 0);
-                }
+        for (int qb = 0; qb < QB; ++qb) {
+            float l_all;
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum[qb]), __float_as_uint(lsum[qb]), false, false);
+                l_all = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);   // the two lane halves hold the two halves of every tile's cells
             }
-            if (pass + 1 < D / DH) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+            const float inv = partial ? 1.0f : 1.0f / l_all;
+            if (partial && q_ok[qb] && h == 0) {               // (m, l) of this share; an empty share leaves (-inf, 0)
+                float * ml = a.part_ml + (((size_t) (tok0 + jr[qb]) * a.n_head + head) * a.n_split + sp) * 2;
+                ml[0] = m[qb] == -INFINITY ? -INFINITY : m[qb] * cexp;
+                ml[1] = l_all;
+            }
+            const size_t th0 = (size_t) (tok0 + tile * QTW + qb * QT) * a.n_head + head;   // (token, head) row of the block's first query
+            const rsrc_t ro = mk_rsrc(partial ? a.part_o + (th0 * a.n_split + sp) * D : a.out + th0 * D, (n_rows - qb * QT - 1) * rowb + D * 4);
+#pragma unroll
+            for (int pass = 0; pass < D / DH; ++pass) {
+#pragma unroll
+                for (int dt = pass * (DH / 32); dt < (pass + 1) * (DH / 32); ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        const int c = ((dt * 32 - pass * DH) + crow(i, h)) / 4;   // registers i..i+3 are 4 consecutive d
+                        *reinterpret_cast<float4 *>(strip + r * DH + ((c ^ (r & 7)) * 4)) =
+                            make_float4(o[qb][dt][i] * inv, o[qb][dt][i + 1] * inv, o[qb][dt][i + 2] * inv, o[qb][dt][i + 3] * inv);
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is private to this wave
+                __builtin_amdgcn_wave_barrier();
+                constexpr int NS = 32 * CPRW / 64;             // store instructions per pass
+#pragma unroll
+                for (int b = 0; b < NS; b += 8) {
+                    float4 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = (b + i) * 64 + lane, row = e / CPRW, c = e % CPRW;
+                        v[i] = *reinterpret_cast<const float4 *>(strip + row * DH + ((c ^ (row & 7)) * 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = (b + i) * 64 + lane, row = e / CPRW, c = e % CPRW;
+                        u4_t w; w.x = __float_as_uint(v[i].x); w.y = __float_as_uint(v[i].y); w.z = __float_as_uint(v[i].z); w.w = __float_as_uint(v[i].w);
+                        __builtin_amdgcn_raw_buffer_store_b128(w, ro, (int) (row * rowb) + (pass * DH + c * 4) * 4, 0, 0);
+                    }
+                }
+                if (pass + 1 < D / DH || qb + 1 < QB) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+            }
         }
     }
     if constexpr (STAMP) {
@@ -716,7 +752,7 @@ __global__ void __launch_bounds__(D / 4) prefill_combine_kernel(const PrefillArg
 }
 
 template <int KT, int VT, int D, int G>
-int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
+int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, int qb, hipStream_t st) {
     if constexpr (KT == PKV_TYPE_F16 && VT == PKV_TYPE_F16 && D == 128 && G == 4) {
         if (pa.stamps) {
             hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, true>), dim3(n_tiles * pa.n_split, pa.n_head_kv, n_seq), dim3(64 * G), 0, st, pa.block_table, pa.seq_lens, pa.q_start, pa);
@@ -725,6 +761,14 @@ int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
         }
     }
     const dim3 grid(n_tiles * pa.n_split, pa.n_head_kv, n_seq), block(64 * G);
+    if constexpr (G <= 4) {
+        if (qb == 2) {   // (launch_attn_prefill asks for it only without mask / soft-cap)
+            hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, false, false, 2>), grid, block, 0, st, pa.block_table, pa.seq_lens, pa.q_start, pa);
+            if (pa.n_split > 1) hipLaunchKernelGGL((prefill_combine_kernel<D>), dim3(pa.n_head, pa.n_tok_total), dim3(D / 4), 0, st, pa);
+            PKV_HIP(hipGetLastError());
+            return PKV_OK;
+        }
+    }
     if (pa.mask) {
         if (pa.softcap != 0.0f) hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, true, false, true>), grid, block, 0, st, pa.block_table, pa.seq_lens, pa.q_start, pa);
         else                    hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, false, true>), grid, block, 0, st, pa.block_table, pa.seq_lens, pa.q_start, pa);
@@ -737,31 +781,31 @@ int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, hipStream_t st) {
     return PKV_OK;
 }
 template <int KT, int VT, int D>
-int launch_g(const PrefillArgs & pa, int G, int n_tiles, int n_seq, hipStream_t st) {
+int launch_g(const PrefillArgs & pa, int G, int n_tiles, int n_seq, int qb, hipStream_t st) {
     switch (G) {
-        case 1: return launch_one<KT, VT, D, 1>(pa, n_tiles, n_seq, st);
-        case 2: return launch_one<KT, VT, D, 2>(pa, n_tiles, n_seq, st);
-        case 4: return launch_one<KT, VT, D, 4>(pa, n_tiles, n_seq, st);
-        case 8: return launch_one<KT, VT, D, 8>(pa, n_tiles, n_seq, st);
+        case 1: return launch_one<KT, VT, D, 1>(pa, n_tiles, n_seq, qb, st);
+        case 2: return launch_one<KT, VT, D, 2>(pa, n_tiles, n_seq, qb, st);
+        case 4: return launch_one<KT, VT, D, 4>(pa, n_tiles, n_seq, qb, st);
+        case 8: return launch_one<KT, VT, D, 8>(pa, n_tiles, n_seq, qb, st);
     }
     set_error("pkv_attn_prefill: unsupported gqa ratio %d (supported 1,2,4,8)", G);
     return PKV_ERR_UNSUPPORTED;
 }
 template <int KT, int VT>
-int launch_d(const PrefillArgs & pa, int D, int G, int n_tiles, int n_seq, hipStream_t st) {
+int launch_d(const PrefillArgs & pa, int D, int G, int n_tiles, int n_seq, int qb, hipStream_t st) {
     switch (D) {
-        case 64:  return launch_g<KT, VT, 64>(pa, G, n_tiles, n_seq, st);
-        case 128: return launch_g<KT, VT, 128>(pa, G, n_tiles, n_seq, st);
+        case 64:  return launch_g<KT, VT, 64>(pa, G, n_tiles, n_seq, qb, st);
+        case 128: return launch_g<KT, VT, 128>(pa, G, n_tiles, n_seq, qb, st);
     }
     set_error("pkv_attn_prefill: unsupported head_dim %d (supported 64,128)", D);
     return PKV_ERR_UNSUPPORTED;
 }
 template <int KT>
-int launch_v(const PrefillArgs & pa, int VT, int D, int G, int n_tiles, int n_seq, hipStream_t st) {
+int launch_v(const PrefillArgs & pa, int VT, int D, int G, int n_tiles, int n_seq, int qb, hipStream_t st) {
     switch (VT) {
-        case PKV_TYPE_F16:  return launch_d<KT, PKV_TYPE_F16>(pa, D, G, n_tiles, n_seq, st);
-        case PKV_TYPE_Q8_0: return launch_d<KT, PKV_TYPE_Q8_0>(pa, D, G, n_tiles, n_seq, st);
-        case PKV_TYPE_Q4_0: return launch_d<KT, PKV_TYPE_Q4_0>(pa, D, G, n_tiles, n_seq, st);
+        case PKV_TYPE_F16:  return launch_d<KT, PKV_TYPE_F16>(pa, D, G, n_tiles, n_seq, qb, st);
+        case PKV_TYPE_Q8_0: return launch_d<KT, PKV_TYPE_Q8_0>(pa, D, G, n_tiles, n_seq, qb, st);
+        case PKV_TYPE_Q4_0: return launch_d<KT, PKV_TYPE_Q4_0>(pa, D, G, n_tiles, n_seq, qb, st);
     }
     return PKV_ERR_UNSUPPORTED;
 }
@@ -802,7 +846,12 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
     pa.causal = (a.flags & PKV_ATTN_NONCAUSAL) ? 0 : 1;
     PKV_REQUIRE(a.max_bias == 0.0f || a.mask, "pkv_attn_prefill: max_bias (ALiBi) needs a mask");
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
-    const int n_tiles = (a.max_q_per_seq + QT - 1) / QT, G = a.n_head / a.n_head_kv;
+    const int G = a.n_head / a.n_head_kv;
+    // 64 queries per wave (one workgroup per CU) when the launch still fills the chip that way: a long prompt, or many sequences
+    int qb = 1;
+    if (G <= 4 && !a.mask && a.logit_softcap == 0.0f && !g_prefill_stamps && (long long) ((a.max_q_per_seq + 2 * QT - 1) / (2 * QT)) * a.n_head_kv * a.n_seq >= 512) qb = 2;
+    if (const char * e = getenv("PKV_PREFILL_QB")) { const int v = atoi(e); if (v == 1 || (v == 2 && G <= 4 && !a.mask && a.logit_softcap == 0.0f && !g_prefill_stamps)) qb = v; }   // experiments
+    const int n_tiles = (a.max_q_per_seq + QT * qb - 1) / (QT * qb);
     // split-KV when the launch would leave most of the 256 CUs (2 workgroups each) idle and the past is long enough to share
     pa.n_split = 1; pa.n_tok_total = a.n_tok; pa.part_o = nullptr; pa.part_ml = nullptr;
     const long long n_wg = (long long) n_tiles * a.n_head_kv * a.n_seq;
@@ -818,13 +867,13 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
         }
     }
 #ifdef PKV_PREFILL_DEV   // development builds: the headline instantiation only (the full set takes minutes to compile)
-    if (a.type_k == PKV_TYPE_F16 && a.type_v == PKV_TYPE_F16 && a.head_dim == 128 && G == 4) return launch_one<PKV_TYPE_F16, PKV_TYPE_F16, 128, 4>(pa, n_tiles, a.n_seq, st);
+    if (a.type_k == PKV_TYPE_F16 && a.type_v == PKV_TYPE_F16 && a.head_dim == 128 && G == 4) return launch_one<PKV_TYPE_F16, PKV_TYPE_F16, 128, 4>(pa, n_tiles, a.n_seq, qb, st);
     set_error("pkv_attn_prefill: development build"); return PKV_ERR_UNSUPPORTED;
 #else
     switch (a.type_k) {
-        case PKV_TYPE_F16:  return launch_v<PKV_TYPE_F16>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);
-        case PKV_TYPE_Q8_0: return launch_v<PKV_TYPE_Q8_0>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);
-        case PKV_TYPE_Q4_0: return launch_v<PKV_TYPE_Q4_0>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, st);
+        case PKV_TYPE_F16:  return launch_v<PKV_TYPE_F16>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, qb, st);
+        case PKV_TYPE_Q8_0: return launch_v<PKV_TYPE_Q8_0>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, qb, st);
+        case PKV_TYPE_Q4_0: return launch_v<PKV_TYPE_Q4_0>(pa, a.type_v, a.head_dim, G, n_tiles, a.n_seq, qb, st);
     }
     return PKV_ERR_UNSUPPORTED;
 #endif
