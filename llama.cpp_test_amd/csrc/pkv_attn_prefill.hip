@@ -331,8 +331,9 @@ struct VStage<PKV_TYPE_F16, D, NT> {
     }
 };
 
-// QB = 32-query blocks per wave.  QB = 2 (G <= 4: one wave per SIMD, the whole 512-entry register file): every K / V^T fragment read from LDS
-// feeds TWO MFMAs, and a staged KV tile, a barrier and a table lookup serve 64 queries per head instead of 32.
+// QB = 32-query blocks per wave.  QB = 2 (one wave per SIMD, the whole 512-entry register file; built with -amdgpu-mfma-vgpr-form, see the
+// Makefile): every K / V^T fragment read from LDS feeds TWO MFMAs, and a staged KV tile, a barrier and a table lookup serve 64 queries per head
+// instead of 32.  Measured slower than QB = 1 at two waves per SIMD (launch_attn_prefill): opt-in experiment.
 template <int KT, int VT, int D, int G, bool SOFTCAP, bool STAMP = false, bool MASKED = false, int QB = 1>
 __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(const int32_t * __restrict__ p_table, const int32_t * __restrict__ p_lens,
                                                                  const int32_t * __restrict__ p_qstart, const PrefillArgs a) {
@@ -761,7 +762,7 @@ int launch_one(const PrefillArgs & pa, int n_tiles, int n_seq, int qb, hipStream
         }
     }
     const dim3 grid(n_tiles * pa.n_split, pa.n_head_kv, n_seq), block(64 * G);
-    if constexpr (G <= 4) {
+    if constexpr (G == 4 && D == 128 && KT == PKV_TYPE_F16 && VT == PKV_TYPE_F16) {   // the one instantiation kept of the 64-queries-per-wave experiment
         if (qb == 2) {   // (launch_attn_prefill asks for it only without mask / soft-cap)
             hipLaunchKernelGGL((attn_prefill_kernel<KT, VT, D, G, false, false, false, 2>), grid, block, 0, st, pa.block_table, pa.seq_lens, pa.q_start, pa);
             if (pa.n_split > 1) hipLaunchKernelGGL((prefill_combine_kernel<D>), dim3(pa.n_head, pa.n_tok_total), dim3(D / 4), 0, st, pa);
@@ -847,10 +848,12 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.max_bias == 0.0f || a.mask, "pkv_attn_prefill: max_bias (ALiBi) needs a mask");
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
     const int G = a.n_head / a.n_head_kv;
-    // 64 queries per wave (one workgroup per CU) when the launch still fills the chip that way: a long prompt, or many sequences
+    // 64 queries per wave (QB = 2: one workgroup per CU, one wave per SIMD) is built, bit-compatible and SLOWER than two 32-query waves per
+    // SIMD (617 vs 644 TFLOP/s at pp4096, 295 vs 334 at 32 x pp512): a single in-order wave per SIMD does not overlap its
+    // softmax arithmetic with its own MFMAs.  Kept as an opt-in experiment for the headline instantiation (PKV_PREFILL_QB=2).
     int qb = 1;
-    if (G <= 4 && !a.mask && a.logit_softcap == 0.0f && !g_prefill_stamps && (long long) ((a.max_q_per_seq + 2 * QT - 1) / (2 * QT)) * a.n_head_kv * a.n_seq >= 512) qb = 2;
-    if (const char * e = getenv("PKV_PREFILL_QB")) { const int v = atoi(e); if (v == 1 || (v == 2 && G <= 4 && !a.mask && a.logit_softcap == 0.0f && !g_prefill_stamps)) qb = v; }   // experiments
+    if (const char * e = getenv("PKV_PREFILL_QB"))
+        if (atoi(e) == 2 && G == 4 && a.head_dim == 128 && a.type_k == PKV_TYPE_F16 && a.type_v == PKV_TYPE_F16 && !a.mask && a.logit_softcap == 0.0f && !g_prefill_stamps) qb = 2;
     const int n_tiles = (a.max_q_per_seq + QT * qb - 1) / (QT * qb);
     // split-KV when the launch would leave most of the 256 CUs (2 workgroups each) idle and the past is long enough to share
     pa.n_split = 1; pa.n_tok_total = a.n_tok; pa.part_o = nullptr; pa.part_ml = nullptr;

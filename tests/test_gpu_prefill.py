@@ -180,3 +180,26 @@ def test_prefill_split_kv_equals_unsplit(pkv, O, tk, nkv, nh):
         got = a[q_start[s]:q_start[s + 1]]                                   # oracle output is [n_q][n_head][D] too
         assert nmse(got, ref) <= 5e-4
         assert np.abs(got - exact).max() <= 1e-3
+
+
+def test_prefill_64_queries_per_wave_variant(pkv, O, monkeypatch):
+    """the opt-in 64-queries-per-wave kernel (PKV_PREFILL_QB=2, DESIGN.md §3: measured, slower, kept as an experiment) computes what the
+    32-query kernel computes: identical bits where both walk the same KV tiles per query, <= 1e-4 on ragged lengths (a 64-query tile
+    reaches the diagonal in a different tile than a 32-query tile does, so the running maximum is updated in a different order)"""
+    rng = np.random.default_rng(64)
+    D, nh, nkv = 128, 32, 8
+    lens = [1, 31, 33, 64, 65, 100, 700, 1000, 512, 512]
+    n_qs = [1, 31, 33, 64, 65, 100, 300, 129, 512, 512]
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=1, type_v=1)
+    q = rng.uniform(-1, 1, (sum(n_qs), nh, D)).astype(np.float32)
+    qs = np.concatenate([[0], np.cumsum(n_qs)]).astype(np.int32)
+    outs = []
+    for qb in ("1", "2"):
+        monkeypatch.setenv("PKV_PREFILL_QB", qb)
+        o = pkv.attn_prefill(dev(q), dev(kp), dev(vp), dev(bt), dev(sl), dev(qs), n_head_kv=nkv, type_k=1, type_v=1, block_size=128,
+                             scale=D ** -0.5, max_seq_len=max(lens), max_q_per_seq=max(n_qs))
+        torch.cuda.synchronize()
+        outs.append(o.cpu().numpy())
+    assert np.isfinite(outs[1]).all()
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-4
+    assert np.array_equal(outs[0][qs[8]:], outs[1][qs[8]:])      # the two whole pp512 prompts: bit for bit
