@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fill the R2_* placeholders of BASELINE.md §5 and the plugin number of DESIGN.md §5 from profiles/r02_* (after probes/r02_summarize.py)."""
+"""Regenerate BASELINE.md §5 (round-2 results table) from probes/r02_baseline_table.tmpl and profiles/r02_* (after probes/r02_summarize.py)."""
 import json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
@@ -29,10 +29,16 @@ rep = {
     "R2_70B_TOKS": toks(c["70b_ctx16384"]), "R2_70B_GBS": gbs(c["70b_ctx16384"]), "R2_70B_PCT": pct(c["70b_ctx16384"]),
     "R2_GEMM": " / ".join(t for _, t in gm), "R2_PREFILL": "%s / %s" % (pfd.get(("32", "512"), "?"), pfd.get(("1", "4096"), "?")),
 }
-for fn in ("BASELINE.md", "DESIGN.md"):
-    t = open(os.path.join(ROOT, fn)).read()
-    for k in sorted(rep, key=len, reverse=True):
-        t = t.replace(k, rep[k])
-    t = t.replace("PLUGIN_8B", "%s" % round(float(plug.group(1))))
-    open(os.path.join(ROOT, fn), "w").write(t)
+rep["R2_CPU_ATTN"] = "%.1f" % b["cpu_baseline"]["value"]
+pa, pb = float(pfd.get(("32", "512"), 0)), float(pfd.get(("1", "4096"), 0))
+rep["R2_PREFILL_PCT"] = "%.0f %% / %.0f %%" % (pa / 25, pb / 25)
+# BASELINE.md section 5 is regenerated from probes/r02_baseline_table.tmpl
+sec = open(os.path.join(ROOT, "probes", "r02_baseline_table.tmpl")).read()
+for k in sorted(rep, key=len, reverse=True):
+    sec = sec.replace(k, rep[k])
+assert "R2_" not in sec, [w for w in sec.split() if "R2_" in w]
+fn = os.path.join(ROOT, "BASELINE.md")
+t = open(fn).read()
+t = t[:t.index("## 5. Results table (round 2")] + sec
+open(fn, "w").write(t)
 print(rep)
