@@ -310,6 +310,10 @@ int32_t pkv_cache_seq_len      (const pkv_cache * c, int32_t seq_id);           
 int32_t pkv_cache_seq_n_blocks (const pkv_cache * c, int32_t seq_id);
 int32_t pkv_cache_seq_blocks   (const pkv_cache * c, int32_t seq_id, int32_t * out, int32_t cap);
 int32_t pkv_cache_seq_is_regular(const pkv_cache * c, int32_t seq_id);            /* pos[i]==i ∀i     */
+/* the per-ubatch device tables in one call (what set_inputs builds per ubatch in the reference, /ref/src/llama-graph.cpp:403-468, instead of the dense
+ * mask): table[n_seq][width] = the sequences' block lists padded with 0, lens[n_seq] = their logical lengths, *all_regular = every sequence has
+ * pos[i] == i.  Returns the longest block list (>= 0) or PKV_ERR_INVALID (a list longer than `width`). */
+int32_t pkv_cache_block_tables(const pkv_cache * c, int32_t n_seq, const int32_t * seq_ids, int32_t width, int32_t * table, int32_t * lens, int32_t * all_regular);
 int32_t pkv_cache_seq_slot_pos (const pkv_cache * c, int32_t seq_id, int32_t * out, int32_t cap);
 int32_t pkv_cache_n_free_blocks(const pkv_cache * c);
 int32_t pkv_cache_block_refcount(const pkv_cache * c, int32_t block);

@@ -378,6 +378,27 @@ int32_t pkv_cache_seq_blocks(const pkv_cache * c, int32_t s, int32_t * out, int3
     return (int32_t) b.size();
 }
 int32_t pkv_cache_seq_is_regular(const pkv_cache * c, int32_t s) { return c ? c->host.seq_is_regular(s) : 1; }
+int32_t pkv_cache_block_tables(const pkv_cache * c, int32_t n_seq, const int32_t * seq_ids, int32_t width, int32_t * table, int32_t * lens, int32_t * all_regular) {
+    if (!c || n_seq < 0 || width <= 0 || !seq_ids || !table || !lens) return PKV_ERR_INVALID;
+    int32_t mb = 0, reg = 1;
+    for (int32_t i = 0; i < n_seq; ++i) {
+        const int32_t s = seq_ids[i];
+        int32_t * row = table + (size_t) i * width;
+        int32_t nb = 0;
+        if (c->host.valid(s)) {
+            const auto & b = c->host.seq_blocks(s);
+            nb = (int32_t) b.size();
+            if (nb > width) { set_error("pkv_cache_block_tables: sequence %d has %d blocks, table width %d", s, nb, width); return PKV_ERR_INVALID; }
+            for (int32_t j = 0; j < nb; ++j) row[j] = b[j];
+        }
+        for (int32_t j = nb; j < width; ++j) row[j] = 0;
+        lens[i] = c->host.seq_len(s);
+        reg &= c->host.seq_is_regular(s) ? 1 : 0;
+        if (nb > mb) mb = nb;
+    }
+    if (all_regular) *all_regular = reg;
+    return mb;
+}
 int32_t pkv_cache_seq_slot_pos(const pkv_cache * c, int32_t s, int32_t * out, int32_t cap) {
     if (!c || !c->host.valid(s)) return 0;
     const auto & p = c->host.seq_slot_pos(s);

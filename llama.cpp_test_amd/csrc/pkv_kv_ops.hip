@@ -5,6 +5,7 @@
 // NORM mode (/ref/ggml/src/ggml-cpu/ggml-cpu.c:10807-10821).  Quantization block reductions (32 elements = 16
 // lanes = one DPP row) use DPP only.
 #include "pkv_common.h"
+#include <cstdlib>
 
 // every kernel of this file must round a given expression the same way (bit-exact parity between the fused and
 // the separate launches): no implicit FMA contraction
@@ -209,8 +210,80 @@ int launch_rope_f16(const void * x, const int32_t * pos, void * out, int n_tok, 
     return PKV_OK;
 }
 
+// The same work for a prefill ubatch: ONE workgroup per token (4 waves), every wave walking rows q heads | k heads | v heads with
+// stride 4.  kv_store_kernel spends a one-wave workgroup and a libm-exact (cos, sin) evaluation on every 512-byte row: a 2048-token
+// ubatch of the 8B geometry is 98,304 rows — 101 us per layer, four times the prefill attention kernel behind it.  A token's angles
+// do not depend on the head: here each wave evaluates them once and rotates its 10 roped rows with them (same rope_cs, same rot0 /
+// rot1: the stored bits are those of kv_store_kernel), and its rows' loads are issued four ahead.
+template <int D>
+__device__ __forceinline__ float2 rope_apply(float2 x, int lane, float2 c0, float2 c1, const RopeDev & r) {
+    const int l = lane % (D / 2);
+    if ((r.mode & 2) == 0) return 2 * l < r.n_dims ? make_float2(rot0(x.x, x.y, c0.x, c0.y), rot1(x.x, x.y, c0.x, c0.y)) : x;
+    constexpr int HL = D / 4;
+    const float px = __shfl_xor(x.x, HL), py = __shfl_xor(x.y, HL);
+    return l < HL ? make_float2(rot0(x.x, px, c0.x, c0.y), rot0(x.y, py, c1.x, c1.y))
+                  : make_float2(rot1(px, x.x, c0.x, c0.y), rot1(py, x.y, c1.x, c1.y));
+}
+template <int KT, int VT, int D>
+__global__ void __launch_bounds__(256) kv_store_tok_kernel(const StoreArgs a) {
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = a.q ? a.n_head_q : 0, nk = a.k_cur ? a.n_head_kv : 0, nv = a.v_cur ? a.n_head_kv : 0;
+    const int blk = a.slot_block[t], off = a.slot_off[t];
+    float2 c0 = make_float2(1.0f, 0.0f), c1 = c0;
+    if (a.has_rope) {
+        const int pos = a.pos[t], e0 = 2 * (lane % (D / 2));
+        if ((a.rope.mode & 2) == 0) {
+            if (e0 < a.rope.n_dims) c0 = rope_cs(pos, e0 / 2, a.rope, 1.0f);
+        } else {
+            const int ic = (lane % (D / 2)) < D / 4 ? e0 : e0 - D / 2;
+            c0 = rope_cs(pos, ic, a.rope, 1.0f);
+            c1 = rope_cs(pos, ic + 1, a.rope, 1.0f);
+        }
+    }
+    const bool act = 2 * lane < D;                     // D = 64: the upper half-wave idles
+    const int n_rows = nq + nk + nv;
+    auto src_of = [&](int row) -> const float * {
+        if (row < nq)      return a.q + ((size_t) t * a.n_head_q + row) * D;
+        if (row < nq + nk) return a.k_cur + ((size_t) t * a.n_head_kv + (row - nq)) * D;
+        return a.v_cur + ((size_t) t * a.n_head_kv + (row - nq - nk)) * D;
+    };
+    for (int r0 = wave; r0 < n_rows; r0 += 16) {
+        float2 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + 4 * j;
+            x[j] = make_float2(0.0f, 0.0f);
+            if (row < n_rows && act) x[j] = *reinterpret_cast<const float2 *>(src_of(row) + 2 * lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + 4 * j;
+            if (row >= n_rows) break;                  // wave-uniform
+            if (row < nq) {
+                const float2 y = a.has_rope ? rope_apply<D>(x[j], lane, c0, c1, a.rope) : x[j];
+                if (act) *reinterpret_cast<float2 *>(a.q + ((size_t) t * a.n_head_q + row) * D + 2 * lane) = y;
+            } else if (blk >= 0) {
+                if (row < nq + nk) {
+                    const int h = row - nq;
+                    const float2 y = a.has_rope ? rope_apply<D>(x[j], lane, c0, c1, a.rope) : x[j];
+                    tile_write<KT, false>(a.k_pool + ((size_t) blk * a.n_head_kv + h) * tile_bytes(KT, a.block_size, D), off, lane, quantize<KT>(y, lane), a.block_size, D);
+                } else {
+                    const int h = row - nq - nk;
+                    tile_write<VT, true>(a.v_pool + ((size_t) blk * a.n_head_kv + h) * tile_bytes(VT, a.block_size, D), off, lane, quantize<VT>(x[j], lane), a.block_size, D);
+                }
+            }
+        }
+    }
+}
 template <int KT, int VT>
 static int store_d(const StoreArgs & a, int n_tok, int D, hipStream_t st) {
+    if (n_tok >= 64 && !getenv("PKV_KV_STORE_ROWS")) {   // a prefill ubatch: one workgroup per token (kv_store_tok_kernel)
+        if (D == 128)      hipLaunchKernelGGL((kv_store_tok_kernel<KT, VT, 128>), dim3(n_tok), dim3(256), 0, st, a);
+        else if (D == 64)  hipLaunchKernelGGL((kv_store_tok_kernel<KT, VT, 64>), dim3(n_tok), dim3(256), 0, st, a);
+        else { set_error("pkv_kv_store: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+        PKV_HIP(hipGetLastError());
+        return PKV_OK;
+    }
     dim3 grid(a.q ? (a.n_head_q > a.n_head_kv ? a.n_head_q : a.n_head_kv) : a.n_head_kv, n_tok, a.q ? 3 : 2);
     if (D == 128)      hipLaunchKernelGGL((kv_store_kernel<KT, VT, 128>), grid, dim3(64), 0, st, a);
     else if (D == 64)  hipLaunchKernelGGL((kv_store_kernel<KT, VT, 64>), grid, dim3(64), 0, st, a);

@@ -69,7 +69,7 @@ class AttnPathRunner:
     def seq_cp(self, src, dst, p0, p1):
         self.cache.seq_cp(src, dst, p0, p1)
 
-    def plan(self, seq_id: Sequence[int], pos: Sequence[int]):
+    def plan(self, seq_id: Sequence[int], pos: Sequence[int], *, with_rope_cache: bool = True):
         """host half of one ubatch: slot placement + the small device tables.  Tokens of one sequence must be adjacent
         (llama_sbatch simple split keeps batch order; batched-bench and llama-bench batches satisfy this)."""
         torch = self.torch
@@ -81,14 +81,14 @@ class AttnPathRunner:
         blk, off = self.cache.find_slot(sid, p)                     # raises PkvError(ERR_NO_SPACE) like a failed find_slot
         self.cache.update(self.rope)                               # copy-on-write copies queued by find_slot
         # runs of equal seq_id -> sequences of this ubatch
-        starts = [0] + [i for i in range(1, n_tok) if sid[i] != sid[i - 1]] + [n_tok]
+        starts = [0] + (np.flatnonzero(sid[1:] != sid[:-1]) + 1).tolist() + [n_tok]
         seqs = [int(sid[s]) for s in starts[:-1]]
         assert len(set(seqs)) == len(seqs), "tokens of one sequence must be adjacent in the ubatch"
         n_q = np.diff(starts)
-        for s in seqs:
-            if not self.cache.seq_is_regular(s):
-                raise PkvError(-5, "irregular sequence (holes / shifted cells): call defrag() + update() first")
-        bt, sl = self.cache.block_table(seqs)
+        bt, sl, mb, regular = self.cache.block_tables(seqs, -(-self.max_seq_len // self.BS))
+        if not regular:
+            raise PkvError(-5, "irregular sequence (holes / shifted cells): call defrag() + update() first")
+        bt = bt[:, :max(1, mb)]
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         all_decode = bool((n_q == 1).all())
         dpos = dev(p)
@@ -96,7 +96,7 @@ class AttnPathRunner:
                     max_seq_len=int(sl.max()), slot_block=dev(blk), slot_off=dev(off), pos=dpos, block_table=dev(bt),
                     seq_lens=dev(sl), q_start=dev(np.asarray(starts, np.int32)),
                     # ggml_rope_cache_init once per ubatch, shared by every layer's fused decode step
-                    rope_cache=rope_cache(dpos, self.rope, self.D) if all_decode else None)
+                    rope_cache=rope_cache(dpos, self.rope, self.D) if (all_decode and with_rope_cache) else None)
 
     def layer(self, il: int, plan, q, k_cur, v_cur, out=None):
         """device half, one layer: q f32 [n_tok][n_head][D], k_cur/v_cur f32 [n_tok][n_head_kv][D], all un-rotated.
@@ -116,6 +116,61 @@ class AttnPathRunner:
         """one ubatch through all layers; q/k_cur/v_cur: per-layer device tensors"""
         plan = self.plan(seq_id, pos)
         return [self.layer(il, plan, q[il], k_cur[il], v_cur[il], None if out is None else out[il]) for il in range(self.L)]
+
+    # ---- the same ubatch with the device half replayed from a hipGraph ---------------------------------------------------------
+    # An eager ubatch is 2 launches per layer through ctypes (~80 us of host time per layer, as much as the kernels of a 2048-token
+    # ubatch take).  The launches of a ubatch depend on its SHAPE only (token count, sequence count, longest query run, decode or
+    # prefill, the block-rounded longest sequence): its tables live in persistent device buffers that plan() refreshes, and the
+    # per-layer launches are captured once per shape and caller-tensor set, then replayed (what the reference's CUDA backend does
+    # for decode graphs, /root/reference/ggml/src/ggml-cuda/ggml-cuda.cu "cuda graphs").
+    def _persistent(self):
+        if getattr(self, "_pt", None) is None:
+            torch = self.torch
+            nt, ns = self.max_batch_tokens, self.cache.n_seq_max
+            i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device="cuda")  # noqa: E731
+            self._pt = dict(slot_block=i32(nt), slot_off=i32(nt), pos=i32(nt), block_table=i32(ns, -(-self.max_seq_len // self.BS)),
+                            seq_lens=i32(ns), q_start=i32(ns + 1), rope_cache=torch.zeros((nt, self.D // 2, 2), dtype=torch.float32, device="cuda"))
+            self._graphs = {}
+            self._stream = torch.cuda.Stream()
+        return self._pt
+
+    def decode_captured(self, seq_id, pos, q: List, k_cur: List, v_cur: List, out: List):
+        """decode() with out given, through a cached hipGraph.  Results and cache contents are those of decode() (same kernels, same
+        arguments; max_seq_len is passed rounded up to whole blocks so that a growing sequence keeps its graph for a block)."""
+        torch = self.torch
+        plan = self.plan(seq_id, pos, with_rope_cache=False)
+        pt = self._persistent()
+        n_tok, n_seq = plan["n_tok"], plan["n_seq"]
+        for k in ("slot_block", "slot_off", "pos"):
+            pt[k][:n_tok].copy_(plan[k], non_blocking=True)
+        bt = plan["block_table"]
+        pt["block_table"][:n_seq, :bt.shape[1]].copy_(bt, non_blocking=True)
+        pt["seq_lens"][:n_seq].copy_(plan["seq_lens"], non_blocking=True)
+        pt["q_start"][:n_seq + 1].copy_(plan["q_start"], non_blocking=True)
+        msl = -(-plan["max_seq_len"] // self.BS) * self.BS
+        gplan = dict(plan, slot_block=pt["slot_block"][:n_tok], slot_off=pt["slot_off"][:n_tok], pos=pt["pos"][:n_tok],
+                     block_table=pt["block_table"][:n_seq], seq_lens=pt["seq_lens"][:n_seq], q_start=pt["q_start"][:n_seq + 1],
+                     max_seq_len=msl, rope_cache=pt["rope_cache"][:n_tok] if plan["all_decode"] else None)
+        key = (n_tok, n_seq, plan["max_q"], plan["all_decode"], msl) + tuple(x.data_ptr() for lst in (q, k_cur, v_cur, out) for x in lst)
+
+        def launches():
+            if plan["all_decode"]:
+                rope_cache(gplan["pos"], self.rope, self.D, out=gplan["rope_cache"])
+            for il in range(self.L):
+                self.layer(il, gplan, q[il], k_cur[il], v_cur[il], out[il])
+
+        g = self._graphs.get(key)
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self._stream):
+                    launches()
+                self._graphs[key] = g
+            g.replay()
+        cur.wait_stream(self._stream)
+        return out
 
     def close(self):
         self.cache.close()

@@ -255,3 +255,21 @@ def test_evict_when_full_shared_tail_and_shift(pkv):
     c.seq_add(0, 0, -1, 3)                                   # pool is full: no eviction, table shapes unchanged
     assert (c.seq_blocks(0).tolist(), c.seq_blocks(1).tolist()) == before or c.n_free_blocks() >= 0
     assert all(0 <= b < 3 for b in c.seq_blocks(0).tolist())
+
+
+def test_block_tables_in_one_call(pkv):
+    """pkv_cache_block_tables (the per-ubatch tables in one library call) == the per-sequence queries, incl. the regularity flag and the width check"""
+    c = pkv.PagedKVCache(n_blocks=12, block_size=4, n_seq_max=4)
+    c.find_slot(np.array([0] * 9 + [1] * 3 + [2] * 5, np.int32), np.array(list(range(9)) + list(range(3)) + list(range(5)), np.int32))
+    bt, sl, mb, reg = c.block_tables([2, 0, 1, 3], 5)
+    assert mb == 3 and reg and sl.tolist() == [5, 9, 3, 0]
+    for i, s in enumerate([2, 0, 1, 3]):
+        b = c.seq_blocks(s)
+        assert bt[i, :len(b)].tolist() == b.tolist() and not bt[i, len(b):].any()
+    ref_bt, ref_sl = c.block_table([2, 0, 1, 3], max_blocks=5)
+    assert np.array_equal(bt, ref_bt) and np.array_equal(sl, ref_sl)
+    c.seq_rm(0, 2, 4)                                   # a hole: sequence 0 is no longer pos[i] == i
+    assert c.block_tables([0, 1], 5)[3] is False and c.block_tables([1, 2], 5)[3] is True
+    with pytest.raises(pkv.PkvError):
+        c.block_tables([0], 2)                          # three blocks do not fit a table of width 2
+    c.close()

@@ -111,3 +111,43 @@ def test_tinyllama_tg128_from_empty_cache(pkv, O):
                 assert np.abs(got - ref).max() <= 2.5e-3 and nmse(got, ref) <= 5e-4, (t, il)
     assert r.cache.seq_len(0) == 131 and len(r.cache.seq_blocks(0)) == 2
     r.close()
+
+
+@pytest.mark.parametrize("tk", [1, 8])
+def test_captured_ubatches_equal_eager_ubatches(pkv, tk):
+    """AttnPathRunner.decode_captured (tables in persistent device buffers, the per-layer launches replayed from a hipGraph cached per ubatch
+    shape) leaves the same outputs and the same cache bits as decode(): ragged prefill, decode steps that cross a block boundary (the graph
+    is keyed on the block-rounded longest sequence), a sequence leaving and another joining in its blocks"""
+    import _load_pkg
+    _load_pkg.load()
+    from llama_cpp_test_amd.runner import AttnPathRunner
+    L, H, HK, D = 3, 8, 2, 128
+    mk = lambda: AttnPathRunner(n_layer=L, n_head=H, n_head_kv=HK, head_dim=D, type_k=tk, type_v=tk, n_blocks=16, n_seq_max=4, max_batch_tokens=512)  # noqa: E731
+    ra, rb = mk(), mk()
+    gen = torch.Generator(device="cuda").manual_seed(7 + tk)
+    nmax = 512
+    bufs = {n: [torch.empty((nmax, h, D), device="cuda") for _ in range(L)] for n, h in (("q", H), ("k", HK), ("v", HK), ("o", H))}
+
+    def step(seq_ids, poss):
+        n = len(seq_ids)
+        for name in ("q", "k", "v"):
+            for x in bufs[name]:
+                x[:n] = torch.rand(x[:n].shape, generator=gen, device="cuda") * 2 - 1
+        qa = [x[:n].clone() for x in bufs["q"]]                      # prefill ubatches rotate q in place: each runner gets its own copy
+        ea = ra.decode(seq_ids, poss, qa, [x[:n] for x in bufs["k"]], [x[:n] for x in bufs["v"]])
+        qb = [x[:n] for x in bufs["q"]]
+        eb = rb.decode_captured(seq_ids, poss, qb, [x[:n] for x in bufs["k"]], [x[:n] for x in bufs["v"]], [x[:n] for x in bufs["o"]])
+        torch.cuda.synchronize()
+        for il in range(L):
+            assert torch.equal(ea[il], eb[il]), (il, n)
+
+    lens = {0: 120, 1: 130, 2: 64}
+    step(sum(([s] * n for s, n in lens.items()), []), sum((list(range(n)) for n in lens.values()), []))
+    for i in range(12):                                              # sequence 0 crosses from block 1 into block 2 at position 128
+        step([0, 1, 2], [lens[0] + i, lens[1] + i, lens[2] + i])
+    ra.seq_rm(1, -1, -1); rb.seq_rm(1, -1, -1)
+    step([3] * 100, list(range(100)))                                # a new sequence in the freed blocks (new shape: new graph)
+    for i in range(3):
+        step([0, 2, 3], [lens[0] + 12 + i, lens[2] + 12 + i, 100 + i])
+    assert len(rb._graphs) >= 3                                      # (equal outputs of the later steps = equal cache contents)
+    ra.close(); rb.close()
