@@ -11,7 +11,7 @@ from llama_cpp_test_amd.runner import AttnPathRunner
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--npl", type=int, default=32); ap.add_argument("--npp", type=int, default=512); ap.add_argument("--ntg", type=int, default=128)
-ap.add_argument("--n-batch", type=int, default=2048); ap.add_argument("--kv-type", default="f16"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--eager", action="store_true", help="per-layer launches from Python instead of the cached hipGraph per ubatch shape")
+ap.add_argument("--n-batch", type=int, default=2048); ap.add_argument("--kv-type", default="f16"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--graph", action="store_true", help="AttnPathRunner.decode_captured: one cached hipGraph per ubatch shape instead of per-layer launches (measured: no faster, the GPU is the bound)")
 a = ap.parse_args()
 L, H, HK, D, BS = 32, 32, 8, 128, 128
 t = pkv.TYPE_BY_NAME[a.kv_type]
@@ -27,7 +27,7 @@ out = [torch.empty((nmax, H, D), device="cuda") for _ in range(L)]
 
 def run(seq_ids, poss):
     n = len(seq_ids)
-    if not a.eager:
+    if a.graph:
         r.decode_captured(seq_ids, poss, [x[:n] for x in q], [x[:n] for x in k], [x[:n] for x in v], [x[:n] for x in out])
         return
     plan = r.plan(seq_ids, poss)
@@ -50,4 +50,4 @@ for rep in range(a.reps + 1):
         res.append((t1 - t0, t2 - t1))
 tpp, ttg = np.median([x[0] for x in res]), np.median([x[1] for x in res])
 print(f"{a.kv_type} B={a.npl} PP={a.npp} TG={a.ntg} n_batch={a.n_batch}: T_PP {tpp*1e3:.1f} ms  S_PP {a.npl*a.npp/tpp:.0f} t/s | "
-      f"T_TG {ttg*1e3:.1f} ms  S_TG {a.npl*a.ntg/ttg:.0f} t/s  ({ttg/a.ntg*1e3:.3f} ms/step, {'eager launches' if a.eager else 'one cached hipGraph per ubatch shape'}, host block manager in the loop)")
+      f"T_TG {ttg*1e3:.1f} ms  S_TG {a.npl*a.ntg/ttg:.0f} t/s  ({ttg/a.ntg*1e3:.3f} ms/step, {'one cached hipGraph per ubatch shape' if a.graph else 'eager launches'}, host block manager in the loop)")
