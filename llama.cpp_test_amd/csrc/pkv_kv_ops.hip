@@ -493,8 +493,70 @@ __global__ void __launch_bounds__(64) qkv_store_mirror_kernel(const QkvStoreArgs
         tile_write<VT, true>(a.v_pool + ((size_t) (cell / a.BS) * a.n_head_kv + h) * tile_bytes(VT, a.BS, D), (int) (cell % a.BS), lane, q, a.BS, D);
     }
 }
+// the prompt-processing form (one workgroup per token, the token's angles evaluated once per wave: see kv_store_tok_kernel)
+template <int KT, int VT, int D>
+__global__ void __launch_bounds__(256) qkv_store_mirror_tok_kernel(const QkvStoreArgs a) {
+    const int64_t t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = a.n_head_q, nk = a.n_head_kv, n_rows = nq + 2 * nk;
+    float2 c0, c1;
+    {
+        const int pos = a.pos[t], l = lane % (D / 2), e0 = 2 * l;
+        c0 = c1 = make_float2(1.0f, 0.0f);
+        if ((a.rope.mode & 2) == 0) {
+            if (e0 < a.rope.n_dims) c0 = rope_cs(pos, e0 / 2, a.rope, 1.0f);
+        } else {
+            const int ic = l < D / 4 ? e0 : e0 - D / 2;
+            c0 = rope_cs(pos, ic, a.rope, 1.0f);
+            c1 = rope_cs(pos, ic + 1, a.rope, 1.0f);
+        }
+    }
+    const bool act = 2 * lane < D;
+    auto src_of = [&](int row) -> const float * {
+        if (row < nq)      return a.q + t * a.q_s_tok + (int64_t) row * a.q_s_head;
+        if (row < nq + nk) return a.k + t * a.k_s_tok + (int64_t) (row - nq) * a.k_s_head;
+        return a.v + (t * a.n_head_kv + (row - nq - nk)) * D;
+    };
+    for (int r0 = wave; r0 < n_rows; r0 += 16) {
+        float2 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + 4 * j;
+            x[j] = make_float2(0.0f, 0.0f);
+            if (row < n_rows && act) x[j] = *reinterpret_cast<const float2 *>(src_of(row) + 2 * lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + 4 * j;
+            if (row >= n_rows) break;                  // wave-uniform
+            if (row < nq) {
+                const float2 y = rope_apply<D>(x[j], lane, c0, c1, a.rope);
+                if (act) *reinterpret_cast<float2 *>(a.q_out + (t * a.n_head_q + row) * D + 2 * lane) = y;
+            } else if (row < nq + nk) {
+                const int h = row - nq;
+                const Q2 q = quantize<KT>(rope_apply<D>(x[j], lane, c0, c1, a.rope), lane);
+                if (a.k_dst) ref_write<KT>(a.k_dst + (t * a.n_head_kv + h) * (int64_t) row_size(KT, D), lane, q, D);
+                const int64_t cell = a.k_cell0 + t;
+                tile_write<KT, false>(a.k_pool + ((size_t) (cell / a.BS) * a.n_head_kv + h) * tile_bytes(KT, a.BS, D), (int) (cell % a.BS), lane, q, a.BS, D);
+            } else {
+                const int h = row - nq - nk;
+                const Q2 q = quantize<VT>(x[j], lane);
+                if (a.v_dst) ref_write<VT>(a.v_dst + (t * a.n_head_kv + h) * (int64_t) row_size(VT, D), lane, q, D);
+                const int64_t cell = a.v_cell0 + t;
+                tile_write<VT, true>(a.v_pool + ((size_t) (cell / a.BS) * a.n_head_kv + h) * tile_bytes(VT, a.BS, D), (int) (cell % a.BS), lane, q, a.BS, D);
+            }
+        }
+    }
+}
 template <int KT, int VT>
 static int qkv_store_d(const QkvStoreArgs & a, int n_tok, int D, hipStream_t st) {
+    if (n_tok >= 64 && !getenv("PKV_KV_STORE_ROWS")) {
+        if (D == 128)     hipLaunchKernelGGL((qkv_store_mirror_tok_kernel<KT, VT, 128>), dim3(n_tok), dim3(256), 0, st, a);
+        else if (D == 64) hipLaunchKernelGGL((qkv_store_mirror_tok_kernel<KT, VT, 64>), dim3(n_tok), dim3(256), 0, st, a);
+        else { set_error("qkv store: unsupported head_dim %d", D); return PKV_ERR_UNSUPPORTED; }
+        PKV_HIP(hipGetLastError());
+        return PKV_OK;
+    }
     const dim3 grid(a.n_head_q > a.n_head_kv ? a.n_head_q : a.n_head_kv, n_tok, 3);
     if (D == 128)     hipLaunchKernelGGL((qkv_store_mirror_kernel<KT, VT, 128>), grid, dim3(64), 0, st, a);
     else if (D == 64) hipLaunchKernelGGL((qkv_store_mirror_kernel<KT, VT, 64>), grid, dim3(64), 0, st, a);
