@@ -9,7 +9,7 @@ def gbs(v): return "%s" % format(round(v["roofline"]["achieved"]), ",")
 def pct(v): return "%.1f" % (100 * v["roofline"]["frac"])
 def toks(v): return format(round(v["value"]), ",")
 plug = re.search(r"([\d.]+) tok/s \(([\d.]+) ms/token\)", open(os.path.join(P, "r02_e2e_8b_q4k_plugin.txt")).read())
-tiny = re.findall(r"MI355X, TinyLlama.*?: ([\d.]+) tok/s", open(os.path.join(P, "r02_tinyllama_e2e_plugin.txt")).read())
+tiny = re.findall(r"MI355X, TinyLlama.*?tg128: ([\d.]+) tok/s", open(os.path.join(P, "r02_tinyllama_e2e_plugin.txt")).read())
 bb = re.search(r"S_PP (\d+) t/s \| T_TG [\d.]+ ms  S_TG (\d+) t/s", open(os.path.join(P, "r02_batched_bench.txt")).read())
 gm = re.findall(r"q4_K  M  14336 K   4096 N +(\d+): +[\d.]+ us +([\d.]+) TFLOP/s", open(os.path.join(P, "r02_gemm_bench.txt")).read())
 pf = re.findall(r"f16 n_seq +(\d+) n_q +(\d+) past +0: +[\d.]+ us +([\d.]+) TFLOP/s", open(os.path.join(P, "r02_bench_prefill.txt")).read())
@@ -29,6 +29,10 @@ rep = {
     "R2_70B_TOKS": toks(c["70b_ctx16384"]), "R2_70B_GBS": gbs(c["70b_ctx16384"]), "R2_70B_PCT": pct(c["70b_ctx16384"]),
     "R2_GEMM": " / ".join(t for _, t in gm), "R2_PREFILL": "%s / %s" % (pfd.get(("32", "512"), "?"), pfd.get(("1", "4096"), "?")),
 }
+tl = open(os.path.join(P, "r02_tinyllama_e2e_plugin.txt")).read()
+rep["R2_TINY_PP"] = format(int(re.findall(r"MI355X, TinyLlama.*?pp512: (\d+) tok/s", tl)[-1]), ",")
+rep["R2_TINY_CPUPP"] = re.findall(r"CPU backend.*?pp512: (\d+) tok/s", tl)[-1]
+rep["R2_TINY_CPU"] = "%.0f" % float(re.findall(r"CPU backend.*?tg128: ([\d.]+) tok/s", tl)[-1])
 rep["R2_CPU_ATTN"] = "%.1f" % b["cpu_baseline"]["value"]
 pa, pb = float(pfd.get(("32", "512"), 0)), float(pfd.get(("1", "4096"), 0))
 rep["R2_PREFILL_PCT"] = "%.0f %% / %.0f %%" % (pa / 25, pb / 25)

@@ -46,11 +46,35 @@ def tg128(label):
     return logits
 
 
+def pp512(label, reps):
+    """llama-bench's pp512: ONE llama_decode of a 512-token prompt (n_batch = n_ubatch = 512) into an empty cache, median of `reps`"""
+    h = C.c_void_p(L.refmodel_load(path.encode(), 512, 512, 1, 1, 1, 1, nth))
+    assert h
+    L.refmodel_detach_capture(h)
+    tok = (np.arange(512, dtype=np.int64) * 7 % 32000).astype(np.int32); pos = np.arange(512, dtype=np.int32); sid = np.zeros(512, np.int32)
+    ts = []
+    for r in range(reps + 1):
+        L.refmodel_seq_rm(h, 0, -1, -1)
+        t0 = time.time()
+        assert L.refmodel_decode(h, tok.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), sid.ctypes.data_as(C.c_void_p), 512) == 0
+        logits = np.empty(32000, np.float32)
+        L.refmodel_logits(h, logits.ctypes.data_as(C.c_void_p), 32000)      # synchronises
+        if r:
+            ts.append(time.time() - t0)
+    dt = float(np.median(ts))
+    print(f"{label}, TinyLlama-1.1B geometry Q8_0, pp512: {512 / dt:.0f} tok/s ({dt * 1e3:.1f} ms)", flush=True)
+    L.refmodel_free(h)
+    return logits
+
+
 cpu = tg128(f"reference CPU backend, {nth} threads")
+cpu_pp = pp512(f"reference CPU backend, {nth} threads", 2)
 if plugin:
     R.load_backend(os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so"))
     R.set_gpu_layers(99)
     gpu = tg128("reference runtime + libggml-mi355.so, all layers on the MI355X")
     err = float(((gpu - cpu) ** 2).sum() / (cpu ** 2).sum())
     print(f"last-token logits, plugin vs CPU: NMSE {err:.2e}")
+    gpu_pp = pp512("reference runtime + libggml-mi355.so, all layers on the MI355X", 5)
+    print(f"last-token logits of the prompt, plugin vs CPU: NMSE {float(((gpu_pp - cpu_pp) ** 2).sum() / (cpu_pp ** 2).sum()):.2e}")
 os.remove(path)
