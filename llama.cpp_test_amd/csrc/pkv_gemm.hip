@@ -7,7 +7,8 @@
 // dequantized to f16 on its way into LDS, and multiplied by v_mfma_f32_32x32x16_f16 with f32 accumulation (the activations are rounded to f16: the
 // reference's CPU backend rounds them to q8_K / q8_0 integers or f16 — both are ~1e-3 relative per element; the harness bar NMSE 5e-4 holds).
 //
-//   workgroup = 128 (m) x 128 (n) outputs, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers);
+//   workgroup = 128 (m) x 128 (n) outputs, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers); 64 x 128 and 64 x 64 tiles
+//   where the launch would otherwise leave CUs without a second workgroup (launch_gemm);
 //   K in steps of 64: thread t stages row t >> 1, 32-element half t & 1 of BOTH operands — one q4_K / q6_K sub-block (or q8_0 block, or 32 halfs)
 //   of W, 32 floats of x — raw loads issued one step ahead of the conversion (issue early / write late), two barriers per step;
 //   LDS rows of 64 f16 padded to 144 B: the 16-byte fragment reads (lane = row r, k = 8 h + ..) are conflict-free;
@@ -21,7 +22,7 @@ namespace {
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BN = 128, BK = 64, LDR = BK + 8;   // LDS row = 72 halfs = 144 B; BM (weight rows per workgroup) = 128, or 64 when 128 would leave CUs idle
+constexpr int BK = 64, LDR = BK + 8;   // LDS row = 72 halfs = 144 B; tile = BM weight rows x BN columns: 128 x 128, or 64 x 128 / 64 x 64 where that would leave CUs idle
 
 __device__ __forceinline__ float hf(uint16_t b) { return (float) *reinterpret_cast<const _Float16 *>(&b); }
 __device__ __forceinline__ uint4 ldu(const unsigned char * p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -82,21 +83,23 @@ template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 2
 
 struct GemmArgs { const unsigned char * w; const float * x; float * y; int64_t M, N, K, row_bytes; };
 
-template <int T, int BM>
+template <int T, int BM, int BN>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
-    constexpr int WM = BM / 64, WN = 4 / WM, TN = BN / WN / 32;      // waves along m / n, MFMA tiles along n per wave (2 along m always)
+    // waves along m / n and MFMA tiles per wave along m / n: 128 x 128: 2 x 2 waves of 2 x 2 tiles; 64 x 128: 1 x 4 of 2 x 1; 64 x 64: 2 x 2 of 1 x 1
+    constexpr int WM = BN == 64 ? 2 : BM / 64, WN = 4 / WM, TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1 && WM * WN == 4, "tile shape");
     __shared__ __attribute__((aligned(16))) _Float16 sA[BM * LDR], sB[BN * LDR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave % WM, wn = wave / WM;
     const int r = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
     // staging role: row srow, 32-element half shalf of both tiles (rows past the end re-read the last row; their outputs are never stored)
     const int srow = tid >> 1, shalf = tid & 1;
-    const bool stage_a = srow < BM;
+    const bool stage_a = srow < BM, stage_b = srow < BN;
     const unsigned char * wrow = a.w + (size_t) min(m0 + (stage_a ? srow : 0), a.M - 1) * a.row_bytes;
-    const float * xrow = a.x + (size_t) min(n0 + srow, a.N - 1) * a.K;
-    floatx16 acc[2][TN];
+    const float * xrow = a.x + (size_t) min(n0 + (stage_b ? srow : 0), a.N - 1) * a.K;
+    floatx16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -106,8 +109,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     float4 rx[8];
     auto load_raw = [&](int64_t k0) {
         if (stage_a) rw.load(wrow, k0 + 32 * shalf);
+        if (stage_b) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rx[i] = reinterpret_cast<const float4 *>(xrow + k0 + 32 * shalf)[i];
+            for (int i = 0; i < 8; ++i) rx[i] = reinterpret_cast<const float4 *>(xrow + k0 + 32 * shalf)[i];
+        }
     };
     load_raw(0);
     for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
@@ -119,24 +124,26 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) da[i] = reinterpret_cast<const uint4 *>(tmp)[i];
             }
-            __attribute__((aligned(16))) _Float16 tb[32];
+            if (stage_b) {
+                __attribute__((aligned(16))) _Float16 tb[32];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { tb[4 * i] = (_Float16) rx[i].x; tb[4 * i + 1] = (_Float16) rx[i].y; tb[4 * i + 2] = (_Float16) rx[i].z; tb[4 * i + 3] = (_Float16) rx[i].w; }
-            uint4 * db = reinterpret_cast<uint4 *>(sB + srow * LDR + 32 * shalf);
+                for (int i = 0; i < 8; ++i) { tb[4 * i] = (_Float16) rx[i].x; tb[4 * i + 1] = (_Float16) rx[i].y; tb[4 * i + 2] = (_Float16) rx[i].z; tb[4 * i + 3] = (_Float16) rx[i].w; }
+                uint4 * db = reinterpret_cast<uint4 *>(sB + srow * LDR + 32 * shalf);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) db[i] = reinterpret_cast<const uint4 *>(tb)[i];
+                for (int i = 0; i < 4; ++i) db[i] = reinterpret_cast<const uint4 *>(tb)[i];
+            }
         }
         __syncthreads();
         if (k0 + BK < a.K) load_raw(k0 + BK);            // the next step's raw bytes fly under this step's MFMAs
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            half8_t af[2], bf[TN];
+            half8_t af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8_t *>(sA + (wm * 64 + i * 32 + r) * LDR + 16 * ks + 8 * h);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t *>(sA + (wm * 32 * TM + i * 32 + r) * LDR + 16 * ks + 8 * h);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8_t *>(sB + (wn * 32 * TN + j * 32 + r) * LDR + 16 * ks + 8 * h);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
@@ -148,10 +155,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
         const int64_t n = n0 + wn * 32 * TN + j * 32 + r;
         if (n >= a.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int64_t m = m0 + wm * 64 + i * 32 + 8 * g + 4 * h;
+                const int64_t m = m0 + wm * 32 * TM + i * 32 + 8 * g + 4 * h;
                 if ((a.M & 3) == 0 && m + 3 < a.M) *reinterpret_cast<float4 *>(a.y + (size_t) n * a.M + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                 else
                     for (int e = 0; e < 4; ++e) if (m + e < a.M) a.y[(size_t) n * a.M + m + e] = acc[i][j][4 * g + e];
@@ -171,12 +178,18 @@ int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t 
     if (!gemm_supported(type_w, M, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
     PKV_REQUIRE(((uintptr_t) x % 16) == 0 && ((uintptr_t) y % 16) == 0, "pkv_mul_mat (batched): x and y must be 16-byte aligned");
     GemmArgs a = {(const unsigned char *) w, x, y, M, n_cols, K, (int64_t) row_size(type_w, K)};
-    // 128 weight rows per workgroup, or 64 where that would leave CUs without a tile
-    const int64_t nt = (n_cols + BN - 1) / BN;
-    const bool small = ((M + 127) / 128) * nt < 256;
-    const int bm = small ? 64 : 128;
-    const dim3 grid((unsigned) ((M + bm - 1) / bm), (unsigned) nt);
-#define PKV_GEMM(T_) do { if (small) hipLaunchKernelGGL((gemm_kernel<T_, 64>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_kernel<T_, 128>), grid, dim3(256), 0, st, a); } while (0)
+    // 128 x 128 tiles; 64 x 128, then 64 x 64, where the larger shape would leave CUs without a tile (or with one: a single 4-wave workgroup per CU
+    // runs at about half the rate of two)
+    const int64_t t128 = ((M + 127) / 128) * ((n_cols + 127) / 128), t64 = ((M + 63) / 64) * ((n_cols + 127) / 128);
+    // (64 x 64 doubles the dequantization per MFMA: it pays for f16 and q4_K weights, +21 ... +29 % at 4096 rows x 512 columns, and loses 10-14 % for
+    // q8_0 / q6_K, whose conversion is a float multiply per element)
+    const bool cheap = type_w == PKV_TYPE_F16 || type_w == PKV_TYPE_Q4_K;
+    const int shape = t128 >= 256 ? 0 : ((t64 >= 512 || !cheap) ? 1 : 2);
+    const int bm = shape == 0 ? 128 : 64, bn = shape == 2 ? 64 : 128;
+    const dim3 grid((unsigned) ((M + bm - 1) / bm), (unsigned) ((n_cols + bn - 1) / bn));
+#define PKV_GEMM(T_) do { if (shape == 0) hipLaunchKernelGGL((gemm_kernel<T_, 128, 128>), grid, dim3(256), 0, st, a); \
+                          else if (shape == 1) hipLaunchKernelGGL((gemm_kernel<T_, 64, 128>), grid, dim3(256), 0, st, a); \
+                          else hipLaunchKernelGGL((gemm_kernel<T_, 64, 64>), grid, dim3(256), 0, st, a); } while (0)
     switch (type_w) {
         case PKV_TYPE_F16:  PKV_GEMM(PKV_TYPE_F16); break;
         case PKV_TYPE_Q8_0: PKV_GEMM(PKV_TYPE_Q8_0); break;
