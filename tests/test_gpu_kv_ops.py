@@ -263,3 +263,33 @@ def test_qkv_prepare_equals_separate_ops(pkv, tk, tv):
     torch.cuda.synchronize()
     assert torch.equal(q1, q2)
     assert torch.equal(pools[0][0], pools[1][0]) and torch.equal(pools[0][1], pools[1][1])
+
+
+@pytest.mark.parametrize("tk,tv", [(1, 1), (8, 8), (2, 8)])
+@pytest.mark.parametrize("D,mode,n_dims", [(128, 0, 128), (128, 2, 128), (64, 0, 64), (64, 2, 64), (128, 0, 64)])
+def test_kv_store_per_token_kernel_equals_per_row_kernel(pkv, tk, tv, D, mode, n_dims, monkeypatch):
+    """prefill ubatches (>= 64 tokens) take kv_store_tok_kernel (one workgroup per token, a token's RoPE angles evaluated once per wave); it must
+    write the bits of the per-row kernel (PKV_KV_STORE_ROWS=1): NORM and NEOX pairs, partial rotation (n_dims < D), every cache type, and the same
+    rotated Q; rope_f32 is the third witness for Q"""
+    rng = np.random.default_rng(D + mode + n_dims + tk)
+    nh, nkv, bs, n_tok = 8, 2, 128, 150
+    q = dev(rng.uniform(-1, 1, (n_tok, nh, D)).astype(np.float32))
+    k = dev(rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32))
+    v = dev((rng.standard_normal((n_tok, nkv, D)) * rng.choice([1e-3, 1.0, 30.0], (n_tok, 1, 1))).astype(np.float32))
+    pos = dev(rng.integers(0, 20000, n_tok).astype(np.int32))
+    cells = rng.permutation(2 * bs)[:n_tok]
+    sb, so = dev((cells // bs).astype(np.int32)), dev((cells % bs).astype(np.int32))
+    rp = pkv.rope_params(n_dims=n_dims, mode=mode)
+    res = []
+    for rows in ("1", None):
+        if rows:
+            monkeypatch.setenv("PKV_KV_STORE_ROWS", rows)
+        else:
+            monkeypatch.delenv("PKV_KV_STORE_ROWS", raising=False)
+        pools = [torch.zeros(pkv.pool_bytes(t, 2, nkv, bs, D), dtype=torch.uint8, device="cuda") for t in (tk, tv)]
+        q2 = q.clone()
+        pkv.qkv_prepare(q2, k, v, pools[0], pools[1], type_k=tk, type_v=tv, slot_block=sb, slot_off=so, block_size=bs, pos=pos, rope=rp)
+        torch.cuda.synchronize()
+        res.append((q2, pools[0], pools[1]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[1][0], pkv.rope_f32(q, pos, rp))
