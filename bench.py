@@ -396,8 +396,13 @@ def main():
         k_graph = measure_dominant_kernel_graph(w, torch, side, max(5, args.kernel_reps))
 
     traffic = None
-    try:   # PMC traffic cannot be collected from inside the run: taken from the committed rocprofv3 passes, if this workload has one
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{args.kv_type}_ctx{args.ctx}_nseq{args.n_seq}") if args.model == "8b" else None
+    try:   # PMC traffic cannot be collected from inside the run: taken from the committed rocprofv3 passes, if this workload has one AND the passes
+        # were taken of THIS kernel source (profiles/traffic.json carries its hash; a changed kernel reports null until the passes are redone)
+        import hashlib
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        src = hashlib.sha256(open(os.path.join(ROOT, "llama.cpp_test_amd", "csrc", "pkv_attn_decode.hip"), "rb").read()).hexdigest()
+        if args.model == "8b" and tj.get("kernel_source_sha256") == src:
+            traffic = tj.get(f"{args.kv_type}_ctx{args.ctx}_nseq{args.n_seq}")
     except Exception:
         pass
     tok_s = world * args.n_seq * args.steps / dt

@@ -2,7 +2,7 @@
 """Summarise gpurun_out/r02_final (probes/r02_evidence.sh) into profiles/r02_*: the bench line, rocprofv3 kernel statistics of the bench command and of
 the end-to-end step, PMC traffic per launch of the decode kernel (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction) -> profiles/traffic.json,
 stamps, A/B against the round-1 library, secondary configurations, harness outputs.  usage: python probes/r02_summarize.py"""
-import csv, glob, json, os, shutil, sys
+import hashlib, csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -87,6 +87,7 @@ if pf and pw:
                           "attn_decode_kernel": {"FETCH_SIZE_avg_per_launch_KiB": cf["FETCH_SIZE"], "WRITE_SIZE_avg_per_launch_KiB": cw["WRITE_SIZE"], "launches": [nf, nw]},
                           "attn_decode_kernel_hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
         json.dump({"_doc": "HBM bytes per launch of pkv::attn_decode_kernel from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, KiB->B; gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md), keyed by bench.py workload; source profiles/r02_summary.json (regenerated after the r02 kernel changes)",
+                   "kernel_source_sha256": hashlib.sha256(open(os.path.join(ROOT, "llama.cpp_test_amd", "csrc", "pkv_attn_decode.hip"), "rb").read()).hexdigest(),
                    "f16_ctx4096_nseq1": hbm}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
         print("traffic per launch", hbm, "algorithmic", bench["roofline"]["algorithmic_bytes_per_launch"])
 json.dump(summary, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
