@@ -76,6 +76,20 @@ struct PrefillArgs {
 
 __device__ __forceinline__ int crow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }  // C/D row of register i
 
+// Dequantization while staging: 4 quants -> 4 halfs times their scales with packed f16 arithmetic.  A byte b under 0x64 is the half 1024 + b
+// (exact), so one v_perm_b32 places two quants as two halfs, one packed add removes the bias (1024 + 128 for int8 ^ 0x80, 1024 + 8 for a q4_0
+// nibble) and one packed multiply applies the f16 scales: q * d is exact in 19 bits and rounded once, the value (f16) ((float) q * (float) d)
+// that the scalar conversion produced with 3 instructions per element.
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2_t as_h2(uint32_t u) { return *reinterpret_cast<const h2_t *>(&u); }
+__device__ __forceinline__ uint32_t as_u(h2_t h) { return *reinterpret_cast<const uint32_t *>(&h); }
+// b = 4 biased quants in 4 bytes (element j in byte j); d01 / d23 = the scales of elements (0, 1) / (2, 3)
+__device__ __forceinline__ void dq4(uint32_t b, float bias, h2_t d01, h2_t d23, uint32_t & o01, uint32_t & o23) {
+    const h2_t nb = {(_Float16) -bias, (_Float16) -bias};
+    o01 = as_u((as_h2(__builtin_amdgcn_perm(0x64646464u, b, 0x04010400u)) + nb) * d01);
+    o23 = as_u((as_h2(__builtin_amdgcn_perm(0x64646464u, b, 0x04030402u)) + nb) * d23);
+}
+
 // Staging of one 64-token K tile: HBM -> registers (load) now, registers -> LDS (write) one loop iteration later, so the
 // loads of tile t+1 are in flight while tile t is being multiplied (cdna_hip_programming.md T14, async-STAGE split).
 // LDS image: f16 rows of D halfs, 16-byte chunk c of row r stored at chunk c ^ (r & 15) (conflict-free ds_read_b128).
@@ -121,19 +135,17 @@ struct KStage {
             if constexpr (KT == PKV_TYPE_F16) {
                 v = make_uint4(raw[i][0], raw[i][1], raw[i][2], raw[i][3]);
             } else {
-                const uint32_t ww[2] = {raw[i][0], raw[i][1]};
-                const unsigned short sb = (unsigned short) dsc[i];
-                const float d = (float) *reinterpret_cast<const _Float16 *>(&sb);
-                _Float16 o[8];
+                const h2_t dd = as_h2((dsc[i] & 0xFFFFu) * 0x10001u);          // the block scale in both halves
+                uint32_t o[4];
                 if constexpr (KT == PKV_TYPE_Q8_0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) (int) (signed char) (ww[j >> 2] >> (8 * (j & 3))) * d);
+                    dq4(raw[i][0] ^ 0x80808080u, 1152.0f, dd, dd, o[0], o[1]);
+                    dq4(raw[i][1] ^ 0x80808080u, 1152.0f, dd, dd, o[2], o[3]);
                 } else {
                     const int sh = (cc & 2) ? 4 : 0;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (_Float16) ((float) ((int) ((ww[j >> 2] >> (8 * (j & 3) + sh)) & 0xF) - 8) * d);
+                    dq4((raw[i][0] >> sh) & 0x0F0F0F0Fu, 1032.0f, dd, dd, o[0], o[1]);
+                    dq4((raw[i][1] >> sh) & 0x0F0F0F0Fu, 1032.0f, dd, dd, o[2], o[3]);
                 }
-                v = *reinterpret_cast<const uint4 *>(o);
+                v = make_uint4(o[0], o[1], o[2], o[3]);
             }
 #if PKV_PREFILL_ABLATE & 256   // timing experiment: wait for the loads, skip the LDS store
             asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
@@ -242,17 +254,16 @@ struct VStage {
             } else {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const u2_t s2 = sc[i][e];
-                    const _Float16 * sp = reinterpret_cast<const _Float16 *>(&s2);
-                    const uint32_t w = VT == PKV_TYPE_Q8_0 ? raw[i][e] : raw[i][e] >> (4 * (u0 & 7));
-                    _Float16 x[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int qv = VT == PKV_TYPE_Q8_0 ? (int) (signed char) (w >> (8 * j)) : (int) ((w >> (4 * j)) & 0xF) - 8;
-                        x[j] = (_Float16) ((float) qv * (float) sp[j]);
+                    const u2_t s2 = sc[i][e];                          // the 4 tokens' f16 scales: (s0, s1) | (s2, s3)
+                    if constexpr (VT == PKV_TYPE_Q8_0) {
+                        dq4(raw[i][e] ^ 0x80808080u, 1152.0f, as_h2(s2.x), as_h2(s2.y), o[2 * e], o[2 * e + 1]);
+                    } else {                                               // nibble j of w = token j: (n1 n0) (n3 n2) -> bytes n0, n2 | n1, n3
+                        const uint32_t w = raw[i][e] >> (4 * (u0 & 7));
+                        const uint32_t b = (w & 0x0F0Fu) | (((w >> 4) & 0x0F0Fu) << 16);
+                        const h2_t nb = {(_Float16) -1032.0f, (_Float16) -1032.0f};
+                        o[2 * e]     = as_u((as_h2(__builtin_amdgcn_perm(0x64646464u, b, 0x04020400u)) + nb) * as_h2(s2.x));
+                        o[2 * e + 1] = as_u((as_h2(__builtin_amdgcn_perm(0x64646464u, b, 0x04030401u)) + nb) * as_h2(s2.y));
                     }
-                    o[2 * e]     = (uint32_t) *reinterpret_cast<const uint16_t *>(&x[0]) | ((uint32_t) *reinterpret_cast<const uint16_t *>(&x[1]) << 16);
-                    o[2 * e + 1] = (uint32_t) *reinterpret_cast<const uint16_t *>(&x[2]) | ((uint32_t) *reinterpret_cast<const uint16_t *>(&x[3]) << 16);
                 }
             }
             if (nval_ < KVT) {                           // workgroup-uniform: only a sequence's last tile
