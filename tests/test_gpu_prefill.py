@@ -14,20 +14,20 @@ from gpu_util import dev, make_paged_case, nmse
 pytestmark = pytest.mark.gpu
 
 
-def run_prefill(pkv, O, rng, *, lens, n_qs, D, nh, nkv, tk, tv, softcap=0.0):
-    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tv)
+def run_prefill(pkv, O, rng, *, lens, n_qs, D, nh, nkv, tk, tv, softcap=0.0, bs=128):
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tv, block_size=bs)
     q_start = np.concatenate([[0], np.cumsum(n_qs)]).astype(np.int32)
     n_tok = int(q_start[-1])
     q = rng.uniform(-1, 1, (n_tok, nh, D)).astype(np.float32)
     out = pkv.attn_prefill(dev(q), dev(kp), dev(vp), dev(bt), dev(sl), dev(q_start), n_head_kv=nkv, type_k=tk, type_v=tv,
-                           block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()), max_q_per_seq=int(max(n_qs)),
+                           block_size=bs, scale=D ** -0.5, max_seq_len=int(sl.max()), max_q_per_seq=int(max(n_qs)),
                            logit_softcap=softcap)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     refs, exacts = [], []
     for s, (n, nq) in enumerate(zip(lens, n_qs)):
-        kc = O.pool_gather(kp, tk, 0, bt[s], n, D=D, block_size=128)
-        vc = O.pool_gather(vp, tv, 1, bt[s], n, D=D, block_size=128)
+        kc = O.pool_gather(kp, tk, 0, bt[s], n, D=D, block_size=bs)
+        vc = O.pool_gather(vp, tv, 1, bt[s], n, D=D, block_size=bs)
         qs = q[q_start[s]:q_start[s + 1]].transpose(1, 0, 2)               # [n_head][n_q][D]
         mask = np.zeros((nq, n), np.float16)
         for j in range(nq):
@@ -203,3 +203,13 @@ def test_prefill_64_queries_per_wave_variant(pkv, O, monkeypatch):
     assert np.isfinite(outs[1]).all()
     assert np.abs(outs[0] - outs[1]).max() <= 1e-4
     assert np.array_equal(outs[0][qs[8]:], outs[1][qs[8]:])      # the two whole pp512 prompts: bit for bit
+
+
+@pytest.mark.parametrize("bs,tk", [(64, 1), (192, 1), (192, 8), (256, 2)])
+def test_prefill_other_block_sizes(pkv, O, bs, tk):
+    """blocks of 64, 192 (not a power of two: the kernel's divide path for the table index) and 256 tokens, chunked prompts over a past"""
+    rng = np.random.default_rng(bs + tk)
+    lens, n_qs = [1, 63, 190, 193, 500, 700], [1, 63, 100, 193, 37, 300]
+    got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=n_qs, D=128, nh=8, nkv=2, tk=tk, tv=tk, bs=bs)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= (np.abs(ref - exact).max() + 3e-4 if tk == 1 else 3e-3) and nmse(got, ref) <= 5e-4
