@@ -217,6 +217,13 @@ typedef struct pkv_step_args {
  * of rotation pair i at pos[t] (identity past n_dims/2).  cache: device f32 [n_tok][head_dim/2][2], 16-byte aligned. */
 int pkv_rope_cache(const int32_t * pos, int n_tok, int head_dim, const pkv_rope_params * rope, float * cache, void * stream);
 int pkv_attn_decode_step(const pkv_attn_args * args, const pkv_step_args * step, void * stream);
+/* The prefill analogue (a ubatch with several query tokens per sequence): RoPE(K) + KV store of the ubatch's rows into (slot_block, slot_off) — the
+ * cells find_slot assigned, as in pkv_kv_store — then pkv_attn_prefill with RoPE(Q) fused into its Q fetch: args->q is read un-rotated and NOT
+ * modified, the rotated Q goes straight into the QK^T operand.  Replaces pkv_qkv_prepare + pkv_attn_prefill (/ref/src/llama-model.cpp:4091-4105,
+ * /ref/src/llama-graph.cpp:1367-1432 for n_tokens > 1) with the same pools and the same output bits, without the in-place rotation pass over Q
+ * (2/3 of that call's traffic).  step->rope_cache (pkv_rope_cache rows of the ubatch's tokens, computed once per ubatch and shared by all layers)
+ * is REQUIRED with rope; step->pos is still read by the K rotation.  PKV_ERR_UNSUPPORTED for NEOX pairs (use the two calls). */
+int pkv_attn_prefill_step(const pkv_attn_args * args, const pkv_step_args * step, const int32_t * slot_block, const int32_t * slot_off, void * stream);
 /* DIAGNOSTIC build of the decode-step kernel with in-kernel phase stamps (f16 KV, head_dim 128, gqa 4 / 8; the two-launch step):
  * same arguments as pkv_attn_decode_step; `stamps` = device u64 [n_workgroups][8 waves][PKV_DECODE_NSTAMP], workgroup index
  * (seq * n_head_kv + kv_head) * n_splits + split.  Slots: 0 = s_memrealtime (100 MHz) at entry, 1..10 = s_memtime (shader clock) at

@@ -216,7 +216,7 @@ def attn_prefill_workspace_bytes(n_tok: int, n_head: int, head_dim: int) -> int:
 
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
-          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None, stamps=None):
+          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None, stamps=None, slots=None):
     import torch
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
@@ -236,6 +236,8 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
         st = StepArgs(_ptr(k_cur), _ptr(v_cur), _ptr(pos), C.pointer(rope) if rope is not None else None, _ptr(rope_cache))
         if stamps is not None:
             check(fn(C.byref(a), C.byref(st), C.c_void_p(_ptr(stamps[0])), int(stamps[1]), C.c_void_p(_stream(stream))))
+        elif slots is not None:
+            check(fn(C.byref(a), C.byref(st), C.c_void_p(_ptr(slots[0])), C.c_void_p(_ptr(slots[1])), C.c_void_p(_stream(stream))))
         else:
             check(fn(C.byref(a), C.byref(st), C.c_void_p(_stream(stream))))
     else:
@@ -326,6 +328,14 @@ class KernelTimer:
 def attn_prefill(q, k_pool, v_pool, block_table, seq_lens, q_start, **kw):
     """Paged causal prefill (many query tokens per sequence); q f32 [n_tok][n_head][D]."""
     return _attn(lib().pkv_attn_prefill, q, k_pool, v_pool, block_table, seq_lens, q_start=q_start, **kw)
+
+
+def attn_prefill_step(q, k_cur, v_cur, pos, rope, k_pool, v_pool, block_table, seq_lens, q_start, slot_block, slot_off, *, rope_cache=None, **kw):
+    """A prefill ubatch of a layer: RoPE(K) + KV store into (slot_block, slot_off), then the prefill attention with RoPE(Q) fused into its Q
+    fetch (pkv_attn_prefill_step): q stays un-rotated and untouched; same pools and output bits as qkv_prepare + attn_prefill.  rope_cache:
+    rows from rope_cache(pos, rope, D) for the ubatch's tokens (required with rope; shared by all layers).  NEOX rope: PkvError (use the two calls)."""
+    return _attn(lib().pkv_attn_prefill_step, q, k_pool, v_pool, block_table, seq_lens, q_start=q_start,
+                 step=(k_cur, v_cur, pos, rope, rope_cache), slots=(slot_block, slot_off), **kw)
 
 
 def k_shift(k_pool, *, type_k, cell_block, cell_off, cell_delta, n_head_kv, head_dim, block_size, rope: RopeParams,

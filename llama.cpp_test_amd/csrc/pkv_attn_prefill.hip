@@ -24,6 +24,7 @@
 // masks per element.  Quantized K/V (q8_0, q4_0) are dequantized to f16 while staging (Q stays f16: closer to exact
 // arithmetic than the reference's q8_0-quantized Q; tolerance in tests/test_gpu_prefill.py).
 #include "pkv_common.h"
+#include "pkv_rowcodec.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -61,6 +62,8 @@ struct PrefillArgs {
     int   n_head, n_head_kv, block_size, max_blocks;
     int   bs_shift;               // log2(block_size), or -1 when it is not a power of two
     int   mask_align8;            // mask rows start on 8-byte boundaries (base and row stride)
+    const float * rope_cache;     // pkv_attn_prefill_step: (cos, sin) rows of the ubatch's tokens [n_tok][D/2][2] (pkv_rope_cache), NORM pairs: Q arrives
+                                  // un-rotated and is rotated on its way into the QK^T operand; NULL = q is used as given
     float scale, softcap;
     const _Float16 * mask;        // optional additive mask f16 [>= n_tok rows][mask_stride], row = token index, col = kv cell
     int64_t mask_stride;
@@ -468,16 +471,28 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
         for (int qb = 0; qb < QB; ++qb) {
             const rsrc_t rq = mk_rsrc(a.q + (size_t) (tok0 + tile * QTW + qb * QT) * a.q_stride_tok + (size_t) head * a.q_stride_head,
                                       (long long) (n_rows - qb * QT - 1) * qsb + D * 4);   // (a block past the end of the tile: no bytes, reads as 0)
+            // fused RoPE(Q): the rows' (cos, sin) pairs, same shape as the rows themselves at half the bytes (float4 = the two pairs of the lane's 4 elements)
+            const rsrc_t rc = mk_rsrc(a.rope_cache ? a.rope_cache + (size_t) (tok0 + tile * QTW + qb * QT) * D : nullptr,
+                                      a.rope_cache ? (long long) (n_rows - qb * QT) * D * 4 : 0);
 #pragma unroll
             for (int b = 0; b < NQ; b += 8) {
-                u4_t x[8];
+                u4_t x[8], cs[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int) (((b + i) * RPI + lr) * qsb) + lc * 16, 0, 0);
+                if (a.rope_cache) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) cs[i] = __builtin_amdgcn_raw_buffer_load_b128(rc, (((b + i) * RPI + lr) * D + lc * 4) * 4, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = (b + i) * RPI + lr;
-                    _Float16 hv[4] = {(_Float16) __uint_as_float(x[i].x), (_Float16) __uint_as_float(x[i].y),
-                                      (_Float16) __uint_as_float(x[i].z), (_Float16) __uint_as_float(x[i].w)};
+                    float x0 = __uint_as_float(x[i].x), x1 = __uint_as_float(x[i].y), x2 = __uint_as_float(x[i].z), x3 = __uint_as_float(x[i].w);
+                    if (a.rope_cache) {   // the rotation of kv_store_kernel's Q plane (rot0 / rot1: every product and the sum rounded on its own)
+                        const float c0 = __uint_as_float(cs[i].x), s0 = __uint_as_float(cs[i].y), c1 = __uint_as_float(cs[i].z), s1 = __uint_as_float(cs[i].w);
+                        const float y0 = rot0(x0, x1, c0, s0), y1 = rot1(x0, x1, c0, s0), y2 = rot0(x2, x3, c1, s1), y3 = rot1(x2, x3, c1, s1);
+                        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+                    }
+                    _Float16 hv[4] = {(_Float16) x0, (_Float16) x1, (_Float16) x2, (_Float16) x3};
                     *reinterpret_cast<uint2 *>(strip + row * D * 2 + (((lc >> 1) ^ (row & 15)) & (D / 8 - 1)) * 16 + (lc & 1) * 8) = *reinterpret_cast<const uint2 *>(hv);
                 }
             }
@@ -834,7 +849,7 @@ size_t prefill_workspace_bytes(int n_tok, int n_head, int D) {
     return (size_t) n_tok * n_head * PREFILL_MAX_SPLIT * (D + 2) * sizeof(float);
 }
 
-int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
+int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * rope_cache) {
     PKV_REQUIRE(a.q && a.out && a.k_pool && a.v_pool && a.block_table && a.seq_lens && a.q_start, "pkv_attn_prefill: null pointer");
     PKV_REQUIRE(a.n_seq > 0 && a.n_tok > 0 && a.max_q_per_seq > 0, "pkv_attn_prefill: bad token counts");
     PKV_REQUIRE(a.n_head > 0 && a.n_head_kv > 0 && a.n_head % a.n_head_kv == 0, "pkv_attn_prefill: bad head counts");
@@ -855,6 +870,8 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st) {
     pa.stamps = (unsigned long long *) g_prefill_stamps;
     pa.mask = (const _Float16 *) a.mask; pa.mask_stride = a.mask_stride; pa.max_bias = a.max_bias;
     pa.mask_align8 = ((uintptr_t) a.mask % 8) == 0 && (a.mask_stride % 4) == 0;
+    pa.rope_cache = rope_cache;
+    PKV_REQUIRE(((uintptr_t) rope_cache % 16) == 0, "pkv_attn_prefill_step: rope_cache must be 16-byte aligned");
     pa.causal = (a.flags & PKV_ATTN_NONCAUSAL) ? 0 : 1;
     PKV_REQUIRE(a.max_bias == 0.0f || a.mask, "pkv_attn_prefill: max_bias (ALiBi) needs a mask");
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;

@@ -256,6 +256,26 @@ int pkv_attn_prefill(const pkv_attn_args * args, void * stream) {
     return launch_attn_prefill(*args, (hipStream_t) stream);
 }
 
+int pkv_attn_prefill_step(const pkv_attn_args * args, const pkv_step_args * step, const int32_t * slot_block, const int32_t * slot_off, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args != nullptr && step != nullptr && slot_block && slot_off, "pkv_attn_prefill_step: null args");
+    PKV_REQUIRE(step->k_cur && step->v_cur, "pkv_attn_prefill_step: k_cur / v_cur missing");
+    hipStream_t st = (hipStream_t) stream;
+    RopeDev r;
+    const float * cache = nullptr;
+    if (step->rope) {
+        if (int rc = make_rope(step->rope, args->head_dim, &r)) return rc;
+        if (r.mode & 2) { set_error("pkv_attn_prefill_step: NEOX pairs are not fused (use pkv_qkv_prepare + pkv_attn_prefill)"); return PKV_ERR_UNSUPPORTED; }
+        PKV_REQUIRE(step->rope_cache != nullptr, "pkv_attn_prefill_step: rope_cache (pkv_rope_cache rows of the ubatch's tokens) is required with rope");
+        PKV_REQUIRE(step->pos != nullptr, "pkv_attn_prefill_step: pos missing");
+        cache = step->rope_cache;
+    }
+    // K rotated + K / V stored (the Q plane of pkv_qkv_prepare is what the attention kernel's Q fetch does now), then the attention
+    if (int rc = launch_kv_store(nullptr, 0, step->k_cur, step->v_cur, const_cast<void *>(args->k_pool), const_cast<void *>(args->v_pool), args->type_k, args->type_v,
+                                 slot_block, slot_off, step->pos, step->rope ? &r : nullptr, args->n_tok, args->n_head_kv, args->head_dim, args->block_size, st, cache)) return rc;
+    return launch_attn_prefill(*args, st, cache);
+}
+
 int pkv_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,
                 const int32_t * cell_delta, int n_cells, int n_head_kv, int head_dim, int block_size,
                 const pkv_rope_params * rope, void * stream) {

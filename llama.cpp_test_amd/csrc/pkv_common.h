@@ -105,9 +105,9 @@ int launch_rope_f16(const void * x, const int32_t * pos, void * out, int n_tok, 
                     int inverse, hipStream_t st, int64_t xs_tok = 0, int64_t xs_head = 0);
 int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * v_cur, void * k_pool, void * v_pool,
                     int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
-                    const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st);
+                    const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st, const float * rope_cache = nullptr);
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_args * step = nullptr);
-int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st);
+int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * rope_cache = nullptr);   // rope_cache: RoPE(Q) fused in (NORM pairs)
 int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);

@@ -74,6 +74,7 @@ struct StoreArgs {
     const int32_t * slot_block; const int32_t * slot_off; const int32_t * pos;
     int n_head_kv, block_size, has_rope;
     RopeDev rope;
+    const float * rope_cache;   // optional pkv_rope_cache rows of these tokens [n_tok][D/2][2] (NORM pairs): read instead of evaluated (kv_store_tok_kernel)
 };
 
 // grid (max(n_head_kv, n_head_q), n_tok, 2 or 3): z = 0 stores K (optionally roped), z = 1 stores V,
@@ -233,7 +234,8 @@ __global__ void __launch_bounds__(256) kv_store_tok_kernel(const StoreArgs a) {
     if (a.has_rope) {
         const int pos = a.pos[t], e0 = 2 * (lane % (D / 2));
         if ((a.rope.mode & 2) == 0) {
-            if (e0 < a.rope.n_dims) c0 = rope_cs(pos, e0 / 2, a.rope, 1.0f);
+            if (a.rope_cache)             c0 = reinterpret_cast<const float2 *>(a.rope_cache)[(size_t) t * (D / 2) + e0 / 2];   // the same values, computed once per ubatch
+            else if (e0 < a.rope.n_dims)  c0 = rope_cs(pos, e0 / 2, a.rope, 1.0f);
         } else {
             const int ic = (lane % (D / 2)) < D / 4 ? e0 : e0 - D / 2;
             c0 = rope_cs(pos, ic, a.rope, 1.0f);
@@ -303,9 +305,10 @@ static int store_v(const StoreArgs & a, int type_v, int n_tok, int D, hipStream_
 
 int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * v_cur, void * k_pool, void * v_pool,
                     int type_k, int type_v, const int32_t * slot_block, const int32_t * slot_off, const int32_t * pos,
-                    const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st) {
+                    const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st, const float * rope_cache) {
     if (n_tok == 0) return PKV_OK;
     StoreArgs a{};
+    a.rope_cache = rope_cache;
     a.q = q; a.n_head_q = n_head_q;
     a.k_cur = k_cur; a.v_cur = v_cur; a.k_pool = (char *) k_pool; a.v_pool = (char *) v_pool;
     a.slot_block = slot_block; a.slot_off = slot_off; a.pos = pos;

@@ -18,7 +18,7 @@ from typing import List, Sequence
 import numpy as np
 
 from . import (ATTN_NONCAUSAL, PagedKVCache, PkvError, RopeParams, attn_decode, attn_decode_step, attn_prefill,  # noqa: F401
-               attn_prefill_workspace_bytes, attn_workspace, qkv_prepare, rope_cache, rope_params)
+               attn_prefill_step, attn_prefill_workspace_bytes, attn_workspace, qkv_prepare, rope_cache, rope_params)
 
 
 class AttnPathRunner:
@@ -39,6 +39,8 @@ class AttnPathRunner:
         self.ws = attn_workspace(n_seq_max, n_head, head_dim, self.max_seq_len, block_size,
                                  min_bytes=attn_prefill_workspace_bytes(min(max_batch_tokens, 2048), n_head, head_dim))
         self.max_batch_tokens = max_batch_tokens
+        # prefill ubatches as ONE fused step per layer (K/V store + attention with RoPE(Q) in its Q fetch) where the rope pairs are NORM (llama)
+        self.fused_prefill = (self.rope.mode & 2) == 0
 
     @classmethod
     def from_gguf(cls, path: str, *, type_k: int, type_v: int, n_blocks: int, n_seq_max: int, **kw):
@@ -96,17 +98,22 @@ class AttnPathRunner:
                     max_seq_len=int(sl.max()), slot_block=dev(blk), slot_off=dev(off), pos=dpos, block_table=dev(bt),
                     seq_lens=dev(sl), q_start=dev(np.asarray(starts, np.int32)),
                     # ggml_rope_cache_init once per ubatch, shared by every layer's fused decode step
-                    rope_cache=rope_cache(dpos, self.rope, self.D) if (all_decode and with_rope_cache) else None)
+                    # ggml_rope_cache_init once per ubatch, shared by every layer's fused step (decode: attn_decode_step; prefill, NORM pairs: attn_prefill_step)
+                    rope_cache=rope_cache(dpos, self.rope, self.D) if (with_rope_cache and (all_decode or self.fused_prefill)) else None)
 
     def layer(self, il: int, plan, q, k_cur, v_cur, out=None):
         """device half, one layer: q f32 [n_tok][n_head][D], k_cur/v_cur f32 [n_tok][n_head_kv][D], all un-rotated.
-        Decode ubatches (one token per sequence) leave q untouched; prefill ubatches rotate it in place."""
+        Decode ubatches (one token per sequence) and fused prefill ubatches (NORM rope pairs) leave q untouched; prefill ubatches with
+        NEOX pairs (fused_prefill False) rotate it in place."""
         c = self.cache
         kw = dict(n_head_kv=self.HK, type_k=self.tk, type_v=self.tv, block_size=self.BS, scale=self.scale,
                   max_seq_len=plan["max_seq_len"], out=out, workspace=self.ws)
         if plan["all_decode"]:
             return attn_decode_step(q, k_cur, v_cur, plan["pos"], self.rope, c.k_pool(il), c.v_pool(il), plan["block_table"],
                                     plan["seq_lens"], rope_cache=plan["rope_cache"], **kw)
+        if self.fused_prefill and plan["rope_cache"] is not None:   # q stays un-rotated: RoPE(Q) happens in the attention kernel's Q fetch
+            return attn_prefill_step(q, k_cur, v_cur, plan["pos"], self.rope, c.k_pool(il), c.v_pool(il), plan["block_table"], plan["seq_lens"],
+                                     plan["q_start"], plan["slot_block"], plan["slot_off"], rope_cache=plan["rope_cache"], max_q_per_seq=plan["max_q"], **kw)
         qkv_prepare(q, k_cur, v_cur, c.k_pool(il), c.v_pool(il), type_k=self.tk, type_v=self.tv, slot_block=plan["slot_block"],
                     slot_off=plan["slot_off"], block_size=self.BS, pos=plan["pos"], rope=self.rope)
         return attn_prefill(q, c.k_pool(il), c.v_pool(il), plan["block_table"], plan["seq_lens"], plan["q_start"],
@@ -150,11 +157,11 @@ class AttnPathRunner:
         msl = -(-plan["max_seq_len"] // self.BS) * self.BS
         gplan = dict(plan, slot_block=pt["slot_block"][:n_tok], slot_off=pt["slot_off"][:n_tok], pos=pt["pos"][:n_tok],
                      block_table=pt["block_table"][:n_seq], seq_lens=pt["seq_lens"][:n_seq], q_start=pt["q_start"][:n_seq + 1],
-                     max_seq_len=msl, rope_cache=pt["rope_cache"][:n_tok] if plan["all_decode"] else None)
+                     max_seq_len=msl, rope_cache=pt["rope_cache"][:n_tok] if (plan["all_decode"] or self.fused_prefill) else None)
         key = (n_tok, n_seq, plan["max_q"], plan["all_decode"], msl) + tuple(x.data_ptr() for lst in (q, k_cur, v_cur, out) for x in lst)
 
         def launches():
-            if plan["all_decode"]:
+            if gplan["rope_cache"] is not None:
                 rope_cache(gplan["pos"], self.rope, self.D, out=gplan["rope_cache"])
             for il in range(self.L):
                 self.layer(il, gplan, q[il], k_cur[il], v_cur[il], out[il])

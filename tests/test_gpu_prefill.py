@@ -213,3 +213,39 @@ def test_prefill_other_block_sizes(pkv, O, bs, tk):
     got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=n_qs, D=128, nh=8, nkv=2, tk=tk, tv=tk, bs=bs)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= (np.abs(ref - exact).max() + 3e-4 if tk == 1 else 3e-3) and nmse(got, ref) <= 5e-4
+
+
+@pytest.mark.parametrize("tk,tv", [(1, 1), (8, 8), (2, 8)])
+def test_prefill_step_equals_prepare_plus_prefill(pkv, O, tk, tv):
+    """pkv_attn_prefill_step (RoPE(K) + KV store, then the attention with RoPE(Q) fused into its Q fetch; q untouched) == pkv_qkv_prepare (q rotated in
+    place) + pkv_attn_prefill: same output bits, same pool bits — ragged ubatch over pasts, partial rotation (n_dims < D) included"""
+    rng = np.random.default_rng(11 + tk)
+    D, nh, nkv, bs = 128, 8, 2, 128
+    lens, n_qs = [1, 40, 200, 333, 512], [1, 40, 70, 333, 129]
+    for n_dims in (128, 64):
+        kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tv)
+        q_start = np.concatenate([[0], np.cumsum(n_qs)]).astype(np.int32)
+        n_tok = int(q_start[-1])
+        q = rng.uniform(-1, 1, (n_tok, nh, D)).astype(np.float32)
+        k = rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32)
+        v = rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32)
+        # the ubatch's tokens are the LAST n_q cells of each sequence
+        cell = np.concatenate([np.arange(n - nq, n) for n, nq in zip(lens, n_qs)])
+        seq = np.concatenate([np.full(nq, s) for s, nq in enumerate(n_qs)])
+        sb, so = bt[seq, cell // bs].astype(np.int32), (cell % bs).astype(np.int32)
+        pos = (cell + rng.integers(0, 3000)).astype(np.int32)
+        rp = pkv.rope_params(n_dims=n_dims)
+        kw = dict(n_head_kv=nkv, type_k=tk, type_v=tv, block_size=bs, scale=D ** -0.5, max_seq_len=max(lens), max_q_per_seq=max(n_qs))
+        pools = [[dev(kp), dev(vp)], [dev(kp), dev(vp)]]
+        q1 = dev(q)
+        pkv.qkv_prepare(q1, dev(k), dev(v), pools[0][0], pools[0][1], type_k=tk, type_v=tv, slot_block=dev(sb), slot_off=dev(so), block_size=bs, pos=dev(pos), rope=rp)
+        o1 = pkv.attn_prefill(q1, pools[0][0], pools[0][1], dev(bt), dev(sl), dev(q_start), **kw)
+        q2 = dev(q)
+        cache = pkv.rope_cache(dev(pos), rp, D)
+        o2 = pkv.attn_prefill_step(q2, dev(k), dev(v), dev(pos), rp, pools[1][0], pools[1][1], dev(bt), dev(sl), dev(q_start), dev(sb), dev(so), rope_cache=cache, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(q2, dev(q))                                 # q is not modified
+        assert torch.equal(pools[0][0], pools[1][0]) and torch.equal(pools[0][1], pools[1][1])
+        assert torch.isfinite(o2).all() and torch.equal(o1, o2), n_dims
+    with pytest.raises(pkv.PkvError):                                  # NEOX pairs are not fused
+        pkv.attn_prefill_step(q2, dev(k), dev(v), dev(pos), pkv.rope_params(n_dims=D, mode=2), pools[1][0], pools[1][1], dev(bt), dev(sl), dev(q_start), dev(sb), dev(so), rope_cache=cache, **kw)
