@@ -215,14 +215,15 @@ def test_prefill_other_block_sizes(pkv, O, bs, tk):
     assert np.abs(got - ref).max() <= (np.abs(ref - exact).max() + 3e-4 if tk == 1 else 3e-3) and nmse(got, ref) <= 5e-4
 
 
+@pytest.mark.parametrize("D,nh,nkv", [(128, 8, 2), (64, 32, 4), (128, 64, 8)])
 @pytest.mark.parametrize("tk,tv", [(1, 1), (8, 8), (2, 8)])
-def test_prefill_step_equals_prepare_plus_prefill(pkv, O, tk, tv):
+def test_prefill_step_equals_prepare_plus_prefill(pkv, O, tk, tv, D, nh, nkv):
     """pkv_attn_prefill_step (RoPE(K) + KV store, then the attention with RoPE(Q) fused into its Q fetch; q untouched) == pkv_qkv_prepare (q rotated in
     place) + pkv_attn_prefill: same output bits, same pool bits — ragged ubatch over pasts, partial rotation (n_dims < D) included"""
-    rng = np.random.default_rng(11 + tk)
-    D, nh, nkv, bs = 128, 8, 2, 128
+    rng = np.random.default_rng(11 + tk + D + nh)
+    bs = 128
     lens, n_qs = [1, 40, 200, 333, 512], [1, 40, 70, 333, 129]
-    for n_dims in (128, 64):
+    for n_dims in (D, D // 2):
         kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tv)
         q_start = np.concatenate([[0], np.cumsum(n_qs)]).astype(np.int32)
         n_tok = int(q_start[-1])
