@@ -16,6 +16,8 @@
 //   so a lane owns 4 consecutive m of one token n per register group: float4 stores into y[n][m].
 #include "pkv_common.h"
 
+#include <cstdlib>
+
 namespace pkv {
 namespace {
 
@@ -184,7 +186,9 @@ int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t 
     // (64 x 64 doubles the dequantization per MFMA: it pays for f16 and q4_K weights, +21 ... +29 % at 4096 rows x 512 columns, and loses 10-14 % for
     // q8_0 / q6_K, whose conversion is a float multiply per element)
     const bool cheap = type_w == PKV_TYPE_F16 || type_w == PKV_TYPE_Q4_K;
-    const int shape = t128 >= 256 ? 0 : ((t64 >= 512 || !cheap) ? 1 : 2);
+    // (... unless even 64-row tiles leave the chip short of one workgroup per CU: TinyLlama's 2048-row matrices, q8_0 71 -> 87, q6_K 54 -> 70 TFLOP/s)
+    int shape = t128 >= 256 ? 0 : ((t64 >= 512 || (!cheap && t64 >= 256)) ? 1 : 2);
+    if (const char * e = getenv("PKV_GEMM_SHAPE")) shape = atoi(e) % 3;   // experiments
     const int bm = shape == 0 ? 128 : 64, bn = shape == 2 ? 64 : 128;
     const dim3 grid((unsigned) ((M + bm - 1) / bm), (unsigned) ((n_cols + bn - 1) / bn));
 #define PKV_GEMM(T_) do { if (shape == 0) hipLaunchKernelGGL((gemm_kernel<T_, 128, 128>), grid, dim3(256), 0, st, a); \
