@@ -138,6 +138,7 @@ int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float 
 // batched products on the matrix cores (pkv_gemm.hip)
 bool gemm_supported(int type_w, int64_t M, int64_t K);
 int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st);
+int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols, hipStream_t st);   // n <= 4 matrices of one type, same x
 int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);
 // decode-step products for K-quant weights (pkv_gemv.hip)
 size_t act_image_bytes(int64_t K);

@@ -83,7 +83,11 @@ template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 2
     }
 };
 
-struct GemmArgs { const unsigned char * w; const float * x; float * y; int64_t M, N, K, row_bytes; };
+// up to GEMM_MAX matrices of one weight type against the same activations in ONE launch (q + k, gate + up of a llama layer: launch_mul_mat_multi):
+// blockIdx.x runs over the row tiles of all of them.  A product of a few hundred rows (k, v: 1024 rows at 8B, 256 at TinyLlama) is a handful of
+// workgroups walking all of K in 64-deep steps at one load latency per step — 50 us whatever its size — so it rides along with a large one instead.
+constexpr int GEMM_MAX = 4;
+struct GemmArgs { const unsigned char * w[GEMM_MAX]; float * y[GEMM_MAX]; int64_t M[GEMM_MAX]; int tile_end[GEMM_MAX]; int n; const float * x; int64_t N, K, row_bytes; };
 
 template <int T, int BM, int BN>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
@@ -93,11 +97,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 sA[BM * LDR], sB[BN * LDR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave % WM, wn = wave / WM;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t) blockIdx.x * BM, n0 = (int64_t) blockIdx.y * BN;
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX; ++i) if (i < a.n && (int) blockIdx.x >= a.tile_end[i - 1]) mi = i;
+    const int64_t aM = a.M[mi];
+    const unsigned char * const aw = a.w[mi];
+    float * const ay = a.y[mi];
+    const int64_t m0 = (int64_t) ((int) blockIdx.x - (mi ? a.tile_end[mi - 1] : 0)) * BM, n0 = (int64_t) blockIdx.y * BN;
     // staging role: row srow, 32-element half shalf of both tiles (rows past the end re-read the last row; their outputs are never stored)
     const int srow = tid >> 1, shalf = tid & 1;
     const bool stage_a = srow < BM, stage_b = srow < BN;
-    const unsigned char * wrow = a.w + (size_t) min(m0 + (stage_a ? srow : 0), a.M - 1) * a.row_bytes;
+    const unsigned char * wrow = aw + (size_t) min(m0 + (stage_a ? srow : 0), aM - 1) * a.row_bytes;
     const float * xrow = a.x + (size_t) min(n0 + (stage_b ? srow : 0), a.N - 1) * a.K;
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -161,9 +171,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t m = m0 + wm * 32 * TM + i * 32 + 8 * g + 4 * h;
-                if ((a.M & 3) == 0 && m + 3 < a.M) *reinterpret_cast<float4 *>(a.y + (size_t) n * a.M + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                if ((aM & 3) == 0 && m + 3 < aM) *reinterpret_cast<float4 *>(ay + (size_t) n * aM + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                 else
-                    for (int e = 0; e < 4; ++e) if (m + e < a.M) a.y[(size_t) n * a.M + m + e] = acc[i][j][4 * g + e];
+                    for (int e = 0; e < 4; ++e) if (m + e < aM) ay[(size_t) n * aM + m + e] = acc[i][j][4 * g + e];
             }
     }
 }
@@ -175,14 +185,24 @@ bool gemm_supported(int type_w, int64_t M, int64_t K) {
     return M > 0 && K > 0 && K % BK == 0 && (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K ? K % 256 == 0 : true);
 }
 
-int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st) {
-    if (M == 0 || n_cols == 0) return PKV_OK;
-    if (!gemm_supported(type_w, M, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
-    PKV_REQUIRE(((uintptr_t) x % 16) == 0 && ((uintptr_t) y % 16) == 0, "pkv_mul_mat (batched): x and y must be 16-byte aligned");
-    GemmArgs a = {(const unsigned char *) w, x, y, M, n_cols, K, (int64_t) row_size(type_w, K)};
+int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols, hipStream_t st) {
+    if (n_cols == 0) return PKV_OK;
+    PKV_REQUIRE(n >= 1 && n <= GEMM_MAX, "pkv_mul_mat (batched): 1 to %d matrices per launch", GEMM_MAX);
+    if (!gemm_supported(type_w, 1, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
+    PKV_REQUIRE(((uintptr_t) x % 16) == 0, "pkv_mul_mat (batched): x must be 16-byte aligned");
+    GemmArgs a = {};
+    a.x = x; a.N = n_cols; a.K = K; a.row_bytes = (int64_t) row_size(type_w, K);
+    int64_t r128 = 0, r64 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (M[i] == 0) continue;
+        PKV_REQUIRE(((uintptr_t) y[i] % 16) == 0, "pkv_mul_mat (batched): y must be 16-byte aligned");
+        a.w[a.n] = (const unsigned char *) w[i]; a.y[a.n] = y[i]; a.M[a.n] = M[i]; ++a.n;
+        r128 += (M[i] + 127) / 128; r64 += (M[i] + 63) / 64;
+    }
+    if (a.n == 0) return PKV_OK;
     // 128 x 128 tiles; 64 x 128, then 64 x 64, where the larger shape would leave CUs without a tile (or with one: a single 4-wave workgroup per CU
     // runs at about half the rate of two)
-    const int64_t t128 = ((M + 127) / 128) * ((n_cols + 127) / 128), t64 = ((M + 63) / 64) * ((n_cols + 127) / 128);
+    const int64_t t128 = r128 * ((n_cols + 127) / 128), t64 = r64 * ((n_cols + 127) / 128);
     // (64 x 64 doubles the dequantization per MFMA: it pays for f16 and q4_K weights, +21 ... +29 % at 4096 rows x 512 columns, and loses 10-14 % for
     // q8_0 / q6_K, whose conversion is a float multiply per element)
     const bool cheap = type_w == PKV_TYPE_F16 || type_w == PKV_TYPE_Q4_K;
@@ -190,7 +210,9 @@ int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t 
     int shape = t128 >= 256 ? 0 : ((t64 >= 512 || (!cheap && t64 >= 256)) ? 1 : 2);
     if (const char * e = getenv("PKV_GEMM_SHAPE")) shape = atoi(e) % 3;   // experiments
     const int bm = shape == 0 ? 128 : 64, bn = shape == 2 ? 64 : 128;
-    const dim3 grid((unsigned) ((M + bm - 1) / bm), (unsigned) ((n_cols + bn - 1) / bn));
+    int tot = 0;
+    for (int i = 0; i < a.n; ++i) { tot += (int) ((a.M[i] + bm - 1) / bm); a.tile_end[i] = tot; }
+    const dim3 grid((unsigned) tot, (unsigned) ((n_cols + bn - 1) / bn));
 #define PKV_GEMM(T_) do { if (shape == 0) hipLaunchKernelGGL((gemm_kernel<T_, 128, 128>), grid, dim3(256), 0, st, a); \
                           else if (shape == 1) hipLaunchKernelGGL((gemm_kernel<T_, 64, 128>), grid, dim3(256), 0, st, a); \
                           else hipLaunchKernelGGL((gemm_kernel<T_, 64, 64>), grid, dim3(256), 0, st, a); } while (0)
@@ -203,6 +225,11 @@ int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t 
 #undef PKV_GEMM
     PKV_HIP(hipGetLastError());
     return PKV_OK;
+}
+
+int launch_gemm(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st) {
+    if (M == 0 || n_cols == 0) return PKV_OK;
+    return launch_gemm_multi(1, &w, type_w, x, &y, &M, K, n_cols, st);
 }
 
 }  // namespace pkv

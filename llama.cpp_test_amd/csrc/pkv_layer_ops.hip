@@ -602,6 +602,7 @@ int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float 
             return launch_gemv(g, st);
         }
     }
+    if (n_cols >= GEMM_MIN_COLS && gemm_supported(type_w, 1, K) && n <= 4) return launch_gemm_multi(n, w, type_w, x, y, M, K, n_cols, st);   // prompt ubatch: ONE MFMA launch
     if ((n_cols >= GEMM_MIN_COLS && gemm_supported(type_w, 1, K)) || (type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q8_0)) {       // one launch each
         for (int i = 0; i < n; ++i) if (int rc = launch_mul_mat(w[i], type_w, x, y[i], M[i], K, n_cols, st)) return rc;
         return PKV_OK;
