@@ -96,7 +96,10 @@ def test_mul_mat(pkv, O, tname, M, K, N):
 
 
 @pytest.mark.parametrize("tname,Ms,K,N", [("q4_K", (4096, 1024, 1024), 4096, 1), ("q4_K", (14336, 14336), 4096, 1), ("q4_K", (70, 9, 257, 8), 768, 3),
-                                          ("q8_0", (64, 96), 256, 2), ("q8_0", (2048, 256, 256), 2048, 1), ("q8_0", (5632, 5632), 2048, 3)])
+                                          ("q8_0", (64, 96), 256, 2), ("q8_0", (2048, 256, 256), 2048, 1), ("q8_0", (5632, 5632), 2048, 3),
+                                          # prompt ubatches (>= 16 columns): ONE MFMA launch over the row tiles of all matrices, every tile shape
+                                          ("q8_0", (2048, 256, 256), 2048, 512), ("q4_K", (4096, 1024, 1024), 4096, 130), ("q4_K", (14336, 14336), 4096, 512),
+                                          ("q4_K", (70, 9, 257, 8), 768, 33)])
 def test_mul_mat_multi(pkv, tname, Ms, K, N):
     """pkv_mul_mat_multi == the separate pkv_mul_mat calls, bit for bit (same arithmetic, one launch for q4_K)"""
     t = {"q8_0": 8, "q4_K": 12}[tname]
