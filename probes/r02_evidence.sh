@@ -47,7 +47,7 @@ O_DIR=$O/pmc_prefill bash probes/r02_pmc_prefill.sh r02_final/pmc_prefill > $O/p
 O_ABL=$O bash probes/r02_p_abl.sh > /dev/null 2>&1; cat $O/ablate.txt
 timeout -k 10 120 python3 probes/stamp_prefill.py > $O/prefill_stamps.txt 2>&1; grep tile $O/prefill_stamps.txt
 step "reference runtime end to end through the plugin"
-timeout -k 10 600 python3 tests/evidence/ref_runtime_8b_q4k.py 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/e2e_8b_q4k_plugin.txt; tail -4 $O/e2e_8b_q4k_plugin.txt
+timeout -k 10 600 python3 tests/evidence/ref_runtime_8b_q4k.py --pp 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/e2e_8b_q4k_plugin.txt; tail -4 $O/e2e_8b_q4k_plugin.txt
 timeout -k 10 600 python3 tests/evidence/ref_cpu_tinyllama.py 32 --plugin 2>&1 | grep -v "^llama_\|^print_info\|^init:\|^llm_load\|^load\|^\.\.\.\.\.\|^set_abort" > $O/tinyllama_e2e_plugin.txt; tail -3 $O/tinyllama_e2e_plugin.txt
 step "the reference's harness"
 export GGML_BACKEND_PATH=$PWD/llama.cpp_test_amd/libggml-mi355.so

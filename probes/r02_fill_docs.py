@@ -33,6 +33,9 @@ tl = open(os.path.join(P, "r02_tinyllama_e2e_plugin.txt")).read()
 rep["R2_TINY_PP"] = format(int(re.findall(r"MI355X, TinyLlama.*?pp512: (\d+) tok/s", tl)[-1]), ",")
 rep["R2_TINY_CPUPP"] = re.findall(r"CPU backend.*?pp512: (\d+) tok/s", tl)[-1]
 rep["R2_TINY_CPU"] = "%.0f" % float(re.findall(r"CPU backend.*?tg128: ([\d.]+) tok/s", tl)[-1])
+pl = open(os.path.join(P, "r02_e2e_8b_q4k_plugin.txt")).read()
+m8 = re.findall(r"pp512: (\d+) tok/s", pl)
+rep["R2_PLUGIN_PP"] = format(int(m8[-1]), ",") if m8 else "n/a"
 rep["R2_CPU_ATTN"] = "%.1f" % b["cpu_baseline"]["value"]
 pa, pb = float(pfd.get(("32", "512"), 0)), float(pfd.get(("1", "4096"), 0))
 rep["R2_PREFILL_PCT"] = "%.0f %% / %.0f %%" % (pa / 25, pb / 25)

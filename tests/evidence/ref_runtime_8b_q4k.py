@@ -55,6 +55,21 @@ def run(label, threads, steps):
         step(int(i * 13 % 32000), CTX + 1 + i)
     dt = time.time() - t0
     print(f"{label}: Llama-3-8B geometry, Q4_K weights, f16 KV, 1 seq at ctx {CTX}: {steps / dt:.2f} tok/s ({dt / steps * 1e3:.2f} ms/token)", flush=True)
+    if "--pp" in sys.argv and threads == 16:
+        # llama-bench's pp512 on the same model: ONE llama_decode of 512 tokens into an emptied cache (n_batch = n_ubatch = 512), median of 4
+        L.refmodel_seq_rm.restype = None
+        tok = (np.arange(512, dtype=np.int64) * 7 % 32000).astype(np.int32); pos = np.arange(512, dtype=np.int32); sid = np.zeros(512, np.int32)
+        ts = []
+        for r in range(5):
+            L.refmodel_seq_rm(h, 0, -1, -1)
+            t0 = time.time()
+            assert L.refmodel_decode(h, tok.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), sid.ctypes.data_as(C.c_void_p), 512) == 0
+            lg = np.empty(32000, np.float32)
+            L.refmodel_logits(h, lg.ctypes.data_as(C.c_void_p), 32000)      # synchronises
+            if r:
+                ts.append(time.time() - t0)
+        dtp = float(np.median(ts))
+        print(f"{label}: Llama-3-8B geometry, Q4_K weights, pp512: {512 / dtp:.0f} tok/s ({dtp * 1e3:.1f} ms)", flush=True)
     L.refmodel_free(h)
 
 
