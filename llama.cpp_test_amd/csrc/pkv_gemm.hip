@@ -87,7 +87,7 @@ template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 2
 // blockIdx.x runs over the row tiles of all of them.  A product of a few hundred rows (k, v: 1024 rows at 8B, 256 at TinyLlama) is a handful of
 // workgroups walking all of K in 64-deep steps at one load latency per step — 50 us whatever its size — so it rides along with a large one instead.
 constexpr int GEMM_MAX = 4;
-struct GemmArgs { const unsigned char * w[GEMM_MAX]; float * y[GEMM_MAX]; int64_t M[GEMM_MAX]; int tile_end[GEMM_MAX]; int n; const float * x; int64_t N, K, row_bytes; };
+struct GemmArgs { const unsigned char * w[GEMM_MAX]; float * y[GEMM_MAX]; int64_t M[GEMM_MAX]; int tile_end[GEMM_MAX]; int n; const float * x; int64_t N, K, row_bytes; int ksplit; };   // ksplit 2: blockIdx.z halves K, results added into zeroed y
 
 template <int T, int BM, int BN>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
@@ -126,8 +126,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
             for (int i = 0; i < 8; ++i) rx[i] = reinterpret_cast<const float4 *>(xrow + k0 + 32 * shalf)[i];
         }
     };
-    load_raw(0);
-    for (int64_t k0 = 0; k0 < a.K; k0 += BK) {
+    // split-K (launch_gemm_multi): this workgroup's half of K; with TWO partial sums per element the atomic adds commute exactly (a + b == b + a)
+    const int64_t kbeg = a.ksplit > 1 ? (int64_t) blockIdx.z * (a.K / a.ksplit) : 0, kend = a.ksplit > 1 ? kbeg + a.K / a.ksplit : a.K;
+    load_raw(kbeg);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         {   // conversion of the staged step into LDS
             if (stage_a) {
                 __attribute__((aligned(16))) _Float16 tmp[32];
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
             }
         }
         __syncthreads();
-        if (k0 + BK < a.K) load_raw(k0 + BK);            // the next step's raw bytes fly under this step's MFMAs
+        if (k0 + BK < kend) load_raw(k0 + BK);           // the next step's raw bytes fly under this step's MFMAs
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             half8_t af[TM], bf[TN];
@@ -171,7 +173,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t m = m0 + wm * 32 * TM + i * 32 + 8 * g + 4 * h;
-                if ((aM & 3) == 0 && m + 3 < aM) *reinterpret_cast<float4 *>(ay + (size_t) n * aM + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                if (a.ksplit > 1) {
+                    for (int e = 0; e < 4; ++e) if (m + e < aM) unsafeAtomicAdd(ay + (size_t) n * aM + m + e, acc[i][j][4 * g + e]);
+                } else if ((aM & 3) == 0 && m + 3 < aM) *reinterpret_cast<float4 *>(ay + (size_t) n * aM + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                 else
                     for (int e = 0; e < 4; ++e) if (m + e < aM) ay[(size_t) n * aM + m + e] = acc[i][j][4 * g + e];
             }
@@ -212,7 +216,15 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
     const int bm = shape == 0 ? 128 : 64, bn = shape == 2 ? 64 : 128;
     int tot = 0;
     for (int i = 0; i < a.n; ++i) { tot += (int) ((a.M[i] + bm - 1) / bm); a.tile_end[i] = tot; }
-    const dim3 grid((unsigned) tot, (unsigned) ((n_cols + bn - 1) / bn));
+    // a long K over very few tiles (16 - 64 columns: 64 workgroups walking all of K at one load latency per step): two workgroups per tile, each
+    // half of K, added into the zeroed output (two addends per element: the result does not depend on their order): 4096^2 x 32, 65 -> 40 us.
+    // Not at hundreds of columns: there the 4 M atomic adds cost more than the idle CUs did (4096^2 x 512: 84 -> 175 us).
+    a.ksplit = 1;
+    if (shape == 2 && n_cols <= 64 && (int64_t) tot * ((n_cols + bn - 1) / bn) <= 768 && K >= 4096 && K % 512 == 0 && !getenv("PKV_GEMM_NO_SPLITK")) {
+        a.ksplit = 2;
+        for (int i = 0; i < a.n; ++i) PKV_HIP(hipMemsetAsync(a.y[i], 0, (size_t) a.M[i] * n_cols * sizeof(float), st));
+    }
+    const dim3 grid((unsigned) tot, (unsigned) ((n_cols + bn - 1) / bn), (unsigned) a.ksplit);
 #define PKV_GEMM(T_) do { if (shape == 0) hipLaunchKernelGGL((gemm_kernel<T_, 128, 128>), grid, dim3(256), 0, st, a); \
                           else if (shape == 1) hipLaunchKernelGGL((gemm_kernel<T_, 64, 128>), grid, dim3(256), 0, st, a); \
                           else hipLaunchKernelGGL((gemm_kernel<T_, 64, 64>), grid, dim3(256), 0, st, a); } while (0)
