@@ -27,6 +27,7 @@
 #include "pkv_rowcodec.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace pkv {
@@ -345,6 +346,61 @@ struct VStage<PKV_TYPE_F16, D, NT> {
     }
 };
 
+// q8_0 V, wide form: the pool tile is [group of 4 tokens][d] dwords (+ 4 f16 token scales per group and 32 columns).  A thread loads 16 bytes = one group x
+// 4 columns and the group's 4 scales (2 + 2 load instructions per wave and tile where the per-(d, kg) form issues 16), dequantizes each dword (4 tokens of
+// one column) with packed f16 arithmetic and stores it as one 8-byte half chunk: lanes 0-15 of a store take the 16 groups of ONE column = the row's 128
+// bytes = every bank once.  Unit q = wave * NI + i: columns 16 q .. 16 q + 15.
+template <int D, int NT>
+struct VStageQ8W {
+    static constexpr int TL = 4;
+    static constexpr int NW = NT / 64, NU = (KVT / 4) * (D / 4) / 64, NI = NU / NW;
+    static_assert(NU % NW == 0 && (NI == 1 || NI % 2 == 0), "units must divide evenly over the waves");
+    u4_t raw[NI];
+    u2_t sc[NI];
+    int  nval_;
+    static __device__ __forceinline__ int u_t(int tid) { return (tid >> 6) * NI; }              // first unit of the thread's wave
+    static __device__ __forceinline__ int goff(int tid) { const int l = tid & 63; return ((l & 15) * D + ((l >> 4) + 4 * u_t(tid)) * 4) * 4; }
+    static __device__ __forceinline__ int soff(int tid) { const int l = tid & 63; return ((l & 15) * (D / PKV_QK) + (NI == 1 ? u_t(tid) >> 1 : u_t(tid) / 2)) * 8; }
+    static __device__ __forceinline__ int u0t(int tid) { return 4 * (tid & 15); }                // first token of the thread's group
+    static __device__ __forceinline__ int woff(int tid) {
+        const int l = tid & 63, g = l & 15, u = u_t(tid);
+        const int kg = (g >> 3) * 4 + ((g >> 2) & 1) * 2 + (g & 1), jh = (g >> 1) & 1;
+        return (4 * (l >> 4)) * (KVT * 2) + u * 16 * (KVT * 2) + ((kg ^ (4 * ((l >> 4) & 1)) ^ (u & 1)) & 7) * 16 + jh * 8;
+    }
+    __device__ __forceinline__ void load(rsrc_t rs, rsrc_t rs_s, int n_rows_valid, int go, int so) {
+        nval_ = n_rows_valid;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, go, 64 * i, 0);
+            sc[i]  = __builtin_amdgcn_raw_buffer_load_b64(rs_s, so, (NI == 1 ? 0 : i >> 1) * 8, 0);
+        }
+    }
+    __device__ __forceinline__ void write(char * lds, int wo, int u0) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            uint32_t k01 = 0xFFFFFFFFu, k23 = 0xFFFFFFFFu;
+            if (nval_ < KVT) {                           // workgroup-uniform: only a sequence's last tile
+                k01 = u0 >= nval_ ? 0u : (u0 + 1 >= nval_ ? 0xFFFFu : 0xFFFFFFFFu);
+                k23 = u0 + 2 >= nval_ ? 0u : (u0 + 3 >= nval_ ? 0xFFFFu : 0xFFFFFFFFu);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t o0, o1;
+                dq4(w[e] ^ 0x80808080u, 1152.0f, as_h2(sc[i].x), as_h2(sc[i].y), o0, o1);
+                const int x = ((e ^ (i & 1)) & 7) * 16, y = e * (KVT * 2) + i * 16 * (KVT * 2);
+                *reinterpret_cast<uint2 *>(lds + ((wo ^ x) + y)) = make_uint2(o0 & k01, o1 & k23);
+            }
+        }
+    }
+};
+template <int VT, int D, int NT> struct VPick { using type = VStage<VT, D, NT>; };
+template <int D, int NT> struct VPick<PKV_TYPE_Q8_0, D, NT> {
+    static constexpr int NU = (KVT / 4) * (D / 4) / 64, NW = NT / 64;
+    static constexpr bool wide = NU % NW == 0 && (NU / NW == 1 || (NU / NW) % 2 == 0);
+    using type = typename std::conditional<wide, VStageQ8W<D, NT>, VStage<PKV_TYPE_Q8_0, D, NT>>::type;
+};
+
 // QB = 32-query blocks per wave.  QB = 2 (one wave per SIMD, the whole 512-entry register file; built with -amdgpu-mfma-vgpr-form, see the
 // Makefile): every K / V^T fragment read from LDS feeds TWO MFMAs, and a staged KV tile, a barrier and a table lookup serve 64 queries per head
 // instead of 32.  Measured slower than QB = 1 at two waves per SIMD (launch_attn_prefill): opt-in experiment.
@@ -421,7 +477,7 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
     const int vsw = vswz(r) ^ h;             // swizzle of this lane's V^T rows (d = 32 dt + r: the same for every dt), its k half folded in
     const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
     using KSt = KStage<KT, D, NT>;
-    using VSt = VStage<VT, D, NT>;
+    using VSt = typename VPick<VT, D, NT>::type;
     KSt kst;
     VSt vst;
     int k_go = 0, k_so = 0;
