@@ -91,12 +91,22 @@ class AttnPathRunner:
         if not regular:
             raise PkvError(-5, "irregular sequence (holes / shifted cells): call defrag() + update() first")
         bt = bt[:, :max(1, mb)]
-        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
         all_decode = bool((n_q == 1).all())
-        dpos = dev(p)
+        # the ubatch's six small tables in ONE upload (each H2D copy is ~5 us of the stream's time: 6 of them were 4 % of a 32-sequence decode step)
+        parts = [np.asarray(blk, np.int32).ravel(), np.asarray(off, np.int32).ravel(), p, np.asarray(sl, np.int32), np.asarray(starts, np.int32),
+                 np.ascontiguousarray(bt, np.int32).ravel()]
+        offs, tot = [], 0
+        for a in parts:
+            offs.append(tot)
+            tot += -(-a.size // 4) * 4                               # 16-byte aligned pieces
+        host = np.zeros(tot, np.int32)
+        for a, o in zip(parts, offs):
+            host[o:o + a.size] = a
+        dall = torch.from_numpy(host).cuda()
+        d_blk, d_off, dpos, d_sl, d_qs, d_bt = (dall[o:o + a.size] for a, o in zip(parts, offs))
         return dict(n_tok=n_tok, n_seq=len(seqs), max_q=int(n_q.max()), all_decode=all_decode,
-                    max_seq_len=int(sl.max()), slot_block=dev(blk), slot_off=dev(off), pos=dpos, block_table=dev(bt),
-                    seq_lens=dev(sl), q_start=dev(np.asarray(starts, np.int32)),
+                    max_seq_len=int(sl.max()), slot_block=d_blk, slot_off=d_off, pos=dpos, block_table=d_bt.view(bt.shape[0], bt.shape[1]),
+                    seq_lens=d_sl, q_start=d_qs,
                     # ggml_rope_cache_init once per ubatch, shared by every layer's fused decode step
                     # ggml_rope_cache_init once per ubatch, shared by every layer's fused step (decode: attn_decode_step; prefill, NORM pairs: attn_prefill_step)
                     rope_cache=rope_cache(dpos, self.rope, self.D) if (with_rope_cache and (all_decode or self.fused_prefill)) else None)
