@@ -10,7 +10,8 @@
 //   workgroup = 128 (m) x 128 (n) outputs, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers); 64 x 128 and 64 x 64 tiles
 //   where the launch would otherwise leave CUs without a second workgroup (launch_gemm);
 //   K in steps of 64: thread t stages row t >> 1, 32-element half t & 1 of BOTH operands — one q4_K / q6_K sub-block (or q8_0 block, or 32 halfs)
-//   of W, 32 floats of x — raw loads issued one step ahead of the conversion (issue early / write late), two barriers per step;
+//   of W, 32 floats of x — raw loads issued one step ahead of the conversion (issue early / write late) into the OTHER of two LDS images per operand:
+//   ONE barrier per step, the stores run under the step's MFMAs (r02: q8_0 / q6_K +25 ... +45 % at 4096 rows, tall matrices 32000 x 2048 +57 ... +68 %);
 //   LDS rows of 64 f16 padded to 144 B: the 16-byte fragment reads (lane = row r, k = 8 h + ..) are conflict-free;
 //   fragments per cdna_hip_programming.md §3: A[row r][k = 8 h + j], B[k = 8 h + j][col r]; C col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h,
 //   so a lane owns 4 consecutive m of one token n per register group: float4 stores into y[n][m].
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     // waves along m / n and MFMA tiles per wave along m / n: 128 x 128: 2 x 2 waves of 2 x 2 tiles; 64 x 128: 1 x 4 of 2 x 1; 64 x 64: 2 x 2 of 1 x 1
     constexpr int WM = BN == 64 ? 2 : BM / 64, WN = 4 / WM, TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1 && WM * WN == 4, "tile shape");
-    __shared__ __attribute__((aligned(16))) _Float16 sA[BM * LDR], sB[BN * LDR];
+    __shared__ __attribute__((aligned(16))) _Float16 sAb[2][BM * LDR], sBb[2][BN * LDR];   // two images per operand: ONE barrier per K-step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave % WM, wn = wave / WM;
     const int r = lane & 31, h = lane >> 5;
     int mi = 0;
@@ -128,27 +129,34 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     };
     // split-K (launch_gemm_multi): this workgroup's half of K; with TWO partial sums per element the atomic adds commute exactly (a + b == b + a)
     const int64_t kbeg = a.ksplit > 1 ? (int64_t) blockIdx.z * (a.K / a.ksplit) : 0, kend = a.ksplit > 1 ? kbeg + a.K / a.ksplit : a.K;
-    load_raw(kbeg);
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        {   // conversion of the staged step into LDS
-            if (stage_a) {
-                __attribute__((aligned(16))) _Float16 tmp[32];
-                rw.to_half(tmp, k0 + 32 * shalf);
-                uint4 * da = reinterpret_cast<uint4 *>(sA + srow * LDR + 32 * shalf);
+    auto stage = [&](int64_t k0, _Float16 * sA, _Float16 * sB) {   // conversion of the loaded step into an LDS image pair
+        if (stage_a) {
+            __attribute__((aligned(16))) _Float16 tmp[32];
+            rw.to_half(tmp, k0 + 32 * shalf);
+            uint4 * da = reinterpret_cast<uint4 *>(sA + srow * LDR + 32 * shalf);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) da[i] = reinterpret_cast<const uint4 *>(tmp)[i];
-            }
-            if (stage_b) {
-                __attribute__((aligned(16))) _Float16 tb[32];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { tb[4 * i] = (_Float16) rx[i].x; tb[4 * i + 1] = (_Float16) rx[i].y; tb[4 * i + 2] = (_Float16) rx[i].z; tb[4 * i + 3] = (_Float16) rx[i].w; }
-                uint4 * db = reinterpret_cast<uint4 *>(sB + srow * LDR + 32 * shalf);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) db[i] = reinterpret_cast<const uint4 *>(tb)[i];
-            }
+            for (int i = 0; i < 4; ++i) da[i] = reinterpret_cast<const uint4 *>(tmp)[i];
         }
-        __syncthreads();
-        if (k0 + BK < kend) load_raw(k0 + BK);           // the next step's raw bytes fly under this step's MFMAs
+        if (stage_b) {
+            __attribute__((aligned(16))) _Float16 tb[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { tb[4 * i] = (_Float16) rx[i].x; tb[4 * i + 1] = (_Float16) rx[i].y; tb[4 * i + 2] = (_Float16) rx[i].z; tb[4 * i + 3] = (_Float16) rx[i].w; }
+            uint4 * db = reinterpret_cast<uint4 *>(sB + srow * LDR + 32 * shalf);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) db[i] = reinterpret_cast<const uint4 *>(tb)[i];
+        }
+    };
+    load_raw(kbeg);
+    stage(kbeg, sAb[0], sBb[0]);
+    if (kbeg + BK < kend) load_raw(kbeg + BK);
+    int it = 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK, ++it) {
+        const _Float16 * sA = sAb[it & 1], * sB = sBb[it & 1];
+        __syncthreads();                                  // image `it` is complete; everyone is done reading image it - 1 (the other one)
+        if (k0 + BK < kend) {
+            stage(k0 + BK, sAb[(it + 1) & 1], sBb[(it + 1) & 1]);   // the step loaded a whole step ago -> the other image, under this step's MFMAs
+            if (k0 + 2 * BK < kend) load_raw(k0 + 2 * BK);
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             half8_t af[TM], bf[TN];
@@ -161,7 +169,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
     // C: col (token) = lane & 31, row (m) = (reg & 3) + 8 (reg >> 2) + 4 h
 #pragma unroll
@@ -211,7 +218,8 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
     // q8_0 / q6_K, whose conversion is a float multiply per element)
     const bool cheap = type_w == PKV_TYPE_F16 || type_w == PKV_TYPE_Q4_K;
     // (... unless even 64-row tiles leave the chip short of one workgroup per CU: TinyLlama's 2048-row matrices, q8_0 71 -> 87, q6_K 54 -> 70 TFLOP/s)
-    int shape = t128 >= 256 ? 0 : ((t64 >= 512 || (!cheap && t64 >= 256)) ? 1 : 2);
+    int shape = t128 >= 256 ? 0 : (t64 >= 256 ? 1 : 2);   // (with two LDS images per operand 64 x 128 is as fast as 64 x 64 was for f16 / q4_K at 4096 rows, and 25-45 % faster for q8_0 / q6_K)
+    (void) cheap;
     if (const char * e = getenv("PKV_GEMM_SHAPE")) shape = atoi(e) % 3;   // experiments
     const int bm = shape == 0 ? 128 : 64, bn = shape == 2 ? 64 : 128;
     int tot = 0;
