@@ -245,12 +245,13 @@ def e2e_record(pkv, torch, *, ctx: int, steps: int, warmup: int, cpu: bool):
         finite = bool(torch.isfinite(dec.logits).all().item())
         n_types = {}
         for name, (t, ty, ne) in dec.w.items():
-            n_types[ty] = n_types.get(ty, 0) + t.numel()
+            n_types[ty & ~pkv.PACKED] = n_types.get(ty & ~pkv.PACKED, 0) + t.numel()
         rec = {"value": round(1.0 / dt, 2), "unit": "tok/s", "ms_per_token": round(dt * 1e3, 4), "steps": steps, "warmup": warmup,
                "workload": f"Llama-3-8B geometry, Q4_K_M tensor mix (synthetic GGUF {os.path.getsize(path) / 2**30:.2f} GiB: "
                            + ", ".join(f"{ {0: 'f32', 12: 'q4_K', 14: 'q6_K'}.get(k, k)} {v / 2**20:.0f} MiB" for k, v in sorted(n_types.items()))
                            + f"), f16 KV, 1 sequence at ctx {ctx}, single-token decode incl. lm_head",
                "host_loop": "llama.cpp_test_amd/decoder.py through the C ABI, one hipGraph per token (own GGUF loader; no reference code)",
+               "weight_layout": "K-quant rows re-laid inside their own bytes at upload (plane layout, csrc/pkv_wlayout.h; pkv_weights_pack)",
                "logits_finite": finite, "weight_bytes": wb, "kv_bytes": kvb, "setup_s": {"synth_gguf": round(t_gen, 1), "load_fill_capture": round(t_load, 1)},
                "roofline": {"bound": "hbm", "achieved": round((wb + kvb) / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round((wb + kvb) / dt / 1e9 / HBM_PEAK_GBS, 4)}}

@@ -410,6 +410,14 @@ int pkv_quantize_act(const float * x, void * image, int64_t K, void * stream);
 /* x_out = x + res (res, x_out both or neither; x_out may alias x), image = quantize(rms_norm(x_out) * w); y (optional) = the f32 row */
 int pkv_rms_norm_mul_q(const float * x, const float * res, float * x_out, const float * w, float * y, void * image, int64_t ne0, float eps, void * stream);
 int pkv_gemv_q(const pkv_gemv * g, void * stream);
+/* PLANE layout of K-quant weight rows (csrc/pkv_wlayout.h): the same bytes re-laid INSIDE each row at upload so that a wave instruction of the
+ * decode-step products reads 1 KiB of contiguous bytes per plane (q4_K row: [16 B of low-half nibbles per 64-element group][16 B of the other half]
+ * [16-byte block headers]; q6_K row: [ql lo][ql hi][qh][scales][d]) — the GGUF block order puts every lane's load at a 144- / 210-byte stride.
+ * Precedent: the reference's CPU backend repacks weights on set_tensor (/ref/ggml/src/ggml-cpu/ggml-cpu-aarch64.cpp:3663-3810, :4145-4172).
+ * A packed tensor is named by `type | PKV_TYPE_PACKED` in pkv_gemv.type_w[], pkv_mul_mat, pkv_mul_mat_multi and pkv_get_rows; results are bit-identical
+ * to the GGUF-order tensor's.  pkv_weights_pack converts n_rows rows of K elements (src != dst; inverse = 1: back to GGUF order, byte-exact). */
+#define PKV_TYPE_PACKED 0x100
+int pkv_weights_pack(const void * src, void * dst, int type, int64_t n_rows, int64_t K, int inverse, void * stream);
 /* ggml_get_rows (/ref/src/llama-model.cpp:4047: inp_embd = get_rows(tok_embd, tokens)): out[i][:] = dequantize(row ids[i] of w);
  * w = n_rows_w rows of K elements in f32 / f16 / q8_0 / q4_K / q6_K; ids device i32 [n_ids]; out device f32 [n_ids][K] */
 int pkv_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, void * stream);

@@ -30,6 +30,7 @@ F32, F16, Q4_0, Q8_0, Q4_K, Q6_K = 0, 1, 2, 8, 12, 14
 TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q6_K": Q6_K}
 # enum pkv_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SPACE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+PACKED = 0x100          # PKV_TYPE_PACKED: K-quant rows in the plane layout (csrc/pkv_wlayout.h), produced by weights_pack()
 ATTN_NO_COMBINE = 1
 ATTN_FUSED_COMBINE = 2
 ATTN_NONCAUSAL = 4
@@ -564,6 +565,55 @@ def gemv_q(ws, types, Ms, K: int, image, outs, *, residual=None, silu_mul: bool 
         g.type_w[i], g.w[i], g.y[i], g.M[i] = int(types[i]), _ptr(ws[i]), _ptr(outs[i] if i < len(outs) else outs[0]), int(Ms[i])
     check(lib().pkv_gemv_q(C.byref(g), C.c_void_p(_stream(stream))))
     return outs
+
+
+def weights_pack(w, type_w: int, n_rows: int, K: int, *, inverse: bool = False, out=None, stream=None):
+    """pkv_weights_pack: GGUF-order q4_K / q6_K rows (device bytes) -> the plane layout the decode-step products stream (`type | PACKED`), or back
+    (inverse=True, byte-exact).  Returns a new device byte tensor."""
+    import torch
+    out = torch.empty_like(w) if out is None else out
+    check(lib().pkv_weights_pack(C.c_void_p(_ptr(w)), C.c_void_p(_ptr(out)), int(type_w) & ~PACKED, C.c_int64(n_rows), C.c_int64(K), C.c_int(int(inverse)),
+                                 C.c_void_p(_stream(stream))))
+    return out
+
+
+def pack_rows_host(rows: np.ndarray, type_w: int, K: int, inverse: bool = False) -> np.ndarray:
+    """host restatement of the plane layout (csrc/pkv_wlayout.h) for tests: rows = uint8 [n_rows][row_bytes] in GGUF order -> packed (or back)"""
+    gpr = K // 64
+    nb = K // 256
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n = rows.shape[0]
+    if type_w == Q4_K:
+        if not inverse:
+            blk = rows.reshape(n, nb, 144)
+            hdr = blk[:, :, :16].reshape(n, nb * 16)
+            qs = blk[:, :, 16:].reshape(n, nb, 4, 2, 16)                    # [block][p][half][16]
+            qa = qs[:, :, :, 0, :].reshape(n, gpr * 16)
+            qb = qs[:, :, :, 1, :].reshape(n, gpr * 16)
+            return np.concatenate([qa, qb, hdr], axis=1)
+        qa = rows[:, :16 * gpr].reshape(n, nb, 4, 1, 16)
+        qb = rows[:, 16 * gpr:32 * gpr].reshape(n, nb, 4, 1, 16)
+        hdr = rows[:, 32 * gpr:].reshape(n, nb, 16)
+        qs = np.concatenate([qa, qb], axis=3).reshape(n, nb, 128)
+        return np.concatenate([hdr, qs], axis=2).reshape(n, nb * 144)
+    if type_w == Q6_K:
+        if not inverse:
+            blk = rows.reshape(n, nb, 210)
+            ql = blk[:, :, :128].reshape(n, nb, 2, 2, 2, 16)                 # [block][n][hi][is][16]
+            la = ql[:, :, :, 0, :, :].reshape(n, gpr * 16)
+            lb = ql[:, :, :, 1, :, :].reshape(n, gpr * 16)
+            hh = blk[:, :, 128:192].reshape(n, gpr * 16)                     # [block][n][is][16] is already item order
+            sc = blk[:, :, 192:208].reshape(n, nb * 16)
+            d = blk[:, :, 208:210].reshape(n, nb * 2)
+            return np.concatenate([la, lb, hh, sc, d], axis=1)
+        la = rows[:, :16 * gpr].reshape(n, nb, 2, 1, 2, 16)
+        lb = rows[:, 16 * gpr:32 * gpr].reshape(n, nb, 2, 1, 2, 16)
+        hh = rows[:, 32 * gpr:48 * gpr].reshape(n, nb, 64)
+        sc = rows[:, 48 * gpr:48 * gpr + 16 * nb].reshape(n, nb, 16)
+        d = rows[:, 52 * gpr:].reshape(n, nb, 2)
+        ql = np.concatenate([la, lb], axis=3).reshape(n, nb, 128)
+        return np.concatenate([ql, hh, sc, d], axis=2).reshape(n, nb * 210)
+    raise ValueError("pack_rows_host: q4_K / q6_K only")
 
 
 def get_rows(w, type_w: int, ids, K: int, n_rows_w: int, out=None, stream=None):

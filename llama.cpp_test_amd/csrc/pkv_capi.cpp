@@ -571,22 +571,25 @@ int pkv_soft_max_ext_f32(const float * x, const void * mask, int mask_f16, float
     PKV_REQUIRE(x && y && ne00 > 0 && ne01 >= 0 && ne02 > 0 && ne03 > 0 && max_bias >= 0.0f, "pkv_soft_max_ext_f32: bad arguments");
     return launch_soft_max(x, mask, mask_f16, y, ne00, ne01, ne02, ne03, scale, max_bias, (hipStream_t) stream);
 }
-int pkv_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream) {
+static bool packed_type_ok(int type_w) { const int bt = type_w & ~PKV_TYPE_PACKED; return type_w == bt || bt == PKV_TYPE_Q4_K || bt == PKV_TYPE_Q6_K; }
+int pkv_mul_mat(const void * w, int type_wf, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream) {
     if (int rc = ensure_device()) return rc;
-    PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0, "pkv_mul_mat: bad arguments");
+    PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0 && packed_type_ok(type_wf), "pkv_mul_mat: bad arguments");
+    const int type_w = type_wf & ~PKV_TYPE_PACKED;
     PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : ((type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K) ? 256 : PKV_QK))) == 0 &&
                 ((uintptr_t) x % 16) == 0 && ((uintptr_t) w % ((type_w == PKV_TYPE_Q8_0 || type_w == PKV_TYPE_Q6_K) ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
-    return launch_mul_mat(w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
+    return launch_mul_mat(w, type_wf, x, y, M, K, n_cols, (hipStream_t) stream);
 }
-int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
+int pkv_mul_mat_multi(int n, const void * const * w, int type_wf, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols,
                       void * stream) {
     if (int rc = ensure_device()) return rc;
-    PKV_REQUIRE(n >= 1 && n <= PKV_MUL_MAT_MAX && w && x && y && M && K > 0 && n_cols >= 0, "pkv_mul_mat_multi: bad arguments");
+    PKV_REQUIRE(n >= 1 && n <= PKV_MUL_MAT_MAX && w && x && y && M && K > 0 && n_cols >= 0 && packed_type_ok(type_wf), "pkv_mul_mat_multi: bad arguments");
+    const int type_w = type_wf & ~PKV_TYPE_PACKED;
     PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : (type_w == PKV_TYPE_Q4_K ? 256 : PKV_QK))) == 0 && ((uintptr_t) x % 16) == 0,
                 "pkv_mul_mat_multi: K / alignment not supported");
     for (int i = 0; i < n; ++i)
         PKV_REQUIRE(w[i] && y[i] && M[i] >= 0 && ((uintptr_t) w[i] % (type_w == PKV_TYPE_Q8_0 ? 2 : 16)) == 0, "pkv_mul_mat_multi: bad product %d", i);
-    return launch_mul_mat_multi(n, w, type_w, x, y, M, K, n_cols, (hipStream_t) stream);
+    return launch_mul_mat_multi(n, w, type_wf, x, y, M, K, n_cols, (hipStream_t) stream);
 }
 
 size_t pkv_act_image_bytes(int64_t K) { return act_image_bytes(K); }
@@ -608,10 +611,15 @@ int pkv_gemv_q(const pkv_gemv * g, void * stream) {
         PKV_REQUIRE(((uintptr_t) g->w[i] % 16) == 0, "pkv_gemv_q: weight matrix %d must be 16-byte aligned", i);
     return launch_gemv(*g, (hipStream_t) stream);
 }
+int pkv_weights_pack(const void * src, void * dst, int type, int64_t n_rows, int64_t K, int inverse, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    return launch_pack_rows(src, dst, type, n_rows, K, inverse, (hipStream_t) stream);
+}
 int pkv_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(w && ids && out && n_ids >= 0 && K > 0 && n_rows_w > 0, "pkv_get_rows: bad arguments");
-    PKV_REQUIRE(K % (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K ? 256 : (type_w == PKV_TYPE_Q8_0 ? 32 : 1)) == 0, "pkv_get_rows: K does not fill whole blocks");
+    { const int bt = type_w & ~PKV_TYPE_PACKED;
+      PKV_REQUIRE(packed_type_ok(type_w) && K % (bt == PKV_TYPE_Q4_K || bt == PKV_TYPE_Q6_K ? 256 : (bt == PKV_TYPE_Q8_0 ? 32 : 1)) == 0, "pkv_get_rows: K does not fill whole blocks"); }
     return launch_get_rows(w, type_w, ids, out, n_ids, K, n_rows_w, (hipStream_t) stream);
 }
 

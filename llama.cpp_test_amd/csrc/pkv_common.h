@@ -144,6 +144,7 @@ int launch_convert_rows(const float * x, void * dst, int type, int64_t n_rows, i
 size_t act_image_bytes(int64_t K);
 int launch_quantize_act(const float * x, void * img, int64_t K, hipStream_t st);
 int launch_gemv(const pkv_gemv & g, hipStream_t st);
+int launch_pack_rows(const void * src, void * dst, int type, int64_t n_rows, int64_t K, int inverse, hipStream_t st);
 int launch_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, hipStream_t st);
 int launch_rms_norm_mul_q(const float * x, const float * res, float * x_out, const float * w, float * y, void * img, int64_t ne0, float eps, hipStream_t st);
 int launch_qkv_store_mirror(const pkv_qkv_store_args * p, const RopeDev & r, hipStream_t st);

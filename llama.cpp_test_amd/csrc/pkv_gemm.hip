@@ -31,6 +31,7 @@ __device__ __forceinline__ float hf(uint16_t b) { return (float) *reinterpret_ca
 __device__ __forceinline__ uint4 ldu(const unsigned char * p) { return *reinterpret_cast<const uint4 *>(p); }
 
 // raw bytes of 32 consecutive weights of one row (k0 a multiple of 32), and their conversion to 32 halfs
+// T may carry PKV_TYPE_PACKED: the row is in the plane layout of pkv_wlayout.h (same bytes, same conversion; only load() differs)
 template <int T> struct RawW;
 template <> struct RawW<PKV_TYPE_F16> {
     uint4 q[4];
@@ -66,6 +67,10 @@ template <> struct RawW<PKV_TYPE_Q4_K> {   // block_q4_K (:279-290): sub-block j
         for (int i = 0; i < 32; ++i) o[i] = (_Float16) (d1 * (float) ((b[i] >> s4) & 0xF) - m1);
     }
 };
+template <> struct RawW<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> : RawW<PKV_TYPE_Q4_K> {
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0, int64_t K) { const size_t gpr = (size_t) (K >> 6), g = (size_t) (k0 >> 6);   // group g = 4 b + (j >> 1)
+        h = ldu(row + 32 * gpr + 16 * (g >> 2)); q[0] = ldu(row + 16 * g); q[1] = ldu(row + 16 * gpr + 16 * g); }
+};
 template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 256, n = e0 / 128, j = (e0 % 128) / 32: ql[64 n + 32 (j & 1) + l] nibble j >> 1, qh[32 n + l] bits 2 j
     uint4 ql[2], qh[2]; uint16_t sc2, d;
     __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 8) * 210; const int e0 = (int) (k0 & 255), n = e0 >> 7, j = (e0 & 127) >> 5;
@@ -82,6 +87,15 @@ template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 2
             o[i] = (_Float16) ((i < 16 ? s0 : s1) * (float) qv);
         }
     }
+};
+
+template <> struct RawW<(PKV_TYPE_Q6_K | PKV_TYPE_PACKED)> : RawW<PKV_TYPE_Q6_K> {
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0, int64_t K) {
+        const size_t gpr = (size_t) (K >> 6), b = (size_t) (k0 >> 8); const int e0 = (int) (k0 & 255), n = e0 >> 7, j = (e0 & 127) >> 5;
+        const size_t it = 4 * b + 2 * n;                                                        // items (b, n, is = 0 / 1): 32 contiguous bytes of a plane
+        const unsigned char * pl = row + (size_t) (j & 1) * 16 * gpr + 16 * it, * ph = row + 32 * gpr + 16 * it;
+        ql[0] = ldu(pl); ql[1] = ldu(pl + 16); qh[0] = ldu(ph); qh[1] = ldu(ph + 16);
+        sc2 = *reinterpret_cast<const uint16_t *>(row + 48 * gpr + 16 * b + 8 * n + 2 * j); d = *reinterpret_cast<const uint16_t *>(row + 52 * gpr + 2 * b); }
 };
 
 // up to GEMM_MAX matrices of one weight type against the same activations in ONE launch (q + k, gate + up of a llama layer: launch_mul_mat_multi):
@@ -121,7 +135,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     RawW<T> rw;
     float4 rx[8];
     auto load_raw = [&](int64_t k0) {
-        if (stage_a) rw.load(wrow, k0 + 32 * shalf);
+        if (stage_a) { if constexpr ((T & PKV_TYPE_PACKED) != 0) rw.load(wrow, k0 + 32 * shalf, a.K); else rw.load(wrow, k0 + 32 * shalf); }
         if (stage_b) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) rx[i] = reinterpret_cast<const float4 *>(xrow + k0 + 32 * shalf)[i];
@@ -192,6 +206,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
 }  // namespace
 
 bool gemm_supported(int type_w, int64_t M, int64_t K) {
+    type_w &= ~PKV_TYPE_PACKED;
     if (type_w != PKV_TYPE_F16 && type_w != PKV_TYPE_Q8_0 && type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q6_K) return false;
     return M > 0 && K > 0 && K % BK == 0 && (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K ? K % 256 == 0 : true);
 }
@@ -202,7 +217,7 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
     if (!gemm_supported(type_w, 1, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
     PKV_REQUIRE(((uintptr_t) x % 16) == 0, "pkv_mul_mat (batched): x must be 16-byte aligned");
     GemmArgs a = {};
-    a.x = x; a.N = n_cols; a.K = K; a.row_bytes = (int64_t) row_size(type_w, K);
+    a.x = x; a.N = n_cols; a.K = K; a.row_bytes = (int64_t) row_size(type_w & ~PKV_TYPE_PACKED, K);
     int64_t r128 = 0, r64 = 0;
     for (int i = 0; i < n; ++i) {
         if (M[i] == 0) continue;
@@ -216,7 +231,7 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
     const int64_t t128 = r128 * ((n_cols + 127) / 128), t64 = r64 * ((n_cols + 127) / 128);
     // (64 x 64 doubles the dequantization per MFMA: it pays for f16 and q4_K weights, +21 ... +29 % at 4096 rows x 512 columns, and loses 10-14 % for
     // q8_0 / q6_K, whose conversion is a float multiply per element)
-    const bool cheap = type_w == PKV_TYPE_F16 || type_w == PKV_TYPE_Q4_K;
+    const bool cheap = type_w == PKV_TYPE_F16 || (type_w & ~PKV_TYPE_PACKED) == PKV_TYPE_Q4_K;
     // (... unless even 64-row tiles leave the chip short of one workgroup per CU: TinyLlama's 2048-row matrices, q8_0 71 -> 87, q6_K 54 -> 70 TFLOP/s)
     int shape = t128 >= 256 ? 0 : (t64 >= 256 ? 1 : 2);   // (with two LDS images per operand 64 x 128 is as fast as 64 x 64 was for f16 / q4_K at 4096 rows, and 25-45 % faster for q8_0 / q6_K)
     (void) cheap;
@@ -241,6 +256,8 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
         case PKV_TYPE_Q8_0: PKV_GEMM(PKV_TYPE_Q8_0); break;
         case PKV_TYPE_Q4_K: PKV_GEMM(PKV_TYPE_Q4_K); break;
         case PKV_TYPE_Q6_K: PKV_GEMM(PKV_TYPE_Q6_K); break;
+        case PKV_TYPE_Q4_K | PKV_TYPE_PACKED: PKV_GEMM((PKV_TYPE_Q4_K | PKV_TYPE_PACKED)); break;
+        case PKV_TYPE_Q6_K | PKV_TYPE_PACKED: PKV_GEMM((PKV_TYPE_Q6_K | PKV_TYPE_PACKED)); break;
     }
 #undef PKV_GEMM
     PKV_HIP(hipGetLastError());

@@ -13,6 +13,9 @@
 // r01's products (pkv_layer_ops.hip) re-staged and re-quantized the column in every 8-row workgroup: 16 KB of activations per 18 KB of
 // weights, 0.18-0.39 of HBM peak.
 #include "pkv_common.h"
+#include "pkv_wlayout.h"
+
+#include <algorithm>
 
 // every instantiation of the product kernel must round a given row identically (one launch for wq + wk + wv == three launches, bit for bit):
 // no implicit FMA contraction anywhere in this file
@@ -189,18 +192,18 @@ __device__ __forceinline__ float wsum_dpp(float x) {
 #endif
 typedef unsigned gv_u4 __attribute__((ext_vector_type(4)));
 #ifndef PKV_GEMV_NT
-#define PKV_GEMV_NT 0
+#define PKV_GEMV_NT 1       // packed rows only: every 128-byte line is consumed by ONE wave instruction (GGUF-order rows: 2-3 instructions per line, nt lost 40 %)
 #endif
-__device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
-#if PKV_GEMV_NT
-    const gv_u4 v = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *reinterpret_cast<const uint4 *>(p);
-#endif
+template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
+    if constexpr (NT) {
+        const gv_u4 v = __builtin_nontemporal_load(reinterpret_cast<const gv_u4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const uint4 *>(p);
+    }
 }
 #define PKV_UNIT_DECL(S) uint4 S##r0[UI], S##r1[UI], S##r2[UI], S##r3[UI]; uint16_t S##dh[UI]; int S##g[UI], S##p[UI], S##ty[UI], S##rs[UI]; bool S##ok[UI]; int S##mi; int64_t S##m0;
-#define PKV_UNIT_LOAD(S, RPI, FI)                                                                                                              \
+#define PKV_UNIT_LOAD(S, RPI, FI, PAST)                                                                                                           \
     {                                                                                                                                          \
         const int rp_ = first + __builtin_amdgcn_readfirstlane(RPI) * stride, f0_ = __builtin_amdgcn_readfirstlane(FI) * (64 * UI);            \
         const char * q0_, * q1_; int t0_, t1_, mi_; int64_t m0_;                                                                               \
@@ -214,21 +217,39 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
             S##g[u] = fc - S##rs[u] * gpr;                                                                                                     \
             S##p[u] = S##g[u] & 3;                                                                                                             \
             S##ty[u] = MODE ? MODE : (S##rs[u] ? t1_ : t0_);                                                                                   \
-            const unsigned char * bp = reinterpret_cast<const unsigned char *>(S##rs[u] ? q1_ : q0_) +                                        \
-                                       (size_t) (S##g[u] >> 2) * (S##ty[u] == PKV_TYPE_Q4_K ? 144 : 210);                                      \
-            const int n_ = S##p[u] >> 1, is_ = S##p[u] & 1;                                                                                    \
+            const unsigned char * rw_ = reinterpret_cast<const unsigned char *>(S##rs[u] ? q1_ : q0_);                                         \
+            const int ga_ = (PAST) ? 0 : S##g[u], pa_ = ga_ & 3;   /* a request past the wave's last unit: every lane the row's first 16 bytes (one line) */ \
+            if constexpr (PK) {   /* plane layout (pkv_wlayout.h): lane-consecutive items = consecutive 16 bytes of each plane */              \
+                const bool k4 = MODE == PKV_TYPE_Q4_K || (MODE == 0 && S##ty[u] == PKV_TYPE_Q4_K);                                             \
+                const unsigned char * it_ = rw_ + 16 * ga_, * bl_ = rw_ + 16 * (ga_ >> 2);                                                           \
+                if (MODE == PKV_TYPE_Q4_K) {                                                                                                   \
+                    S##r0[u] = ld16w<NTL>(bl_ + 32 * gpr);                                                                                     \
+                    S##r1[u] = ld16w<NTL>(it_);                                                                                                \
+                    S##r2[u] = ld16w<NTL>(it_ + 16 * gpr);                                                                                     \
+                    S##r3[u] = make_uint4(0, 0, 0, 0); S##dh[u] = 0;                                                                           \
+                } else {                                                                                                                       \
+                    S##r0[u] = ld16w<NTL>(k4 ? bl_ + 32 * gpr : it_);                                                                          \
+                    S##r1[u] = ld16w<NTL>(k4 ? it_ : it_ + 16 * gpr);                                                                          \
+                    S##r2[u] = ld16w<NTL>(k4 ? it_ + 16 * gpr : it_ + 32 * gpr);                                                               \
+                    S##r3[u] = ld16w<NTL>(k4 ? bl_ + 32 * gpr : bl_ + 48 * gpr);                                                               \
+                    S##dh[u] = *reinterpret_cast<const uint16_t *>(k4 ? bl_ + 32 * gpr : rw_ + 52 * gpr + 2 * (ga_ >> 2)    );                 \
+                }                                                                                                                              \
+            } else {                                                                                                                           \
+            const unsigned char * bp = rw_ + (size_t) (ga_ >> 2) *       (S##ty[u] == PKV_TYPE_Q4_K ? 144 : 210);                                \
+            const int n_ = pa_ >> 1, is_ = pa_ & 1;                                                                                            \
             if (MODE == PKV_TYPE_Q4_K) {                                                                                                       \
-                S##r0[u] = ld16w(bp);                                                                                                          \
-                S##r1[u] = ld16w(bp + 16 + 32 * S##p[u]);                                                                                      \
-                S##r2[u] = ld16w(bp + 32 + 32 * S##p[u]);                                                                                      \
+                S##r0[u] = ld16w<false>(bp);                                                                                                   \
+                S##r1[u] = ld16w<false>(bp + 16 + 32 * pa_    );                                                                               \
+                S##r2[u] = ld16w<false>(bp + 32 + 32 * pa_    );                                                                               \
                 S##r3[u] = make_uint4(0, 0, 0, 0); S##dh[u] = 0;                                                                               \
             } else {                                                                                                                           \
                 const bool k4 = MODE == 0 && S##ty[u] == PKV_TYPE_Q4_K;                                                                        \
-                S##r0[u] = ld16w(bp + (k4 ? 0 : 64 * n_ + 16 * is_));                                                                          \
-                S##r1[u] = ld16w(bp + (k4 ? 16 + 32 * S##p[u] : 64 * n_ + 16 * is_ + 32));                                                     \
-                S##r2[u] = ld16w(bp + (k4 ? 32 + 32 * S##p[u] : 128 + 32 * n_ + 16 * is_));                                                    \
-                S##r3[u] = ld16w(bp + (k4 ? 0 : 192));                                                                                         \
+                S##r0[u] = ld16w<false>(bp + (k4 ? 0 : 64 * n_ + 16 * is_));                                                                   \
+                S##r1[u] = ld16w<false>(bp + (k4 ? 16 + 32 * pa_     : 64 * n_ + 16 * is_ + 32));                                              \
+                S##r2[u] = ld16w<false>(bp + (k4 ? 32 + 32 * pa_     : 128 + 32 * n_ + 16 * is_));                                             \
+                S##r3[u] = ld16w<false>(bp + (k4 ? 0 : 192));                                                                                  \
                 S##dh[u] = *reinterpret_cast<const uint16_t *>(bp + (k4 ? 0 : 208));                                                           \
+            }                                                                                                                                  \
             }                                                                                                                                  \
         }                                                                                                                                      \
     }
@@ -272,11 +293,14 @@ __device__ __forceinline__ uint4 ld16w(const unsigned char * p) {
 // the wave will ever read is requested before the column is touched.
 // KS = 2 (ffn_down at Llama-3-8B sizes: 2048 row pairs of 3.5 units): the two halves of a row pair's groups go to two waves of the workgroup, so that
 // all 16 waves of every CU stream (and quantize the 14336-element column) and every wave is SHORT; their sums meet in LDS behind one barrier.
-template <int MODE, int NWV, bool SHORT, int KS = 1>
+template <int MODE, int NWV, bool SHORT, int KS = 1, bool PK = false>
 __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
-    // lane-loads of a unit: two (row, group) items per lane, or ONE where the q6_K item (4 x 16 bytes + header) would push a 16-wave workgroup past its
-    // 128 registers per lane (r02's first form spilled 72-112 bytes there)
-    constexpr int UI = (MODE != PKV_TYPE_Q4_K && NWV == 16) ? 1 : 2;
+    constexpr bool NTL = PK && PKV_GEMV_NT;
+    // A unit = ONE (row, group) item per lane = 3-4 wave loads of 1 KiB.  r02 ran two items per lane and two units ahead: 12 KB requested per wave,
+    // 192 KB per CU — eight times what a CU keeps in flight (~24 KiB), so every wave sat blocked at load ISSUE for microseconds before it
+    // reached the column prologue (timing ablations profiles/r03_gemv_ablation.txt: neither the dots nor the prologue explained 18 us against an 11 us
+    // bare read).  Now one small unit goes out ahead of the prologue, the second behind it, and two stay in flight per wave in the loop.
+    constexpr int UI = 1;
     constexpr int NT = 64 * NWV;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     constexpr int TAIL = MODE == PKV_TYPE_Q4_K ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
@@ -318,10 +342,34 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
     // the end a request re-reads the wave's last unit (the load count stays static: a load behind a branch drains the queue at the join)
     int lr = 0, lf = 0, cr = 0, cf = 0;
     auto step = [&](int & r, int & f) { if (++f == n_f0) { f = 0; ++r; } };
-#define PKV_LOAD_NEXT(S) { const bool past_ = lr >= n_rp; PKV_UNIT_LOAD(S, past_ ? n_rp - 1 : lr, past_ ? n_f0 - 1 : lf) step(lr, lf); }
+#define PKV_LOAD_NEXT(S) { const bool past_ = lr >= n_rp; if (PKV_GEMV_ABLATE == 3 && past_) {} else PKV_UNIT_LOAD(S, past_ ? n_rp - 1 : lr, past_ ? n_f0 - 1 : lf, past_) step(lr, lf); }
 #define PKV_COMPUTE_NEXT(S) { PKV_UNIT_COMPUTE(S, cr, cf) step(cr, cf); }
+    // The column's own loads go out FIRST.  Vector-memory results return in issue order (one vmcnt counter per wave) and a CU serves its
+    // requests first come, first served: r02 requested two units of weights per wave (192 KB per CU at 16 waves) ahead of the column, so the
+    // column (16-57 KB, L2-resident) arrived behind ALL of them — the norm / quantize prologue started 5-8 us into the launch and every dot
+    // waited for it (ffn_down: the whole matrix had landed before the first dot ran; profiles/r03_gemv_read_pattern.txt: a bare read of the same
+    // bytes takes 6.5 us where the product took 12.0).  Now: column loads, then the weight loads, then a counted wait for the column alone.
+    const int n4 = (int) (a.K >> 2);
+    const bool colk = PKV_GEMV_ABLATE != 2 && a.img == nullptr;      // the column is normalised / quantized here (no image from a launch of its own)
+    constexpr int NV = 2048 / NT;                                    // float4 per thread of the norm path (K <= 8192, checked on the host)
+    constexpr int NVP = NT >= 512 ? 4096 / NT : 8;                   // ... preloaded without a norm: K <= 16384 (8192 at 4 waves) in one round trip, the rest in batches
+    float4 v[NVP], w4[NV];
+    if (colk) {
+#pragma unroll
+        for (int j = 0; j < NVP; ++j) {                              // float4 index i = tid + NT j: the 64 lanes of a wave hold one 256-block (n4 % 64 == 0)
+            const int i = threadIdx.x + NT * j;
+            v[j] = i - lane < n4 ? reinterpret_cast<const float4 *>(a.x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (a.norm_w) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = threadIdx.x + NT * j;
+                w4[j] = i - lane < n4 ? reinterpret_cast<const float4 *>(a.norm_w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     PKV_LOAD_NEXT(A)                                                  // the first weight loads fly while the column is prepared
-    PKV_LOAD_NEXT(B)
     __builtin_amdgcn_sched_barrier(0);
 
     // tail of a group's record from the quantizer's registers: lane = float4 i of the column (dword i & 15 of group i >> 4)
@@ -351,10 +399,9 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
         if constexpr (TAIL == 0)
             for (int b = threadIdx.x; b < (int) (a.K >> 5); b += NT) sq[(b >> 1) * REC + 16 + (b & 1)] = (uint32_t) bb[b];
     } else {
-        // ... or here: [rms_norm(x) * w ->] q8_K straight into LDS.  float4 index i = tid + NT j: the 64 lanes of a wave hold one 256-block.
+        // ... or here: [rms_norm(x) * w ->] q8_K straight into LDS.
         // The sum of squares is the canonical one of pkv_common.h (f32 squares accumulated in f64 per 256-block, blocks added in order), the same
         // bits whatever the workgroup shape: the fused launch and the norm + quantize + product launches produce the same image.
-        const int n4 = (int) (a.K >> 2);
         auto put = [&](int i, const float4 o) {
             uint32_t packed; float d; int bs, bs16;
             quant_block_q8k(o, lane, packed, d, bs, bs16);
@@ -362,14 +409,6 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
             put_tail(i, d, bs, bs16);
         };
         if (a.norm_w) {
-            constexpr int NV = 2048 / NT;                             // norm: K <= 8192 (checked on the host)
-            float4 v[NV], w4[NV];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {                            // the column AND the norm weights in one memory round trip
-                const int i = threadIdx.x + NT * j;
-                v[j]  = i < n4 ? reinterpret_cast<const float4 *>(a.x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                w4[j] = i < n4 ? reinterpret_cast<const float4 *>(a.norm_w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int b = wv + NWV * j;                           // the wave's 256-block of pass j
@@ -394,16 +433,21 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
                 }
             }
         } else {
-            constexpr int NB8 = 8;                                    // batches of 8 float4 per thread: the loads of a batch share one round trip
-            for (int i0 = threadIdx.x; i0 - lane < n4; i0 += NT * NB8) {
-                float4 v[NB8];
 #pragma unroll
-                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; v[j] = reinterpret_cast<const float4 *>(a.x)[i - lane < n4 ? i : i0]; }
+            for (int j = 0; j < NVP; ++j) { const int i = threadIdx.x + NT * j; if (i - lane < n4) put(i, v[j]); }
+            constexpr int NB8 = 8;                                    // a longer column: batches of 8 float4 per thread, the loads of a batch share one round trip
+            for (int i0 = threadIdx.x + NT * NVP; i0 - lane < n4; i0 += NT * NB8) {
+                float4 vb[NB8];
 #pragma unroll
-                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; if (i - lane < n4) put(i, v[j]); }
+                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; vb[j] = reinterpret_cast<const float4 *>(a.x)[i - lane < n4 ? i : i0]; }
+#pragma unroll
+                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; if (i - lane < n4) put(i, vb[j]); }
             }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    PKV_LOAD_NEXT(B)                                                  // the wave's second unit: requested as soon as its share of the column is in LDS
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 
     if constexpr (SHORT) {
@@ -421,8 +465,11 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
 
 // ---- ggml_get_rows (/ref/src/llama-model.cpp:4047 inp_embd = get_rows(tok_embd, tokens); CPU kernel ggml_compute_forward_get_rows,
 //      /ref/ggml/src/ggml-cpu/ggml-cpu.c:8940-9090): out[i][:] = dequantize(row ids[i]) ----------------------------------------------
-template <int T>
+// PK: the row is in the plane layout of pkv_wlayout.h; byte `o` of the GGUF-order row is at row[pk(o)]
+template <int T, bool PK = false>
 __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int32_t * ids, float * out, int64_t K, int64_t n_rows_w) {
+    const int gpr = (int) (K >> 6);
+    auto pk = [&](size_t o) -> size_t { if constexpr (!PK) return o; else return T == PKV_TYPE_Q4_K ? pk_offset_q4k(gpr, o) : pk_offset_q6k(gpr, o); };
     const int64_t r = ids[blockIdx.x];
     float * o = out + (size_t) blockIdx.x * K;
     if (r < 0 || r >= n_rows_w) { for (int64_t k = threadIdx.x; k < K; k += 256) o[k] = 0.0f; return; }
@@ -438,32 +485,59 @@ __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int
         }
     } else if constexpr (T == PKV_TYPE_Q4_K) {      // dequantize_row_q4_K (/ref/ggml/src/ggml-quants.c:1280-1302)
         for (int64_t k = threadIdx.x; k < K; k += 256) {
-            const unsigned char * b = row + (k >> 8) * 144;
+            const size_t b = (size_t) (k >> 8) * 144;                       // GGUF-order offset of the block inside the row
             const int e = (int) (k & 255), j = e >> 5, l = e & 31;           // sub-block j, element l
-            const float d = h2f(*reinterpret_cast<const uint16_t *>(b)), dmin = h2f(*reinterpret_cast<const uint16_t *>(b + 2));
-            const unsigned char * s = b + 4;
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b))), dmin = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b + 2)));
+            auto s = [&](int i) -> int { return (int) row[pk(b + 4 + i)]; };
             int sc, mn;
-            if (j < 4) { sc = s[j] & 63; mn = s[j + 4] & 63; }
-            else       { sc = (s[j + 4] & 0xF) | ((s[j - 4] >> 6) << 4); mn = (s[j + 4] >> 4) | ((s[j] >> 6) << 4); }
-            const unsigned char qb = b[16 + 32 * (j >> 1) + l];
+            if (j < 4) { sc = s(j) & 63; mn = s(j + 4) & 63; }
+            else       { sc = (s(j + 4) & 0xF) | ((s(j - 4) >> 6) << 4); mn = (s(j + 4) >> 4) | ((s(j) >> 6) << 4); }
+            const unsigned char qb = row[pk(b + 16 + 32 * (j >> 1) + l)];
             const int q = (j & 1) ? (qb >> 4) : (qb & 0xF);
             const float d1 = d * (float) sc, m1 = dmin * (float) mn;         // f32 products, as the reference forms them
             o[k] = d1 * (float) q - m1;
         }
     } else {                                         // q6_K: dequantize_row_q6_K (:1690-1719)
         for (int64_t k = threadIdx.x; k < K; k += 256) {
-            const unsigned char * b = row + (k >> 8) * 210;
+            const size_t b = (size_t) (k >> 8) * 210;
             const int e = (int) (k & 255), n = e >> 7, r128 = e & 127, j = r128 >> 5, l = r128 & 31;
-            const unsigned char lq = b[64 * n + l + 32 * (j & 1)], hq = b[128 + 32 * n + l];
+            const unsigned char lq = row[pk(b + 64 * n + l + 32 * (j & 1))], hq = row[pk(b + 128 + 32 * n + l)];
             const int q = (int) (((j >> 1) ? (lq >> 4) : (lq & 0xF)) | (((hq >> (2 * j)) & 3) << 4)) - 32;
-            const float d = h2f(*reinterpret_cast<const uint16_t *>(b + 208));
-            const int sc = (int) reinterpret_cast<const signed char *>(b + 192)[8 * n + (l >> 4) + 2 * j];
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b + 208)));
+            const int sc = (int) (signed char) row[pk(b + 192 + 8 * n + (l >> 4) + 2 * j)];
             o[k] = d * (float) sc * (float) q;
         }
     }
 }
 
+// GGUF-order rows <-> plane-layout rows (pkv_wlayout.h), 2 bytes per thread-step (a block_q6_K is only 2-byte aligned; every field of both
+// formats is a whole number of 2-byte units).  One-time work at upload, or the inverse for tensor_get.
+template <int T>
+__global__ void __launch_bounds__(256) pack_rows_kernel(const uint16_t * src, uint16_t * dst, int64_t n_rows, int64_t K, int inverse) {
+    const int gpr = (int) (K >> 6);
+    const int64_t rb2 = (int64_t) (row_size(T, K) >> 1), n = n_rows * rb2;
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
+        const int64_t r = i / rb2, o = (i - r * rb2) * 2;
+        const int64_t po = (int64_t) (T == PKV_TYPE_Q4_K ? pk_offset_q4k(gpr, (size_t) o) : pk_offset_q6k(gpr, (size_t) o));
+        if (inverse) dst[i] = src[r * rb2 + (po >> 1)];
+        else         dst[r * rb2 + (po >> 1)] = src[i];
+    }
+}
+
 }  // namespace
+
+int launch_pack_rows(const void * src, void * dst, int type, int64_t n_rows, int64_t K, int inverse, hipStream_t st) {
+    PKV_REQUIRE(src && dst && src != dst && n_rows >= 0 && K > 0 && K % 256 == 0, "pkv_weights_pack: bad arguments (src != dst, K %% 256 == 0)");
+    PKV_REQUIRE(type == PKV_TYPE_Q4_K || type == PKV_TYPE_Q6_K, "pkv_weights_pack: q4_K / q6_K rows only");
+    PKV_REQUIRE(((uintptr_t) src % 2) == 0 && ((uintptr_t) dst % 2) == 0, "pkv_weights_pack: 2-byte aligned pointers");
+    if (n_rows == 0) return PKV_OK;
+    const int64_t n = n_rows * (int64_t) (row_size(type, K) >> 1);
+    const unsigned grid = (unsigned) std::min<int64_t>((n + 255) / 256, 1 << 16);
+    if (type == PKV_TYPE_Q4_K) hipLaunchKernelGGL(pack_rows_kernel<PKV_TYPE_Q4_K>, dim3(grid), dim3(256), 0, st, (const uint16_t *) src, (uint16_t *) dst, n_rows, K, inverse);
+    else                       hipLaunchKernelGGL(pack_rows_kernel<PKV_TYPE_Q6_K>, dim3(grid), dim3(256), 0, st, (const uint16_t *) src, (uint16_t *) dst, n_rows, K, inverse);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
+}
 
 size_t act_image_bytes(int64_t K) { return (size_t) K + (size_t) (K / 256) * 4 + (size_t) (K / 32) * 4; }
 
@@ -482,10 +556,14 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     PKV_REQUIRE(!g.residual || g.n == 1, "pkv_gemv_q: the residual epilogue takes one product");
     GemvArgs a = {};
     int tot = 0;
+    const bool packed = (g.type_w[0] & PKV_TYPE_PACKED) != 0;       // plane-layout rows (pkv_wlayout.h): all matrices of a launch, or none
+    int tw[PKV_GEMV_MAX] = {};
     for (int i = 0; i < g.n; ++i) {
         PKV_REQUIRE(g.w[i] && g.y[i] && g.M[i] > 0 && g.M[i] % 2 == 0, "pkv_gemv_q: matrix %d: null pointer or odd row count", i);
-        if (g.type_w[i] != PKV_TYPE_Q4_K && g.type_w[i] != PKV_TYPE_Q6_K) { set_error("pkv_gemv_q: weight type %d not supported (q4_K, q6_K)", g.type_w[i]); return PKV_ERR_UNSUPPORTED; }
-        a.w[i] = (const char *) g.w[i]; a.y[i] = g.y[i]; a.M[i] = g.M[i]; a.type[i] = g.type_w[i];
+        PKV_REQUIRE(((g.type_w[i] & PKV_TYPE_PACKED) != 0) == packed, "pkv_gemv_q: the matrices of one launch are all packed or all in GGUF order");
+        tw[i] = g.type_w[i] & ~PKV_TYPE_PACKED;
+        if (tw[i] != PKV_TYPE_Q4_K && tw[i] != PKV_TYPE_Q6_K) { set_error("pkv_gemv_q: weight type %d not supported (q4_K, q6_K)", g.type_w[i]); return PKV_ERR_UNSUPPORTED; }
+        a.w[i] = (const char *) g.w[i]; a.y[i] = g.y[i]; a.M[i] = g.M[i]; a.type[i] = tw[i];
         tot += g.silu_mul ? (i == 0 ? (int) g.M[0] : 0) : (int) (g.M[i] / 2);
         a.rp_end[i] = tot;
     }
@@ -497,7 +575,7 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     const size_t lds = (size_t) REC * a.gpr * 4;
     // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)
     bool all4 = true, all6 = true;
-    for (int i = 0; i < g.n; ++i) { all4 = all4 && g.type_w[i] == PKV_TYPE_Q4_K; all6 = all6 && g.type_w[i] == PKV_TYPE_Q6_K; }
+    for (int i = 0; i < g.n; ++i) { all4 = all4 && tw[i] == PKV_TYPE_Q4_K; all6 = all6 && tw[i] == PKV_TYPE_Q6_K; }
     const int mode = all4 ? PKV_TYPE_Q4_K : (all6 ? PKV_TYPE_Q6_K : 0);
     int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
     int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
@@ -505,15 +583,16 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     const int f_half = ((a.gpr + 63) / 64) * 64;
     const bool split = nwv == 8 && grid * 8 >= tot && 2 * a.gpr > 256;
     if (split) nwv = 16;
-    const int ui = (mode != PKV_TYPE_Q4_K && nwv == 16) ? 1 : 2;     // items per lane and unit (the kernel's UI)
+    const int ui = 1;                                                // items per lane and unit (the kernel's UI)
     const int n_f0 = ((split ? f_half : 2 * a.gpr) + 64 * ui - 1) / (64 * ui);
     const bool shrt = (int64_t) (split ? 1 : (tot + grid * nwv - 1) / (grid * nwv)) * n_f0 <= 2;
-#define PKV_GEMV_LAUNCH(MODE_, NWV_, SHORT_) hipLaunchKernelGGL((gemv_kernel<MODE_, NWV_, SHORT_>), dim3((unsigned) grid), dim3(64 * NWV_), lds, st, a)
-#define PKV_GEMV_PICK_S(MODE_, NWV_) do { if (shrt) PKV_GEMV_LAUNCH(MODE_, NWV_, true); else PKV_GEMV_LAUNCH(MODE_, NWV_, false); } while (0)
-#define PKV_GEMV_PICK_W(MODE_) do { if (split) { if (shrt) hipLaunchKernelGGL((gemv_kernel<MODE_, 16, true, 2>), dim3((unsigned) grid), dim3(1024), lds, st, a); else hipLaunchKernelGGL((gemv_kernel<MODE_, 16, false, 2>), dim3((unsigned) grid), dim3(1024), lds, st, a); } else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8); else PKV_GEMV_PICK_S(MODE_, 4); } while (0)
-    if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_W(PKV_TYPE_Q4_K);
-    else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_W(PKV_TYPE_Q6_K);
-    else                            PKV_GEMV_PICK_W(0);
+#define PKV_GEMV_LAUNCH(MODE_, NWV_, SHORT_, KS_, PK_) hipLaunchKernelGGL((gemv_kernel<MODE_, NWV_, SHORT_, KS_, PK_>), dim3((unsigned) grid), dim3(64 * NWV_), lds, st, a)
+#define PKV_GEMV_PICK_S(MODE_, NWV_, KS_, PK_) do { if (shrt) PKV_GEMV_LAUNCH(MODE_, NWV_, true, KS_, PK_); else PKV_GEMV_LAUNCH(MODE_, NWV_, false, KS_, PK_); } while (0)
+#define PKV_GEMV_PICK_W(MODE_, PK_) do { if (split) PKV_GEMV_PICK_S(MODE_, 16, 2, PK_); else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16, 1, PK_); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8, 1, PK_); else PKV_GEMV_PICK_S(MODE_, 4, 1, PK_); } while (0)
+#define PKV_GEMV_PICK_P(MODE_) do { if (packed) PKV_GEMV_PICK_W(MODE_, true); else PKV_GEMV_PICK_W(MODE_, false); } while (0)
+    if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_P(PKV_TYPE_Q4_K);
+    else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_P(PKV_TYPE_Q6_K);
+    else                            PKV_GEMV_PICK_P(0);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
@@ -521,6 +600,8 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
 int launch_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, hipStream_t st) {
     if (n_ids == 0) return PKV_OK;
     const dim3 grid((unsigned) n_ids);
+    if (type_w == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q4_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
+    if (type_w == (PKV_TYPE_Q6_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q6_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
     switch (type_w) {
         case PKV_TYPE_F32:  hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_F32>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;
         case PKV_TYPE_F16:  hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_F16>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;

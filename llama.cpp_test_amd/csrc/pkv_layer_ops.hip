@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(256) silu_kernel(const float * x, float * y, i
 // bandwidth-bound: the next step is fewer, larger launches (fused gate/up, persistent layer kernel), not a different inner loop.
 constexpr int MM_CT = 8, Q4K_ROWS = 2;
 // block_q4_K rows x one f32 activation column per pass; `wg` = index of the group of 4 Q4K_ROWS rows this workgroup owns
+template <bool PK = false>   // PK: rows in the plane layout of pkv_wlayout.h
 __device__ __forceinline__ void q4k_rows(const char * w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, size_t w_row_bytes,
                                          int64_t wg) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -283,11 +284,18 @@ __device__ __forceinline__ void q4k_rows(const char * w, const float * x, float 
                 uint4 hdr[R], qa[R], qb[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const unsigned char * bp = reinterpret_cast<const unsigned char *>(w) + (size_t) min(m0 + r, M - 1) * w_row_bytes +
-                                               (size_t) ((k0 >> 8) + (min(lane, ng - 1) >> 2)) * 144;
+                    const unsigned char * rowp = reinterpret_cast<const unsigned char *>(w) + (size_t) min(m0 + r, M - 1) * w_row_bytes;
+                    if constexpr (PK) {
+                        const size_t gpr = (size_t) (K >> 6), g = (size_t) (k0 >> 6) + (size_t) min(lane, ng - 1);
+                        hdr[r] = *reinterpret_cast<const uint4 *>(rowp + 32 * gpr + 16 * (g >> 2));
+                        qa[r]  = *reinterpret_cast<const uint4 *>(rowp + 16 * g);
+                        qb[r]  = *reinterpret_cast<const uint4 *>(rowp + 16 * gpr + 16 * g);
+                    } else {
+                    const unsigned char * bp = rowp + (size_t) ((k0 >> 8) + (min(lane, ng - 1) >> 2)) * 144;
                     hdr[r] = *reinterpret_cast<const uint4 *>(bp);   // d, dmin and the 12 scale bytes in ONE 16-byte load
                     qa[r]  = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p);
                     qb[r]  = *reinterpret_cast<const uint4 *>(bp + 16 + 32 * p + 16);
+                    }
                 }
                 // the chunk's activations: all of a thread's float4 are requested before any is used (a loop over them would pay
                 // the L2 latency once per iteration: kc is not a compile-time constant)
@@ -401,7 +409,8 @@ __global__ void __launch_bounds__(256) mul_mat_multi_kernel(MulMatMulti a, const
     int i = 0;
     while (i + 1 < a.n && (int) blockIdx.x >= a.wg_end[i]) ++i;
     const int64_t wg = (int64_t) blockIdx.x - (i ? a.wg_end[i - 1] : 0);
-    if constexpr (WT == PKV_TYPE_Q4_K) q4k_rows(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, wg);
+    if constexpr (WT == PKV_TYPE_Q4_K) q4k_rows<false>(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, wg);
+    else if constexpr (WT == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED)) q4k_rows<true>(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, wg);
     else                               q8_rows(a.w[i], x, a.y[i], a.M[i], K, n_cols, w_row_bytes, wg);
 }
 
@@ -411,7 +420,8 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t m = (int64_t) blockIdx.x * 4 + wv;
     const char * wr = w + (size_t) min(m, M - 1) * w_row_bytes;            // surplus waves redo the last row and do not store
-    if constexpr (WT == PKV_TYPE_Q4_K) { q4k_rows(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
+    if constexpr (WT == PKV_TYPE_Q4_K) { q4k_rows<false>(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
+    if constexpr (WT == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED)) { q4k_rows<true>(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
     if constexpr (WT == PKV_TYPE_Q8_0) { q8_rows(w, x, y, M, K, n_cols, w_row_bytes, (int64_t) blockIdx.x); return; }
     for (int64_t c0 = 0; c0 < n_cols; c0 += MM_CT) {
         const int nc = (int) min((int64_t) MM_CT, n_cols - c0);
@@ -444,7 +454,7 @@ __global__ void __launch_bounds__(256) mul_mat_kernel(const char * w, const floa
                     }
                 }
             }
-        } else if constexpr (WT == PKV_TYPE_Q4_K) {
+        } else if constexpr ((WT & ~PKV_TYPE_PACKED) == PKV_TYPE_Q4_K) {
             // handled below (activations staged through LDS): nothing in the generic column-tile loop
         } else {
             for (int64_t blk = lane; blk < K / PKV_QK; blk += 64) {
@@ -566,7 +576,7 @@ int launch_silu(const float * x, float * y, int64_t n, hipStream_t st) {
     return PKV_OK;
 }
 // one column of K-quant weights: the decode-step product of pkv_gemv.hip (the column quantized to q8_K in its prologue)
-static bool gemv_shape(int type_w, int64_t M, int64_t K) { return (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K) && K % 256 == 0 && K <= 49152 && M % 2 == 0; }
+static bool gemv_shape(int type_w, int64_t M, int64_t K) { type_w &= ~PKV_TYPE_PACKED; return (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K) && K % 256 == 0 && K <= 49152 && M % 2 == 0; }
 constexpr int64_t GEMM_MIN_COLS = 16;   // from here on a weight tile read once per 128 columns beats a stream per column
 int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st) {
     if (M == 0 || n_cols == 0) return PKV_OK;
@@ -575,11 +585,13 @@ int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64
         g.n = 1; g.type_w[0] = type_w; g.w[0] = w; g.y[0] = y; g.M[0] = M; g.K = K; g.x = x;
         return launch_gemv(g, st);
     }
-    if ((n_cols >= GEMM_MIN_COLS || type_w == PKV_TYPE_Q6_K) && gemm_supported(type_w, M, K)) return launch_gemm(w, type_w, x, y, M, K, n_cols, st);
-    const int rows_wg = type_w == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
+    const int bt = type_w & ~PKV_TYPE_PACKED;                        // plane-layout rows (pkv_wlayout.h) keep the base type's row size
+    if ((n_cols >= GEMM_MIN_COLS || bt == PKV_TYPE_Q6_K) && gemm_supported(type_w, M, K)) return launch_gemm(w, type_w, x, y, M, K, n_cols, st);
+    const int rows_wg = bt == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
     const dim3 grid((unsigned) ((M + rows_wg - 1) / rows_wg));
-    const size_t rb = row_size(type_w, K);
+    const size_t rb = row_size(bt, K);
     switch (type_w) {
+        case PKV_TYPE_Q4_K | PKV_TYPE_PACKED: hipLaunchKernelGGL(mul_mat_kernel<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)>, grid, dim3(256), 0, st, (const char *) w, x, y, M, K, n_cols, rb); break;
         case PKV_TYPE_F32:  hipLaunchKernelGGL(mul_mat_kernel<PKV_TYPE_F32>, grid, dim3(256), 0, st, (const char *) w, x, y, M, K, n_cols, rb); break;
         case PKV_TYPE_F16:  hipLaunchKernelGGL(mul_mat_kernel<PKV_TYPE_F16>, grid, dim3(256), 0, st, (const char *) w, x, y, M, K, n_cols, rb); break;
         case PKV_TYPE_Q8_0: hipLaunchKernelGGL(mul_mat_kernel<PKV_TYPE_Q8_0>, grid, dim3(256), 0, st, (const char *) w, x, y, M, K, n_cols, rb); break;
@@ -603,7 +615,8 @@ int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float 
         }
     }
     if (n_cols >= GEMM_MIN_COLS && gemm_supported(type_w, 1, K) && n <= 4) return launch_gemm_multi(n, w, type_w, x, y, M, K, n_cols, st);   // prompt ubatch: ONE MFMA launch
-    if ((n_cols >= GEMM_MIN_COLS && gemm_supported(type_w, 1, K)) || (type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q8_0)) {       // one launch each
+    const int bt = type_w & ~PKV_TYPE_PACKED;
+    if ((n_cols >= GEMM_MIN_COLS && gemm_supported(type_w, 1, K)) || (bt != PKV_TYPE_Q4_K && bt != PKV_TYPE_Q8_0)) {       // one launch each
         for (int i = 0; i < n; ++i) if (int rc = launch_mul_mat(w[i], type_w, x, y[i], M[i], K, n_cols, st)) return rc;
         return PKV_OK;
     }
@@ -613,12 +626,13 @@ int launch_mul_mat_multi(int n, const void * const * w, int type_w, const float 
     for (int i = 0; i < n; ++i) {
         if (M[i] == 0) continue;
         a.w[a.n] = (const char *) w[i]; a.y[a.n] = y[i]; a.M[a.n] = M[i];
-        const int rows_wg = type_w == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
+        const int rows_wg = bt == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
         tot += (int) ((M[i] + rows_wg - 1) / rows_wg);
         a.wg_end[a.n++] = tot;
     }
     if (a.n == 0) return PKV_OK;
     if (type_w == PKV_TYPE_Q4_K) hipLaunchKernelGGL(mul_mat_multi_kernel<PKV_TYPE_Q4_K>, dim3((unsigned) tot), dim3(256), 0, st, a, x, K, n_cols, row_size(PKV_TYPE_Q4_K, K));
+    else if (bt == PKV_TYPE_Q4_K) hipLaunchKernelGGL(mul_mat_multi_kernel<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)>, dim3((unsigned) tot), dim3(256), 0, st, a, x, K, n_cols, row_size(PKV_TYPE_Q4_K, K));
     else                         hipLaunchKernelGGL(mul_mat_multi_kernel<PKV_TYPE_Q8_0>, dim3((unsigned) tot), dim3(256), 0, st, a, x, K, n_cols, row_size(PKV_TYPE_Q8_0, K));
     PKV_HIP(hipGetLastError());
     return PKV_OK;

@@ -24,7 +24,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from . import (F16, Q4_K, Q6_K, PagedKVCache, PkvError, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add, rms_norm_mul, rope_cache,
+from . import (F16, Q4_K, Q6_K, PACKED, weights_pack, PagedKVCache, PkvError, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add, rms_norm_mul, rope_cache,
                rope_params, silu_mul, kv_store)
 from .gguf_synth import read_gguf, row_bytes
 
@@ -32,7 +32,7 @@ _KQ = (Q4_K, Q6_K)
 
 
 class LlamaDecoder:
-    def __init__(self, path: str, *, n_ctx: int, type_k: int = F16, type_v: int = F16, block_size: int = 128, device: int = 0):
+    def __init__(self, path: str, *, n_ctx: int, type_k: int = F16, type_v: int = F16, block_size: int = 128, device: int = 0, pack_weights: bool = True):
         import torch
         self.torch = torch
         meta, tensors, _ = read_gguf(path)
@@ -50,7 +50,13 @@ class LlamaDecoder:
 
         def up(name):
             ne, t, _, data = tensors[name]
-            return torch.from_numpy(np.array(data)).to(dev), int(t), tuple(int(x) for x in ne)   # a copy: the file map is read-only
+            w = torch.from_numpy(np.array(data)).to(dev)                    # a copy: the file map is read-only
+            ne, t = tuple(int(x) for x in ne), int(t)
+            if pack_weights and t in _KQ and len(ne) == 2 and ne[0] % 256 == 0:
+                # K-quant rows are re-laid inside their own bytes at upload (plane layout, csrc/pkv_wlayout.h; the reference's CPU backend repacks on
+                # set_tensor too, /root/reference/ggml/src/ggml-cpu/ggml-cpu-aarch64.cpp:4145-4172): same integers, same results, coalesced streaming
+                w, t = weights_pack(w, t, ne[1], ne[0]), t | PACKED
+            return w, t, ne
         self.w: Dict[str, tuple] = {name: up(name) for name in tensors}
         self.n_vocab = self.w["token_embd.weight"][2][1]
         if "output.weight" not in self.w:                             # tied embeddings (:1601-1606)
@@ -86,7 +92,7 @@ class LlamaDecoder:
         n = 0
         for name, (t, ty, ne) in self.w.items():
             if name == "token_embd.weight":
-                n += row_bytes(ty, ne[0])
+                n += row_bytes(ty & ~PACKED, ne[0])
                 if self.w["output.weight"] is not self.w["token_embd.weight"]:
                     continue
             if name == "rope_freqs.weight":
@@ -96,7 +102,8 @@ class LlamaDecoder:
 
     # ---- products ------------------------------------------------------------------------------------------------------------
     def _kq(self, names) -> bool:
-        return all(self.w[n][1] in _KQ for n in names) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
+        return (all((self.w[n][1] & ~PACKED) in _KQ for n in names) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
+                and len({self.w[n][1] & PACKED for n in names}) == 1)
 
     def _products(self, names, outs, x_f32, *, norm=None, residual=None, silu=False):
         """outs[i] = W_i x' (+ residual | SwiGLU) with x' = x, or rms_norm(x) * norm weights: ONE pkv_gemv_q launch for K-quant rows (the column is

@@ -39,10 +39,16 @@ SHAPES = [  # name, [(type, M)], K, norm, residual, silu
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", nargs="*", default=[]); ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--packed", action="store_true", help="second arm: the same library on plane-layout rows (type | PKV_TYPE_PACKED; random bytes, timing only)")
     a = ap.parse_args()
     mods = {"this tree": load_pkg("pkv_a", None)}
+    flag = {k: 0 for k in mods}
+    if a.packed:
+        mods = {"gguf order": mods["this tree"], "packed": mods["this tree"]}
+        flag = {"gguf order": 0, "packed": 0x100}
     for i, l in enumerate(a.libs):
         mods[os.path.basename(l)] = load_pkg(f"pkv_l{i}", l)
+        flag[os.path.basename(l)] = 0x100 if a.packed else 0
     dev = torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(1)
     st = torch.cuda.Stream()
@@ -58,15 +64,17 @@ def main():
         graphs = {}
         with torch.cuda.stream(st):
             for k, m in mods.items():
+                fl = flag[k]
+
                 def run():
                     for i in range(n_launch):
                         w = ws[i % n_buf]
                         if silu:
-                            m.gemv_q(w, [t for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], silu_mul=True, x=x, norm_w=nw, eps=1e-5)
+                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], silu_mul=True, x=x, norm_w=nw, eps=1e-5)
                         elif resid:
-                            m.gemv_q(w, [t for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], residual=outs[0], x=x)
+                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], residual=outs[0], x=x)
                         else:
-                            m.gemv_q(w, [t for t, _ in mats], [M for _, M in mats], K, None, outs, x=x, norm_w=nw, eps=1e-5)
+                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, outs, x=x, norm_w=nw, eps=1e-5)
                 run(); torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st):

@@ -76,14 +76,21 @@ def test_own_loop_reproduces_reference_logits(pkv, gen, model_path, kv):
     again = d.eval(int(tok[last]), last).cpu().numpy()
     assert np.array_equal(again, eager)
     d.close()
+    # GGUF-order weights (pack_weights=False) give the same logits bit for bit: the plane layout permutes bytes, not arithmetic
+    d2 = LlamaDecoder(model_path, n_ctx=256, type_k=t, type_v=t, pack_weights=False)
+    for i in range(last + 1):
+        lg2 = d2.eval(int(tok[i]), i)
+    assert np.array_equal(lg2.cpu().numpy(), eager)
+    d2.close()
 
 
 def test_weight_types_and_bytes(pkv, model_path):
     """the loader sees the Q4_K_M mix (q6_K output / attn_v / ffn_down of the `use_more_bits` layers) and counts the bytes one step reads"""
     from llama_cpp_test_amd.decoder import LlamaDecoder
     d = LlamaDecoder(model_path, n_ctx=256)
-    assert d.w["output.weight"][1] == pkv.Q6_K and d.w["blk.0.attn_q.weight"][1] == pkv.Q4_K and d.w["token_embd.weight"][1] == pkv.Q4_K
-    assert {d.w[f"blk.{l}.attn_v.weight"][1] for l in range(d.n_layer)} <= {pkv.Q4_K, pkv.Q6_K}
+    P = pkv.PACKED                                                 # K-quant rows are re-laid inside their own bytes at upload (csrc/pkv_wlayout.h)
+    assert d.w["output.weight"][1] == pkv.Q6_K | P and d.w["blk.0.attn_q.weight"][1] == pkv.Q4_K | P and d.w["token_embd.weight"][1] == pkv.Q4_K | P
+    assert {d.w[f"blk.{l}.attn_v.weight"][1] for l in range(d.n_layer)} <= {pkv.Q4_K | P, pkv.Q6_K | P}
     total = sum(t.numel() for n, (t, _, _) in d.w.items())
     assert 0 < d.weight_bytes() < total
     d.close()
