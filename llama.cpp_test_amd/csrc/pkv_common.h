@@ -82,9 +82,18 @@ __device__ __forceinline__ double block_sumsq(const float4 v) {
     s += (double) __fmul_rn(v.w, v.w);
     return wave_sum_d(s);
 }
+// (n_blocks <= 64.)  ONE LDS read per lane — lane l holds block l — then the blocks are added in index order out of registers (v_readlane): the
+// serial loop over LDS paid one read latency per block, 0.6 us for the 16 blocks of a 4096-element row on the critical path of every norm
+// (profiles/r03_gemv_stamps.txt).  Same additions in the same order: the same bits.
 __device__ __forceinline__ float rms_scale(const double * block_sums, int n_blocks, int64_t ne0, float eps) {
+    const int l_ = (int) (threadIdx.x & 63);
+    const unsigned long long mine = __double_as_longlong(l_ < n_blocks ? block_sums[l_] : 0.0);
+    const int lo = (int) (unsigned) mine, hi = (int) (unsigned) (mine >> 32);
     double t = 0.0;
-    for (int b = 0; b < n_blocks; ++b) t += block_sums[b];
+    for (int b = 0; b < n_blocks; ++b) {
+        const unsigned lb = (unsigned) __builtin_amdgcn_readlane(lo, b), hb = (unsigned) __builtin_amdgcn_readlane(hi, b);
+        t += __longlong_as_double(((unsigned long long) hb << 32) | lb);
+    }
     const float mean = (float) (t / (double) ne0);
     return 1.0f / sqrtf(mean + eps);
 }

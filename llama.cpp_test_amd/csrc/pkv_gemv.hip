@@ -16,6 +16,7 @@
 #include "pkv_wlayout.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 // every instantiation of the product kernel must round a given row identically (one launch for wq + wk + wv == three launches, bit for bit):
 // no implicit FMA contraction anywhere in this file
@@ -87,6 +88,7 @@ struct GemvArgs {
     const float * norm_w;
     float        eps;
     float *      norm_out, * col_out;     // optional: the normalised column (x * scale, and * norm_w), written by workgroup 0
+    unsigned long long * stamps;          // diagnostic builds only (-DPKV_GEMV_STAMPS): [workgroup][wave][16] clock stamps, else NULL
     int64_t      K;
     int          gpr, gs;                // 64-element groups per row, LDS row stride (odd)
 };
@@ -187,6 +189,14 @@ __device__ __forceinline__ float wsum_dpp(float x) {
 // Plain named registers per pipeline stage (a struct handed to lambdas by reference ended up in scratch memory: 368 bytes per lane and
 // every weight load doubled by a scratch store — rocprofv3 Scratch_Size column).
 // Weight rows are read once by one CU: non-temporal loads (MI355X_MICROARCH.md price list, row nt-weights).
+#ifndef PKV_GEMV_STAMPS
+#define PKV_GEMV_STAMPS 0   // diagnostic build (probes/gemv_stamps.py): per-wave s_memtime stamps kept in registers, written once at the end; never in the product library
+#endif
+#if PKV_GEMV_STAMPS
+#define PKV_STAMP(i) { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PKV_STAMP(i)
+#endif
 #ifndef PKV_GEMV_ABLATE
 #define PKV_GEMV_ABLATE 0   // timing-only builds (results wrong): 1 = no dots (loads + reduce), 2 = no column prologue
 #endif
@@ -293,8 +303,12 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
 // the wave will ever read is requested before the column is touched.
 // KS = 2 (ffn_down at Llama-3-8B sizes: 2048 row pairs of 3.5 units): the two halves of a row pair's groups go to two waves of the workgroup, so that
 // all 16 waves of every CU stream (and quantize the 14336-element column) and every wave is SHORT; their sums meet in LDS behind one barrier.
+// The five leading arguments (8 dwords) are preloaded into SGPRs at dispatch (-amdgpu-kernarg-preload-count=8): the column's loads go out without
+// waiting for a kernel-argument fetch; r02 read everything through the by-value struct — three dependent scalar-load round trips (~1 us, stamps in
+// profiles/r03_gemv_stamps.txt) before the first vector load.  The rest of GemvArgs arrives in ONE batch of scalar loads behind them.
 template <int MODE, int NWV, bool SHORT, int KS = 1, bool PK = false>
-__global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
+__global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict__ ax, const float * __restrict__ anw, const char * __restrict__ aimg, const int aK, const float aeps,
+                                                        const GemvArgs a) {
     constexpr bool NTL = PK && PKV_GEMV_NT;
     // A unit = ONE (row, group) item per lane = 3-4 wave loads of 1 KiB.  r02 ran two items per lane and two units ahead: 12 KB requested per wave,
     // 192 KB per CU — eight times what a CU keeps in flight (~24 KiB), so every wave sat blocked at load ISSUE for microseconds before it
@@ -303,8 +317,39 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
     constexpr int UI = 1;
     constexpr int NT = 64 * NWV;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    // The column's own loads go out FIRST.  Vector-memory results return in issue order (one vmcnt counter per wave) and a CU serves its
+    // requests first come, first served: r02 requested two units of weights per wave (192 KB per CU at 16 waves) ahead of the column, so the
+    // column (16-57 KB, L2-resident) arrived behind ALL of them — the norm / quantize prologue started 5-8 us into the launch and every dot
+    // waited for it (ffn_down: the whole matrix had landed before the first dot ran; profiles/r03_gemv_read_pattern.txt: a bare read of the same
+    // bytes takes 6.5 us where the product took 12.0).  Now: column loads, then the weight loads, then a counted wait for the column alone.
+#if PKV_GEMV_STAMPS
+    unsigned long long st_[20];
+    for (int i = 0; i < 20; ++i) st_[i] = 0;
+    st_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    PKV_STAMP(1)
+    const int n4 = (int) (aK >> 2);
+    const bool colk = PKV_GEMV_ABLATE != 2 && aimg == nullptr;      // the column is normalised / quantized here (no image from a launch of its own)
+    constexpr int NV = 2048 / NT;                                    // float4 per thread of the norm path (K <= 8192, checked on the host)
+    constexpr int NVP = NT >= 512 ? 4096 / NT : 8;                   // ... preloaded without a norm: K <= 16384 (8192 at 4 waves) in one round trip, the rest in batches
+    float4 v[NVP], w4[NV];
+    if (colk) {
+#pragma unroll
+        for (int j = 0; j < NVP; ++j) {                              // float4 index i = tid + NT j: the 64 lanes of a wave hold one 256-block (n4 % 64 == 0)
+            const int i = threadIdx.x + NT * j;
+            v[j] = i - lane < n4 ? reinterpret_cast<const float4 *>(ax)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (anw) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = threadIdx.x + NT * j;
+                w4[j] = i - lane < n4 ? reinterpret_cast<const float4 *>(anw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     constexpr int TAIL = MODE == PKV_TYPE_Q4_K ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
-    const int gpr = a.gpr;
+    const int gpr = aK >> 6;
     uint32_t * sq = g_lds;                                           // gpr records of REC dwords
     __shared__ double sred[32];                                       // sums of squares per 256-element block (norm prologue)
     const int total_rp = a.rp_end[0] > a.rp_end[1] ? (a.rp_end[0] > a.rp_end[2] ? a.rp_end[0] : a.rp_end[2]) : (a.rp_end[1] > a.rp_end[2] ? a.rp_end[1] : a.rp_end[2]);
@@ -333,8 +378,8 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
             w0 = w1 = mi == 0 ? a.w[0] : (mi == 1 ? a.w[1] : a.w[2]);
             type0 = type1 = mi == 0 ? a.type[0] : (mi == 1 ? a.type[1] : a.type[2]);
         }
-        r0 = w0 + (size_t) m0 * row_size(type0, a.K);
-        r1 = w1 + (size_t) (a.silu_mul ? m0 : m0 + 1) * row_size(type1, a.K);
+        r0 = w0 + (size_t) m0 * row_size(type0, aK);
+        r1 = w1 + (size_t) (a.silu_mul ? m0 : m0 + 1) * row_size(type1, aK);
     };
     float acc0 = 0.0f, acc1 = 0.0f;
     PKV_UNIT_DECL(A) PKV_UNIT_DECL(B)
@@ -344,33 +389,17 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
     auto step = [&](int & r, int & f) { if (++f == n_f0) { f = 0; ++r; } };
 #define PKV_LOAD_NEXT(S) { const bool past_ = lr >= n_rp; if (PKV_GEMV_ABLATE == 3 && past_) {} else PKV_UNIT_LOAD(S, past_ ? n_rp - 1 : lr, past_ ? n_f0 - 1 : lf, past_) step(lr, lf); }
 #define PKV_COMPUTE_NEXT(S) { PKV_UNIT_COMPUTE(S, cr, cf) step(cr, cf); }
-    // The column's own loads go out FIRST.  Vector-memory results return in issue order (one vmcnt counter per wave) and a CU serves its
-    // requests first come, first served: r02 requested two units of weights per wave (192 KB per CU at 16 waves) ahead of the column, so the
-    // column (16-57 KB, L2-resident) arrived behind ALL of them — the norm / quantize prologue started 5-8 us into the launch and every dot
-    // waited for it (ffn_down: the whole matrix had landed before the first dot ran; profiles/r03_gemv_read_pattern.txt: a bare read of the same
-    // bytes takes 6.5 us where the product took 12.0).  Now: column loads, then the weight loads, then a counted wait for the column alone.
-    const int n4 = (int) (a.K >> 2);
-    const bool colk = PKV_GEMV_ABLATE != 2 && a.img == nullptr;      // the column is normalised / quantized here (no image from a launch of its own)
-    constexpr int NV = 2048 / NT;                                    // float4 per thread of the norm path (K <= 8192, checked on the host)
-    constexpr int NVP = NT >= 512 ? 4096 / NT : 8;                   // ... preloaded without a norm: K <= 16384 (8192 at 4 waves) in one round trip, the rest in batches
-    float4 v[NVP], w4[NV];
-    if (colk) {
-#pragma unroll
-        for (int j = 0; j < NVP; ++j) {                              // float4 index i = tid + NT j: the 64 lanes of a wave hold one 256-block (n4 % 64 == 0)
-            const int i = threadIdx.x + NT * j;
-            v[j] = i - lane < n4 ? reinterpret_cast<const float4 *>(a.x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (a.norm_w) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = threadIdx.x + NT * j;
-                w4[j] = i - lane < n4 ? reinterpret_cast<const float4 *>(a.norm_w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
     __builtin_amdgcn_sched_barrier(0);
     PKV_LOAD_NEXT(A)                                                  // the first weight loads fly while the column is prepared
+#if PKV_GEMV_ABLATE == 4
+    PKV_LOAD_NEXT(B)
+#endif
     __builtin_amdgcn_sched_barrier(0);
+    PKV_STAMP(2)                                                      // column + unit A requested
+#if PKV_GEMV_STAMPS == 1
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 3);                           // vmcnt(3): (q4_K) the column has landed — clean phase shares
+    PKV_STAMP(3)
+#endif
 
     // tail of a group's record from the quantizer's registers: lane = float4 i of the column (dword i & 15 of group i >> 4)
     auto put_tail = [&](int i, float d, int bs32, int bs16) {
@@ -380,12 +409,12 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
         if ((i & 15) == 0) r[2] = __float_as_uint(d);                 // the 256-block's scale, once per 64-group
     };
     if (PKV_GEMV_ABLATE == 2) {} else
-    if (a.img) {
+    if (aimg) {
         // the column image was made by a launch of its own: K / 4 dwords of int8, the 256-block scales, the per-32 sums
-        const uint32_t * qi = reinterpret_cast<const uint32_t *>(a.img);
-        const float * dd = reinterpret_cast<const float *>(a.img + a.K);
-        const int *   bb = reinterpret_cast<const int *>(a.img + a.K + (a.K >> 8) * 4);
-        for (int i = threadIdx.x; i < (int) (a.K >> 2); i += NT) {
+        const uint32_t * qi = reinterpret_cast<const uint32_t *>(aimg);
+        const float * dd = reinterpret_cast<const float *>(aimg + aK);
+        const int *   bb = reinterpret_cast<const int *>(aimg + aK + (aK >> 8) * 4);
+        for (int i = threadIdx.x; i < (int) (aK >> 2); i += NT) {
             const uint32_t w = qi[i];
             sq[(i >> 4) * REC + (i & 15)] = w;
             if constexpr (TAIL == 1) {                                // per-16 sums are not in the image: from the quants (4 lanes = one run of 16)
@@ -397,7 +426,7 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
         }
         for (int g = threadIdx.x; g < gpr; g += NT) sq[g * REC + 18] = __float_as_uint(dd[g >> 2]);
         if constexpr (TAIL == 0)
-            for (int b = threadIdx.x; b < (int) (a.K >> 5); b += NT) sq[(b >> 1) * REC + 16 + (b & 1)] = (uint32_t) bb[b];
+            for (int b = threadIdx.x; b < (int) (aK >> 5); b += NT) sq[(b >> 1) * REC + 16 + (b & 1)] = (uint32_t) bb[b];
     } else {
         // ... or here: [rms_norm(x) * w ->] q8_K straight into LDS.
         // The sum of squares is the canonical one of pkv_common.h (f32 squares accumulated in f64 per 256-block, blocks added in order), the same
@@ -408,7 +437,7 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
             sq[(i >> 4) * REC + (i & 15)] = packed;
             put_tail(i, d, bs, bs16);
         };
-        if (a.norm_w) {
+        if (anw) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int b = wv + NWV * j;                           // the wave's 256-block of pass j
@@ -417,8 +446,14 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
                     if (lane == 0) sred[b] = bsum;
                 }
             }
+            PKV_STAMP(16)
             __syncthreads();
-            const float scale = rms_scale(sred, (n4 + 63) >> 6, a.K, a.eps);
+            PKV_STAMP(17)
+            const float scale = rms_scale(sred, (n4 + 63) >> 6, aK, aeps);
+#if PKV_GEMV_STAMPS
+            st_[19] = (unsigned long long) __float_as_uint(scale);   // (forces the value)
+#endif
+            PKV_STAMP(18)
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = threadIdx.x + NT * j;                   // n4 % 64 == 0: a wave is in or out as a whole
@@ -439,28 +474,48 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const GemvArgs a) {
             for (int i0 = threadIdx.x + NT * NVP; i0 - lane < n4; i0 += NT * NB8) {
                 float4 vb[NB8];
 #pragma unroll
-                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; vb[j] = reinterpret_cast<const float4 *>(a.x)[i - lane < n4 ? i : i0]; }
+                for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; vb[j] = reinterpret_cast<const float4 *>(ax)[i - lane < n4 ? i : i0]; }
 #pragma unroll
                 for (int j = 0; j < NB8; ++j) { const int i = i0 + NT * j; if (i - lane < n4) put(i, vb[j]); }
             }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+#if PKV_GEMV_ABLATE != 4
     PKV_LOAD_NEXT(B)                                                  // the wave's second unit: requested as soon as its share of the column is in LDS
+#endif
     __builtin_amdgcn_sched_barrier(0);
+    PKV_STAMP(4)                                                      // this wave's share of the column is in LDS, unit B requested
     __syncthreads();
+    PKV_STAMP(5)
 
     if constexpr (SHORT) {
         PKV_COMPUTE_NEXT(A)
+        PKV_STAMP(6)
         if (n_it > 1) PKV_COMPUTE_NEXT(B)
+        PKV_STAMP(7)
     } else {
         for (int it = 0; it < n_it; it += 2) {           // two units in flight behind the one being consumed
             PKV_COMPUTE_NEXT(A)
+#if PKV_GEMV_STAMPS
+            if (it == 0) PKV_STAMP(6) else if (it == 2) PKV_STAMP(8) else if (it + 2 >= n_it) PKV_STAMP(10)
+#endif
             PKV_LOAD_NEXT(A)
             if (it + 1 < n_it) PKV_COMPUTE_NEXT(B)
+#if PKV_GEMV_STAMPS
+            if (it == 0) PKV_STAMP(7) else if (it == 2) PKV_STAMP(9) else if (it + 2 >= n_it) PKV_STAMP(11)
+#endif
             PKV_LOAD_NEXT(B)
         }
     }
+#if PKV_GEMV_STAMPS
+    PKV_STAMP(12)
+    __builtin_amdgcn_s_waitcnt(0);                                    // stores acknowledged, stray requests back
+    PKV_STAMP(13)
+    st_[14] = __builtin_amdgcn_s_memrealtime();
+    st_[15] = (unsigned long long) n_it;
+    if (a.stamps && lane == 0) for (int i = 0; i < 20; ++i) a.stamps[((size_t) blockIdx.x * NWV + wv) * 20 + i] = st_[i];
+#endif
 }
 
 // ---- ggml_get_rows (/ref/src/llama-model.cpp:4047 inp_embd = get_rows(tok_embd, tokens); CPU kernel ggml_compute_forward_get_rows,
@@ -571,6 +626,9 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     a.n = g.n; a.silu_mul = g.silu_mul; a.residual = g.residual; a.img = (const char *) g.xq; a.K = g.K;
     a.x = g.x; a.norm_w = g.xq ? nullptr : g.norm_w; a.eps = g.eps;
     a.norm_out = a.norm_w ? g.norm_out : nullptr; a.col_out = a.norm_w ? g.col_out : nullptr;
+#if PKV_GEMV_STAMPS
+    if (const char * e = getenv("PKV_GEMV_STAMP_PTR")) a.stamps = (unsigned long long *) strtoull(e, nullptr, 0);   // device buffer [grid][waves][16] of the caller
+#endif
     a.gpr = (int) (g.K / 64); a.gs = 0;
     const size_t lds = (size_t) REC * a.gpr * 4;
     // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)
@@ -578,6 +636,9 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     for (int i = 0; i < g.n; ++i) { all4 = all4 && tw[i] == PKV_TYPE_Q4_K; all6 = all6 && tw[i] == PKV_TYPE_Q6_K; }
     const int mode = all4 ? PKV_TYPE_Q4_K : (all6 ? PKV_TYPE_Q6_K : 0);
     int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
+    // (8 waves with exactly 7 row pairs each instead of 16 with 3 or 4 — gate + up at Llama-3-8B sizes — is SLOWER, 16.4 vs 14.3 us: the waves hide
+    // each other's load latency; profiles/r03_gemv_shapes.txt)
+    if (const char * e = getenv("PKV_GEMV_NWV")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) nwv = v; }   // experiments
     int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
     // long rows, few of them (ffn_down): two waves per row pair, 16 waves per CU
     const int f_half = ((a.gpr + 63) / 64) * 64;
@@ -586,7 +647,8 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     const int ui = 1;                                                // items per lane and unit (the kernel's UI)
     const int n_f0 = ((split ? f_half : 2 * a.gpr) + 64 * ui - 1) / (64 * ui);
     const bool shrt = (int64_t) (split ? 1 : (tot + grid * nwv - 1) / (grid * nwv)) * n_f0 <= 2;
-#define PKV_GEMV_LAUNCH(MODE_, NWV_, SHORT_, KS_, PK_) hipLaunchKernelGGL((gemv_kernel<MODE_, NWV_, SHORT_, KS_, PK_>), dim3((unsigned) grid), dim3(64 * NWV_), lds, st, a)
+#define PKV_GEMV_LAUNCH(MODE_, NWV_, SHORT_, KS_, PK_) hipLaunchKernelGGL((gemv_kernel<MODE_, NWV_, SHORT_, KS_, PK_>), dim3((unsigned) grid), dim3(64 * NWV_), lds, st, \
+                                                                          a.x, a.norm_w, a.img, (int) a.K, a.eps, a)
 #define PKV_GEMV_PICK_S(MODE_, NWV_, KS_, PK_) do { if (shrt) PKV_GEMV_LAUNCH(MODE_, NWV_, true, KS_, PK_); else PKV_GEMV_LAUNCH(MODE_, NWV_, false, KS_, PK_); } while (0)
 #define PKV_GEMV_PICK_W(MODE_, PK_) do { if (split) PKV_GEMV_PICK_S(MODE_, 16, 2, PK_); else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16, 1, PK_); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8, 1, PK_); else PKV_GEMV_PICK_S(MODE_, 4, 1, PK_); } while (0)
 #define PKV_GEMV_PICK_P(MODE_) do { if (packed) PKV_GEMV_PICK_W(MODE_, true); else PKV_GEMV_PICK_W(MODE_, false); } while (0)
