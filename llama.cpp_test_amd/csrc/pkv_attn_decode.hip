@@ -941,64 +941,67 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
 }
 
 // merge the per-block partials: out = sum_j O_j e^{m_j - M} / sum_j l_j e^{m_j - M}.
-// One workgroup per (sequence, query head), thread d owns output column d.  The kernel is pure latency (a few KB per
-// workgroup), so every load it will ever need — this thread's column of up to CH partials AND the (m, l) pairs — is
-// issued before the first dependent instruction: one memory round trip instead of two.
+// ONE WAVE per (sequence, query head), lane = D / 64 adjacent output columns.  The kernel is pure latency (a few KB per wave), so every load
+// it will ever need — this lane's columns of up to CH partials AND the (m, l) pairs — is issued before the first dependent instruction: one
+// memory round trip instead of two.  r03: no LDS and no barrier any more (r02: D threads per head, one 4-byte column each, three barriers, the
+// weights handed round through LDS; 4.6 us per launch against a 1.8 us empty launch): lane j < 32 owns split j of a pass exactly as thread j
+// did, the maximum and the sum of the weights are wave reductions, weight u reaches every lane as an SGPR (v_readlane) — the same additions in
+// the same order as before, bit for bit, with half the load instructions (D = 128: 8-byte loads) and a quarter of the waves.
 template <int D>
-__global__ void __launch_bounds__(D) attn_combine_kernel(const DecodeArgs a) {
+__global__ void __launch_bounds__(64) attn_combine_kernel(const DecodeArgs a) {
     constexpr int CH = 32;  // splits per pass (ctx 4096 = one pass)
-    __shared__ float sW[CH];
-    __shared__ float sRed[2][D / 64];
-    const int h = blockIdx.x, s = blockIdx.y, d = threadIdx.x, wave = d >> 6, lane = d & 63;
+    constexpr int C = D / 64;                                   // columns per lane
+    static_assert(D % 64 == 0 && (C == 1 || C == 2 || C == 4), "head size");
+    typedef float colv __attribute__((ext_vector_type(C)));
+    const int h = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
     const int seq_len = a.seq_lens[s];
     const float * ml = a.part_ml + ((size_t) s * a.n_head + h) * a.n_splits * 2;
-    const float * po = a.part_o + ((size_t) s * a.n_head + h) * a.n_splits * D;
+    const float * po = a.part_o + ((size_t) s * a.n_head + h) * a.n_splits * D + C * lane;
     // The first pass of columns and of (m, l) pairs is requested BEFORE seq_len is back: the addresses only need the
     // host-known split count (slots past the sequence's own count hold stale partials; they are selected away below,
     // never multiplied), so the sequence length and the data share one memory round trip.
     const int nsm = a.n_splits - 1;
-    float pv[CH];
+    colv pv[CH];
 #pragma unroll
-    for (int u = 0; u < CH; ++u) pv[u] = po[(size_t) min(u, nsm) * D + d];
-    const float2 ml0 = *reinterpret_cast<const float2 *>(ml + (size_t) min(d, nsm) * 2);
+    for (int u = 0; u < CH; ++u) pv[u] = *reinterpret_cast<const colv *>(po + (size_t) min(u, nsm) * D);
+    const float2 ml0 = *reinterpret_cast<const float2 *>(ml + (size_t) min(lane, nsm) * 2);
     const int ns = (seq_len + WG_TOK - 1) / WG_TOK;
-    float * o = a.out + ((size_t) s * a.n_head + h) * D;
-    if (ns <= 0) { o[d] = 0.0f; return; }
-    float m = d < ns ? ml0.x : -INFINITY;
-    for (int j = d + D; j < ns; j += D) m = fmaxf(m, ml[j * 2]);
-    m = wave_max(m);
-    if (lane == 0) sRed[0][wave] = m;
-    __syncthreads();
-    float M = sRed[0][0];
+    float * o = a.out + ((size_t) s * a.n_head + h) * D + C * lane;
+    if (ns <= 0) { colv z; for (int c = 0; c < C; ++c) z[c] = 0.0f; *reinterpret_cast<colv *>(o) = z; return; }
+    float m = lane < ns ? ml0.x : -INFINITY;
+    for (int j = lane + 64; j < ns; j += 64) m = fmaxf(m, ml[j * 2]);
+    const float M = wave_max(m);
+    float L = 0.0f;
+    colv acc;
 #pragma unroll
-    for (int w = 1; w < D / 64; ++w) M = fmaxf(M, sRed[0][w]);
-    float L = 0.0f, acc = 0.0f;
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
     for (int j0 = 0; j0 < ns; j0 += CH) {
         const int n = min(CH, ns - j0);
         float2 v = ml0;
         if (j0 > 0) {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) pv[u] = po[(size_t) (j0 + min(u, n - 1)) * D + d];
-            if (d < n) v = *reinterpret_cast<const float2 *>(ml + (size_t) (j0 + d) * 2);
+            for (int u = 0; u < CH; ++u) pv[u] = *reinterpret_cast<const colv *>(po + (size_t) (j0 + min(u, n - 1)) * D);
+            if (lane < n) v = *reinterpret_cast<const float2 *>(ml + (size_t) (j0 + lane) * 2);
         }
         float w = 0.0f;
-        if (d < n) {
+        if (lane < n) {
             w = v.x == -INFINITY ? 0.0f : __expf(v.x - M);
             L = fmaf(v.y, w, L);
         }
-        __syncthreads();  // previous pass finished reading sW
-        if (d < CH) sW[d] = w;
-        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < CH; ++u) acc = u < n ? fmaf(pv[u], sW[u], acc) : acc;
+        for (int u = 0; u < CH; ++u) {
+            const float wu = __uint_as_float((unsigned) __builtin_amdgcn_readlane((int) __float_as_uint(w), u));   // lanes >= n hold 0
+            if (u < n) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(pv[u][c], wu, acc[c]);
+            }
+        }
     }
-    L = wave_sum(L);
-    if (lane == 0) sRed[1][wave] = L;
-    __syncthreads();
-    float Ls = sRed[1][0];
+    const float Ls = wave_sum(L);
+    colv r;
 #pragma unroll
-    for (int w = 1; w < D / 64; ++w) Ls += sRed[1][w];
-    o[d] = acc / Ls;  // all cells masked -> 0/0 = NaN, like the reference's 1/S with S == 0
+    for (int c = 0; c < C; ++c) r[c] = acc[c] / Ls;  // all cells masked -> 0/0 = NaN, like the reference's 1/S with S == 0
+    *reinterpret_cast<colv *>(o) = r;
 }
 
 // measurement hook (pkv_attn_decode_profiled): when set, the split-KV kernel is launched with start/stop events that
@@ -1040,7 +1043,7 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
         if (da.stamps) { set_error("pkv_attn_decode_stamps: f16 KV, head_dim 128, gqa 4 or 8 only"); return PKV_ERR_UNSUPPORTED; }
         if constexpr (QKV) { if (wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, TQ>, grid, block32, st, da); }
         if (!wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
-        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
+        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
     } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, false>, grid, block, st, da);
     } else {
@@ -1050,7 +1053,7 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
         else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false, false>, grid, block, st, da);
         else if (cap && !sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, false, false, false>, grid, block, st, da);
         else                  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, true, false, false>, grid, block, st, da);
-        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(D), 0, st, da);
+        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
     }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
