@@ -9,9 +9,10 @@ this path, so `value` is attention-path tok/s, not end-to-end
 Inputs are synthetic, seeded, already resident in HBM; the 32 layers hold 512 MiB of distinct KV (> 2x the 256 MiB
 Infinity Cache), so the dominant kernel streams from HBM, not from MALL.
 
-    python bench.py                       # 1 GPU
+    python bench.py                       # 1 GPU: the headline line + `configs` (BASELINE's other single-GPU configurations) + `e2e` (whole model)
+    python bench.py --gpus N              # N independent replicas: this process starts the N ranks itself (child processes) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W     # N independent replicas (one block pool per GPU, no collective
+        bench.py --gpus N --steps K --warmup W     # ... or under an outside launcher (one block pool per GPU, no collective
                                                      on the data path; RCCL only carries the barrier / max-time)
 Prints ONE JSON line on rank 0.
 """
@@ -206,7 +207,7 @@ def cpu_baseline(w: Workload, pkv, budget_s: float = 20.0):
 LLAMA3_8B = dict(n_layer=32, n_embd=4096, n_head=32, n_head_kv=8, n_ff=14336, n_vocab=128256, n_ctx=8192, rope_freq_base=500000.0)
 
 
-def e2e_record(pkv, torch, *, ctx: int, steps: int, warmup: int, cpu: bool):
+def e2e_record(pkv, torch, *, ctx: int, steps: int, warmup: int, cpu: bool, reps: int = 5):
     """The metric's other half: a FULL decode step of Llama-3-8B geometry (Q4_K_M tensor-type mix: q4_K with q6_K output / attn_v / ffn_down
     of the use_more_bits layers; synthetic, seeded, well-formed blocks), ONE sequence at `ctx`, run by the repo's own host loop
     (llama.cpp_test_amd/decoder.py: own GGUF loader -> pkv_get_rows / pkv_rms_norm_mul_q / pkv_gemv_q / pkv_attn_decode_step through the C ABI),
@@ -240,6 +241,14 @@ def e2e_record(pkv, torch, *, ctx: int, steps: int, warmup: int, cpu: bool):
                 g.replay()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
+            rep_tok_s = []
+            for _ in range(reps):                                     # llama-bench: repetitions for mean +- stdev
+                torch.cuda.synchronize()
+                r0 = time.perf_counter()
+                for _ in range(steps):
+                    g.replay()
+                torch.cuda.synchronize()
+                rep_tok_s.append(steps / (time.perf_counter() - r0))
         wb = dec.weight_bytes()
         kvb = LLAMA3_8B["n_layer"] * algorithmic_bytes(ctx, pkv.F16, pkv.F16, pkv, GEOM)
         finite = bool(torch.isfinite(dec.logits).all().item())
@@ -247,6 +256,7 @@ def e2e_record(pkv, torch, *, ctx: int, steps: int, warmup: int, cpu: bool):
         for name, (t, ty, ne) in dec.w.items():
             n_types[ty & ~pkv.PACKED] = n_types.get(ty & ~pkv.PACKED, 0) + t.numel()
         rec = {"value": round(1.0 / dt, 2), "unit": "tok/s", "ms_per_token": round(dt * 1e3, 4), "steps": steps, "warmup": warmup,
+               "repetitions": {"n": reps, "mean_tok_s": round(float(np.mean(rep_tok_s)), 2), "stdev_tok_s": round(float(np.std(rep_tok_s, ddof=1)), 2)} if reps > 1 else None,
                "workload": f"Llama-3-8B geometry, Q4_K_M tensor mix (synthetic GGUF {os.path.getsize(path) / 2**30:.2f} GiB: "
                            + ", ".join(f"{ {0: 'f32', 12: 'q4_K', 14: 'q6_K'}.get(k, k)} {v / 2**20:.0f} MiB" for k, v in sorted(n_types.items()))
                            + f"), f16 KV, 1 sequence at ctx {ctx}, single-token decode incl. lm_head",
@@ -308,7 +318,7 @@ def e2e_cpu_baseline(path: str, ctx: int, steps: int = 6):
             "sample": f"{steps} llama_decode steps of the reference's CPU backend ({cores} threads) on the same GGUF at ctx {ctx} (context restored from a session blob), {dt * 1e3:.1f} ms/token"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -327,7 +337,219 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end record (full Llama-3-8B Q4_K_M decode step through the own host loop)")
     ap.add_argument("--e2e-steps", type=int, default=30)
-    args = ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` sub-record (short runs of BASELINE's other single-GPU configurations)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions behind the timed steps for mean +- stdev (llama-bench: 1 warm-up + 5 repetitions)")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` without an outside launcher: start the N ranks as CHILD processes (`python -m torch.distributed.run`, one per GPU),
+    relay rank 0's JSON line, exit non-zero if a rank fails.  Runs before anything in this process has touched torch or the GPU (a process that has
+    initialised HIP must never be replaced or forked into ranks)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout[-4000:])
+        sys.stderr.write(f"\nbench.py: the {n}-rank launch failed (exit code {p.returncode}, JSON line {'missing' if line is None else 'present'})\n")
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def rehearsal_rank(args) -> int:
+    """CPU REHEARSAL of the N-rank protocol (tests only, PKV_BENCH_CPU_REHEARSAL=1; never a measurement and the line says so): each rank drives its own
+    bookkeeping-only block manager (find_slot / seq_rm churn of its sequences) where a GPU rank replays its step, then the same barrier, max-over-ranks
+    and whole-job aggregation, over gloo."""
+    import torch
+    import torch.distributed as dist
+    import _load_pkg
+    pkv = _load_pkg.load()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist.init_process_group("gloo")
+    if os.environ.get("PKV_BENCH_REHEARSAL_FAIL_RANK") == str(rank):      # tests: a rank that dies must fail the whole launch
+        raise SystemExit(3)
+    c = pkv.PagedKVCache(n_blocks=args.n_seq * 4, block_size=128, n_seq_max=args.n_seq, n_layer=0)
+
+    def step(i):
+        c.find_slot(list(range(args.n_seq)), [i % 256] * args.n_seq)
+        if i % 256 == 255:
+            c.clear()
+    for i in range(args.warmup):
+        step(i)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(world * args.n_seq * args.steps / dt, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "REHEARSAL on CPU (PKV_BENCH_CPU_REHEARSAL): host block-manager traffic only, no kernel ran - not a measurement",
+                          "config": {"workload": "rank protocol rehearsal", "parallelism": f"replicas x{world} (no collective on the data path)"}}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def timed_config(pkv, torch, *, model, ctx, n_seq, kv_type, steps, warmup, reps, kernel_reps, dist=None, shared=False, rank=0, world=1, no_graph=False, fused_merge=False,
+                 two_call=False, keep=False):
+    """one configuration of the attention path: W warm-up steps, K timed steps between barriers (max over ranks), then `reps` repetitions of K steps for
+    mean +- stdev (llama-bench's 1 warm-up + 5 repetitions, /root/reference/examples/llama-bench/llama-bench.cpp:1604-1641), the dominant kernel's own duration and its roofline"""
+    t = pkv.TYPE_BY_NAME[kv_type]
+    g = GEOM if model == "8b" else GEOM_70B
+    w = Workload(pkv, torch, ctx=ctx, n_seq=n_seq, type_k=t, type_v=t, seed=1234 + rank, g=g)
+    w.step_flags = pkv.ATTN_FUSED_COMBINE if fused_merge else 0
+    w.fused_step = not two_call
+    side = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(side):
+        w.step()
+        torch.cuda.synchronize()
+        if not no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                w.step()
+        run = graph.replay if graph is not None else w.step
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        rep_tok_s = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            torch.cuda.synchronize()
+            rep_tok_s.append(n_seq * steps / (time.perf_counter() - r0))
+        k_mean, k_med, k_min = measure_dominant_kernel(w, torch, kernel_reps)
+    k_graph = None
+    if not fused_merge and not no_graph:
+        k_graph = measure_dominant_kernel_graph(w, torch, side, max(5, kernel_reps))
+    bytes_launch = n_seq * algorithmic_bytes(ctx, t, t, pkv, g)
+    k_used = k_graph if k_graph is not None else k_mean
+    achieved = bytes_launch / k_used / 1e9
+    rec = {"tok_s": world * n_seq * steps / dt, "dt": dt, "graph": graph is not None, "w": w if keep else None, "g": g, "t": t,
+           "reps": {"n": reps, "mean_tok_s": round(float(np.mean(rep_tok_s)), 2), "stdev_tok_s": round(float(np.std(rep_tok_s, ddof=1)), 2)} if reps > 1 else None,
+           "bytes_launch": bytes_launch, "achieved": achieved,
+           "kernel_us": {"mean": round(k_used * 1e6, 3), "event_bound_mean": round(k_mean * 1e6, 3), "event_bound_median": round(k_med * 1e6, 3), "event_bound_min": round(k_min * 1e6, 3)},
+           "k_graph": k_graph is not None}
+    if not keep:
+        del w
+        torch.cuda.empty_cache()
+    return rec
+
+
+def configs_record(pkv, torch, *, reps, kernel_reps):
+    """BASELINE.json's other single-GPU configurations as short runs under the same clock (value of the headline line untouched): 32 sequences x ctx 4096 (f16 and q8_0
+    KV), 32 x ctx 640 (the decode step at the end of config 3), Llama-3-70B geometry at ctx 16384 (config 5), and config 3 itself with batched-bench semantics"""
+    out = {}
+    for name, kw in (("8b_32seq_ctx4096_f16", dict(model="8b", ctx=4096, n_seq=32, kv_type="f16", steps=20, warmup=3)),
+                     ("8b_32seq_ctx4096_q8_0", dict(model="8b", ctx=4096, n_seq=32, kv_type="q8_0", steps=20, warmup=3)),
+                     ("8b_32seq_ctx640_f16", dict(model="8b", ctx=640, n_seq=32, kv_type="f16", steps=50, warmup=5)),
+                     ("70b_1seq_ctx16384_f16", dict(model="70b", ctx=16384, n_seq=1, kv_type="f16", steps=20, warmup=3))):
+        try:
+            r = timed_config(pkv, torch, reps=reps, kernel_reps=max(3, kernel_reps // 4), **kw)
+            out[name] = {"value": round(r["tok_s"], 2), "unit": "tok/s", "ms_per_step": round(r["dt"] / kw["steps"] * 1e3, 5), "steps": kw["steps"], "repetitions": r["reps"],
+                         "roofline": {"bound": "hbm", "achieved": round(r["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(r["achieved"] / HBM_PEAK_GBS, 4),
+                                      "algorithmic_bytes_per_launch": r["bytes_launch"], "kernel_us": r["kernel_us"]}}
+        except Exception as e:   # one configuration must not take the line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        out["8b_batched_bench_32x_pp512_tg128_f16"] = batched_bench_record(pkv, torch, npl=32, npp=512, ntg=128, n_batch=2048, kv_type="f16", reps=reps)
+    except Exception as e:
+        out["8b_batched_bench_32x_pp512_tg128_f16"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps):
+    """llama-batched-bench semantics over the attention path (/root/reference/examples/batched-bench/batched-bench.cpp:150-175): per repetition clear the cache (block alloc /
+    free churn), prefill PP tokens for each of B sequences in ubatches of n_batch tokens, then TG decode steps of B tokens, host block manager in the loop, eager launches;
+    S_PP = B PP / T_PP, S_TG = B TG / T_TG; 1 warm-up + `reps` repetitions, mean +- stdev"""
+    from llama_cpp_test_amd.runner import AttnPathRunner
+    L, H, HK, D, BS = GEOM["n_layer"], GEOM["n_head"], GEOM["n_head_kv"], GEOM["head_dim"], GEOM["block_size"]
+    t = pkv.TYPE_BY_NAME[kv_type]
+    ctx = npp + ntg
+    r = AttnPathRunner(n_layer=L, n_head=H, n_head_kv=HK, head_dim=D, type_k=t, type_v=t, n_blocks=npl * (-(-ctx // BS)), n_seq_max=npl, max_batch_tokens=max(n_batch, npl),
+                       max_seq_len=-(-ctx // BS) * BS)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    nmax = max(n_batch, npl)
+    q = [torch.rand((nmax, H, D), generator=gen, device="cuda") * 2 - 1 for _ in range(L)]
+    k = [torch.rand((nmax, HK, D), generator=gen, device="cuda") * 2 - 1 for _ in range(L)]
+    v = [torch.rand((nmax, HK, D), generator=gen, device="cuda") * 2 - 1 for _ in range(L)]
+    out = [torch.empty((nmax, H, D), device="cuda") for _ in range(L)]
+
+    def run(seq_ids, poss):
+        n = len(seq_ids)
+        plan = r.plan(seq_ids, poss)
+        for il in range(L):
+            r.layer(il, plan, q[il][:n], k[il][:n], v[il][:n], out[il][:n])
+    spp, stg = [], []
+    for rep in range(reps + 1):
+        r.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks = [(s, p) for s in range(npl) for p in range(npp)]              # sequence-major like batched-bench's prompt batch
+        for i in range(0, len(toks), n_batch):
+            chunk = toks[i:i + n_batch]
+            run([s for s, _ in chunk], [p for _, p in chunk])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(ntg):
+            run(list(range(npl)), [npp + i] * npl)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if rep:
+            spp.append(npl * npp / (t1 - t0))
+            stg.append(npl * ntg / (t2 - t1))
+    r.close() if hasattr(r, "close") else None
+    del q, k, v, out
+    torch.cuda.empty_cache()
+    sd = lambda a: round(float(np.std(a, ddof=1)), 1) if len(a) > 1 else 0.0   # noqa: E731
+    return {"S_PP": round(float(np.mean(spp)), 1), "S_PP_stdev": sd(spp), "S_TG": round(float(np.mean(stg)), 1), "S_TG_stdev": sd(stg), "unit": "tok/s", "repetitions": reps,
+            "workload": f"batched-bench semantics, B={npl} PP={npp} TG={ntg} n_batch={n_batch}, {kv_type} KV, attention path of all {L} layers, host block manager in the loop, eager launches"}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    # N > 1 started plainly: this process only launches the ranks (before torch / the library / any HIP call) and relays rank 0's line
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, argv)
+    if os.environ.get("PKV_BENCH_CPU_REHEARSAL"):
+        return rehearsal_rank(args)
 
     import torch
     import _load_pkg
@@ -337,7 +559,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
     if n_dev == 0:
@@ -354,47 +576,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local % n_dev))
 
-    t = pkv.TYPE_BY_NAME[args.kv_type]
-    g = GEOM if args.model == "8b" else GEOM_70B
-    w = Workload(pkv, torch, ctx=args.ctx, n_seq=args.n_seq, type_k=t, type_v=t, seed=1234 + rank, g=g)
-    w.step_flags = pkv.ATTN_FUSED_COMBINE if args.fused_merge else 0
-    w.fused_step = not args.two_call
-
     # one decode step = 32 layers x (fused RoPE(Q)+RoPE(K)+KV store, split-KV attention, merge); captured once, replayed per step
-    side = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(side):
-        w.step()
-        torch.cuda.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                w.step()
-        run = graph.replay if graph is not None else w.step
-
-        def barrier():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-
-        k_mean, k_med, k_min = measure_dominant_kernel(w, torch, args.kernel_reps)
-    k_graph = None
-    if not args.fused_merge and not args.no_graph:
-        k_graph = measure_dominant_kernel_graph(w, torch, side, max(5, args.kernel_reps))
+    r = timed_config(pkv, torch, model=args.model, ctx=args.ctx, n_seq=args.n_seq, kv_type=args.kv_type, steps=args.steps, warmup=args.warmup, reps=args.reps if world == 1 else 0,
+                     kernel_reps=args.kernel_reps, dist=dist, shared=shared, rank=rank, world=world, no_graph=args.no_graph, fused_merge=args.fused_merge, two_call=args.two_call, keep=True)
+    w, g, t, dt = r["w"], r["g"], r["t"], r["dt"]
 
     traffic = None
     try:   # PMC traffic cannot be collected from inside the run: taken from the committed rocprofv3 passes, if this workload has one AND the passes
@@ -406,47 +591,48 @@ def main():
             traffic = tj.get(f"{args.kv_type}_ctx{args.ctx}_nseq{args.n_seq}")
     except Exception:
         pass
-    tok_s = world * args.n_seq * args.steps / dt
-    bytes_launch = args.n_seq * algorithmic_bytes(args.ctx, t, t, pkv, g)
-    k_used = k_graph if k_graph is not None else k_mean
-    achieved = bytes_launch / k_used / 1e9
     line = {
-        "metric": METRIC, "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps,
+        "metric": METRIC, "value": round(r["tok_s"], 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.kv_type if args.kv_type != "f16" else "f16",
         "data": "synthetic",
         "config": {"workload": f"Llama-3-{args.model.upper()} geometry, {args.n_seq} seq/GPU, ctx {args.ctx} paged decode "
                                f"(block_size 128, {args.kv_type} KV), attention path of all {g['n_layer']} layers per token",
                    "n_layer": g["n_layer"], "n_head": g["n_head"], "n_head_kv": g["n_head_kv"], "head_dim": 128, "block_size": 128, "ctx": args.ctx,
-                   "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "eager" if graph is None else "hipGraph", "merge": "in-kernel (last-arriving workgroup)" if args.fused_merge else "second launch",
+                   "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "hipGraph" if r["graph"] else "eager", "merge": "in-kernel (last-arriving workgroup)" if args.fused_merge else "second launch",
                    "step": "pkv_attn_decode_step (RoPE + KV store inside the decode launch) + merge" if w.fused_step else "pkv_qkv_prepare + pkv_attn_decode",
                    "parallelism": f"replicas x{world} (no collective on the data path)"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "repetitions": r["reps"],
+        "roofline": {"bound": "hbm", "achieved": round(r["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(r["achieved"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
                      "kernel": "pkv::attn_decode_kernel (split-KV paged decode" + (", RoPE(Q,K) + KV store of the new token fused in" if w.fused_step else "") + "; one launch per layer)",
-                     "algorithmic_bytes_per_launch": bytes_launch,
-                     "kernel_us": {"mean": round(k_used * 1e6, 3), "event_bound_mean": round(k_mean * 1e6, 3),
-                                   "event_bound_median": round(k_med * 1e6, 3), "event_bound_min": round(k_min * 1e6, 3)},
+                     "algorithmic_bytes_per_launch": r["bytes_launch"],
+                     "kernel_us": r["kernel_us"],
                      "timing": ("mean = HIP events around back-to-back replays of a hipGraph holding ONLY the n_layer launches of this kernel "
                                 "(elapsed / launches; layers cycled: cold KV); event_bound_* = hipExtLaunchKernel start/stop events of single "
-                                "launches (the event-bound dispatch itself is ~1 us slower)") if k_graph is not None else
+                                "launches (the event-bound dispatch itself is ~1 us slower)") if r["k_graph"] else
                                "hipExtLaunchKernel start/stop events of each launch (GPU timestamps of the dispatch), layers cycled (cold KV)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, pkv)
-    if rank == 0 and world == 1 and not args.no_e2e and args.model == "8b" and args.n_seq == 1 and args.kv_type == "f16":
-        del w                                                         # the attention-path pools make room for the model
-        torch.cuda.empty_cache()
+    del w
+    r["w"] = None
+    torch.cuda.empty_cache()                                          # the attention-path pools make room for the other records
+    headline = args.model == "8b" and args.n_seq == 1 and args.kv_type == "f16"
+    if rank == 0 and world == 1 and not args.no_configs and headline:
+        line["configs"] = configs_record(pkv, torch, reps=args.reps, kernel_reps=args.kernel_reps)
+    if rank == 0 and world == 1 and not args.no_e2e and headline:
         try:
-            line["e2e"] = e2e_record(pkv, torch, ctx=args.ctx, steps=args.e2e_steps, warmup=3, cpu=not args.no_cpu_baseline)
+            line["e2e"] = e2e_record(pkv, torch, ctx=args.ctx, steps=args.e2e_steps, warmup=3, cpu=not args.no_cpu_baseline, reps=args.reps)
         except Exception as e:                                        # the headline record must not be lost to a failure of the extra one
             line["e2e"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

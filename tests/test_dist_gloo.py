@@ -76,3 +76,38 @@ def test_two_rank_replicas():
         flat = [b for blocks, _ in tabs.values() for b in blocks]
         assert len(flat) == len(set(flat))
     assert sorted(seen) == list(range(n_seqs))
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    env = dict(os.environ, PKV_BENCH_CPU_REHEARSAL="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the process starts 2 ranks itself (children, gloo on CPU in this rehearsal), relays ONE JSON line
+    that says n_gpus 2 with the whole-job aggregate — never again a silent one-GPU run"""
+    rc, lines, err = _run_bench({}, "--gpus", "2", "--steps", "40", "--warmup", "4", "--n-seq", "3")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["steps"] == 40 and ln["scaling"] == "weak" and "REHEARSAL" in ln["data"]
+    assert ln["value"] == pytest.approx(2 * 3 * 40 / (ln["ms_per_step"] * 40 / 1e3), rel=1e-3)       # whole job: both ranks' sequences over the max-over-ranks time
+
+
+def test_bench_fails_when_a_rank_fails():
+    rc, lines, _ = _run_bench({"PKV_BENCH_REHEARSAL_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "5", "--warmup", "1")
+    assert rc != 0 and lines == []
+
+
+def test_bench_refuses_a_mismatched_world():
+    """under an outside launcher WORLD_SIZE must equal --gpus (a 1-rank world with --gpus 2 is an error, not a one-GPU result)"""
+    import subprocess
+    env = dict(os.environ, PKV_BENCH_CPU_REHEARSAL="1", WORLD_SIZE="1", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
