@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -60,6 +61,10 @@ struct buffer_ctx {
     void * base;
     std::unordered_map<const void *, kv_mirror> mirrors;   // keyed by the flat tensor's data pointer
     std::unordered_map<const void *, size_t>    tracked;   // flat tensors we have seen as K/V roots -> their byte size
+    // K-quant weight tensors of a WEIGHTS buffer whose rows are in the plane layout (csrc/pkv_wlayout.h): re-laid inside their own bytes by set_tensor, as the
+    // reference's CPU backend repacks on set_tensor (/ref/ggml/src/ggml-cpu/ggml-cpu-aarch64.cpp:4145-4172); get_tensor applies the inverse, so the reference's bytes
+    // round-trip.  Keyed by the tensor's data pointer; the products name such a tensor `type | PKV_TYPE_PACKED`.
+    std::unordered_set<const void *>            packed;
     ~buffer_ctx() { for (auto & kv : mirrors) if (kv.second.pool && !kv.second.in_place) (void) hipFree(kv.second.pool); }
 };
 struct backend_ctx {
@@ -133,64 +138,154 @@ kv_mirror * in_place_of(const ggml_tensor * t, size_t * off_out = nullptr) {
     if (off_out) *off_out = off;
     return &it->second;
 }
-// whole cell rows [off, off + n) of an in-place cache tensor <-> reference-format rows in host memory
-bool in_place_rows(kv_mirror * m, size_t off, size_t n, void * host, bool to_pool) {
+// bytes [off, off + n) of an in-place cache tensor, in the reference's flat row format <-> host memory.  The tile layout is addressed by whole cells: a range that
+// starts or ends inside a cell is served by gathering the touched cells, patching / cutting the byte range on the host side of the staging rows, and (for a write)
+// scattering them back.  The buffer interface has no error return: a failed transfer ABORTS (a dropped write or an uninitialised read would carry on as silent
+// KV corruption — session restore, test-backend-ops' sentinels).
+void in_place_rows(kv_mirror * m, size_t off, size_t n, void * host, bool to_pool) {
+    if (n == 0) return;
     const size_t row_cell = ggml_row_size((ggml_type) m->type, m->D) * m->n_head_kv;
-    if (off % row_cell != 0 || n % row_cell != 0) { MI355_LOG("a write / read of a paged cache tensor must cover whole cells (offset %zu, %zu bytes, %zu per cell)\n", off, n, row_cell); return false; }
-    const int64_t c0 = (int64_t) (off / row_cell), nc = (int64_t) (n / row_cell);
-    if (nc == 0) return true;
+    const int64_t c0 = (int64_t) (off / row_cell), c1 = (int64_t) ((off + n + row_cell - 1) / row_cell), nc = c1 - c0;
+    GGML_ASSERT(c1 <= m->n_cells && "access past the end of a paged cache tensor");
+    const size_t span = (size_t) nc * row_cell, head = off - (size_t) c0 * row_cell;
+    const bool whole = head == 0 && n == span;
     std::vector<int32_t> slot(2 * (size_t) nc);
     for (int64_t i = 0; i < nc; ++i) { slot[i] = (int32_t) ((c0 + i) / BLOCK); slot[nc + i] = (int32_t) ((c0 + i) % BLOCK); }
     void * rows = nullptr; int32_t * dslot = nullptr;
-    bool ok = hipMalloc(&rows, n) == hipSuccess && hipMalloc((void **) &dslot, slot.size() * sizeof(int32_t)) == hipSuccess &&
+    bool ok = hipMalloc(&rows, span) == hipSuccess && hipMalloc((void **) &dslot, slot.size() * sizeof(int32_t)) == hipSuccess &&
               hipMemcpy(dslot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok && to_pool) ok = hipMemcpy(rows, host, n, hipMemcpyHostToDevice) == hipSuccess &&
+    if (ok && (!to_pool || !whole))      // a read, or the cells a partial write does not cover completely
+        ok = pkv_pool_gather_rows(m->pool, m->type, m->is_v, rows, dslot, dslot + nc, (int) nc, m->n_head_kv, m->D, BLOCK, nullptr) == PKV_OK && hipDeviceSynchronize() == hipSuccess;
+    if (ok && to_pool) ok = hipMemcpy((char *) rows + head, host, n, hipMemcpyHostToDevice) == hipSuccess &&
                             pkv_pool_scatter_rows(m->pool, m->type, m->is_v, rows, dslot, dslot + nc, (int) nc, m->n_head_kv, m->D, BLOCK, nullptr) == PKV_OK;
-    if (ok && !to_pool) ok = pkv_pool_gather_rows(m->pool, m->type, m->is_v, rows, dslot, dslot + nc, (int) nc, m->n_head_kv, m->D, BLOCK, nullptr) == PKV_OK &&
-                             hipDeviceSynchronize() == hipSuccess && hipMemcpy(host, rows, n, hipMemcpyDeviceToHost) == hipSuccess;
-    (void) hipDeviceSynchronize();
+    if (ok && !to_pool) ok = hipMemcpy(host, (const char *) rows + head, n, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = hipDeviceSynchronize() == hipSuccess && ok;
     if (rows) (void) hipFree(rows);
     if (dslot) (void) hipFree(dslot);
-    if (!ok) MI355_LOG("paged cache tensor row transfer failed: %s\n", pkv_last_error());
-    return ok;
+    if (!ok) GGML_ABORT("mi355: transfer of %zu bytes at offset %zu %s a paged cache tensor failed: %s", n, off, to_pool ? "into" : "out of", pkv_last_error());
 }
-void buf_memset(ggml_backend_buffer_t, ggml_tensor * t, uint8_t v, size_t off, size_t n) {
+// ---- K-quant weights in the plane layout ------------------------------------------------------------------------------------
+bool packable(const ggml_tensor * t) {
+    static const bool off = getenv("GGML_MI355_NO_PACK") != nullptr;
+    return !off && !t->view_src && t->buffer && t->buffer->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS && (t->type == GGML_TYPE_Q4_K || t->type == GGML_TYPE_Q6_K) &&
+           ggml_is_contiguous(t) && t->ne[0] % 256 == 0;
+}
+// the packed weight tensor `t` is (a row-aligned view of), or NULL
+const ggml_tensor * packed_root(const ggml_tensor * t) {
+    const ggml_tensor * root = t;
+    while (root->view_src) root = root->view_src;
+    if (!root->buffer || root->buffer->iface.free_buffer != buf_free) return nullptr;
+    auto * c = (buffer_ctx *) root->buffer->context;
+    return c->packed.count(root->data) ? root : nullptr;
+}
+int wtype(const ggml_tensor * w) { return (int) w->type | (packed_root(w) ? PKV_TYPE_PACKED : 0); }
+// rows [r0, r1) of a packed tensor <-> GGUF-order bytes in a device staging buffer
+void pack_rows(const ggml_tensor * t, int64_t r0, int64_t r1, void * staging, bool inverse) {
+    const size_t rb = ggml_row_size(t->type, t->ne[0]);
+    char * rows = (char *) t->data + (size_t) r0 * rb;
+    const int rc = inverse ? pkv_weights_pack(rows, staging, (int) t->type, r1 - r0, t->ne[0], 1, nullptr) : pkv_weights_pack(staging, rows, (int) t->type, r1 - r0, t->ne[0], 0, nullptr);
+    if (rc != PKV_OK || hipDeviceSynchronize() != hipSuccess) GGML_ABORT("mi355: re-laying the rows of weight tensor %s failed: %s", t->name, pkv_last_error());
+}
+// bytes [off, off + n) of a packable weight tensor, GGUF order on the host side
+void packed_io(buffer_ctx * c, ggml_tensor * t, size_t off, size_t n, void * host, bool write) {
+    if (n == 0) return;
+    const size_t rb = ggml_row_size(t->type, t->ne[0]), total = ggml_nbytes(t);
+    GGML_ASSERT(off + n <= total);
+    (void) hipDeviceSynchronize();
+    const bool known = c->packed.count(t->data) != 0;
+    if (!known) {   // first contact: whatever the tensor holds (zeros of the fresh buffer, or a memset) becomes packed rows — unless this write replaces all of it anyway
+        if (!(write && off == 0 && n == total)) {
+            void * all = nullptr;
+            if (hipMalloc(&all, total) != hipSuccess || hipMemcpy(all, t->data, total, hipMemcpyDeviceToDevice) != hipSuccess) GGML_ABORT("mi355: staging %zu bytes for weight tensor %s failed", total, t->name);
+            pack_rows(t, 0, (int64_t) (total / rb), all, false);
+            (void) hipFree(all);
+        }
+        c->packed.insert(t->data);
+    }
+    const int64_t r0 = (int64_t) (off / rb), r1 = (int64_t) ((off + n + rb - 1) / rb);
+    const size_t span = (size_t) (r1 - r0) * rb, head = off - (size_t) r0 * rb;
+    void * st = nullptr;
+    if (hipMalloc(&st, span) != hipSuccess) GGML_ABORT("mi355: staging %zu bytes for weight tensor %s failed", span, t->name);
+    const bool whole = head == 0 && n == span;
+    if (!write || !whole) pack_rows(t, r0, r1, st, true);                    // the rows as the GGUF holds them
+    bool ok = true;
+    if (write) { ok = hipMemcpy((char *) st + head, host, n, hipMemcpyHostToDevice) == hipSuccess; if (ok) pack_rows(t, r0, r1, st, false); }
+    else       ok = hipMemcpy(host, (const char *) st + head, n, hipMemcpyDeviceToHost) == hipSuccess;
+    (void) hipFree(st);
+    if (!ok) GGML_ABORT("mi355: transfer of %zu bytes %s weight tensor %s failed", n, write ? "into" : "out of", t->name);
+}
+void buf_memset(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t v, size_t off, size_t n) {
     size_t toff = 0;
     if (kv_mirror * m = in_place_of(t, &toff)) {
-        std::vector<uint8_t> h(n, v);
         (void) hipDeviceSynchronize();
-        (void) in_place_rows(m, toff + off, n, h.data(), true);
+        if (toff + off == 0 && n == ggml_nbytes(t) && !t->view_src) {   // a uniform fill of the whole tensor does not depend on the layout
+            if (hipMemset(t->data, v, n) != hipSuccess) GGML_ABORT("mi355: memset of a paged cache tensor failed");
+            return;
+        }
+        std::vector<uint8_t> h(n, v);
+        in_place_rows(m, toff + off, n, h.data(), true);
+        return;
+    }
+    auto * c = (buffer_ctx *) b->context;
+    if (c->packed.count(t->data) && !(off == 0 && n == ggml_nbytes(t))) {   // a partial fill of packed rows: through the GGUF-order view (a whole-tensor fill is layout-free)
+        std::vector<uint8_t> h(n, v);
+        packed_io(c, t, off, n, h.data(), true);
         return;
     }
     (void) hipMemset((char *) t->data + off, v, n);
     note_write(t, off, n);
 }
-void buf_set(ggml_backend_buffer_t, ggml_tensor * t, const void * d, size_t off, size_t n) {
+void buf_set(ggml_backend_buffer_t b, ggml_tensor * t, const void * d, size_t off, size_t n) {
     size_t toff = 0;
     if (kv_mirror * m = in_place_of(t, &toff)) {
         (void) hipDeviceSynchronize();
-        (void) in_place_rows(m, toff + off, n, const_cast<void *>(d), true);
+        in_place_rows(m, toff + off, n, const_cast<void *>(d), true);
         return;
     }
-    (void) hipMemcpy((char *) t->data + off, d, n, hipMemcpyHostToDevice);
+    auto * c = (buffer_ctx *) b->context;
+    if (packable(t) || c->packed.count(t->data)) { packed_io(c, t, off, n, const_cast<void *>(d), true); return; }
+    if (const ggml_tensor * root = packed_root(t)) { (void) root; GGML_ABORT("mi355: set_tensor through a view of packed weight tensor %s is not supported", t->name); }
+    if (hipMemcpy((char *) t->data + off, d, n, hipMemcpyHostToDevice) != hipSuccess) GGML_ABORT("mi355: set_tensor of %zu bytes into %s failed", n, t->name);
     note_write(t, off, n);
 }
-void buf_get(ggml_backend_buffer_t, const ggml_tensor * t, void * d, size_t off, size_t n) {
+void buf_get(ggml_backend_buffer_t b, const ggml_tensor * t, void * d, size_t off, size_t n) {
     (void) hipDeviceSynchronize();
     size_t toff = 0;
-    if (kv_mirror * m = in_place_of(t, &toff)) { (void) in_place_rows(m, toff + off, n, d, false); return; }
-    (void) hipMemcpy(d, (const char *) t->data + off, n, hipMemcpyDeviceToHost);
+    if (kv_mirror * m = in_place_of(t, &toff)) { in_place_rows(m, toff + off, n, d, false); return; }
+    auto * c = (buffer_ctx *) b->context;
+    if (c->packed.count(t->data) && !t->view_src) { packed_io(c, const_cast<ggml_tensor *>(t), off, n, d, false); return; }
+    if (const ggml_tensor * root = packed_root(t)) {                          // a view of packed rows: read through the root at the view's byte offset
+        size_t voff = 0;
+        for (const ggml_tensor * x = t; x->view_src; x = x->view_src) voff += x->view_offs;
+        packed_io(c, const_cast<ggml_tensor *>(root), voff + off, n, d, false);
+        return;
+    }
+    if (hipMemcpy(d, (const char *) t->data + off, n, hipMemcpyDeviceToHost) != hipSuccess) GGML_ABORT("mi355: get_tensor of %zu bytes out of %s failed", n, t->name);
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
     auto * c = (buffer_ctx *) b->context;
-    (void) hipMemset(c->base, v, b->size);
+    (void) hipMemset(c->base, v, b->size);                                      // (uniform bytes: the same in either row layout, packed tensors stay packed)
     for (auto & kv : c->mirrors) { kv.second.dirty.clear(); kv.second.dirty.emplace_back(0, (size_t) -1); }
+}
+// a tensor (re)allocated at an address: whatever the previous tenant of that address left in the maps is void.  (ggml-alloc hands the same compute-buffer
+// address to different tensors graph after graph; cache and weight tensors are initialised once.)  Views are initialised too and share their root's address at
+// offset 0: they are not tenants.
+enum ggml_status buf_init_tensor(ggml_backend_buffer_t b, ggml_tensor * t) {
+    if (t->view_src) return GGML_STATUS_SUCCESS;
+    auto * c = (buffer_ctx *) b->context;
+    auto it = c->mirrors.find(t->data);
+    if (it != c->mirrors.end()) {
+        if (it->second.pool && !it->second.in_place) (void) hipFree(it->second.pool);
+        c->mirrors.erase(it);
+    }
+    c->packed.erase(t->data);
+    return GGML_STATUS_SUCCESS;
 }
 
 const ggml_backend_buffer_i BUFFER_IFACE = {
     /* free_buffer   */ buf_free,
     /* get_base      */ buf_base,
-    /* init_tensor   */ nullptr,
+    /* init_tensor   */ buf_init_tensor,
     /* memset_tensor */ buf_memset,
     /* set_tensor    */ buf_set,
     /* get_tensor    */ buf_get,
@@ -252,7 +347,9 @@ char * mirror_sync(backend_ctx * bc, const ggml_tensor * t, int is_v, int n_kv, 
         const int64_t nb = (n_cells + BLOCK - 1) / BLOCK;
         const size_t bytes = pkv_pool_bytes(t->type, (int) nb, n_head_kv, BLOCK, D);
         static const bool keep_mirror = getenv("GGML_MI355_KV_MIRROR") != nullptr;
-        if (!keep_mirror && n_cells % BLOCK == 0 && bytes == ggml_nbytes(root)) {
+        // ... never a tensor of a graph-allocated compute buffer: ggml-alloc gives that address to another tensor in the next graph, which would then be read as
+        // tiles; test-backend-ops' free-standing K / V in such buffers keep the mirror path with its dirty ranges
+        if (!keep_mirror && n_cells % BLOCK == 0 && bytes == ggml_nbytes(root) && ggml_backend_buffer_get_usage(root->buffer) != GGML_BACKEND_BUFFER_USAGE_COMPUTE) {
             // the tensor becomes its own pool: tiles built beside it once, copied over its flat rows, the transient freed
             void * tmp = nullptr;
             if (hipMalloc(&tmp, bytes) != hipSuccess) return nullptr;
@@ -415,6 +512,9 @@ bool supports_cpy(const ggml_tensor * op) {
     // (/ref/src/llama-graph.cpp:1375-1397): shapes differ, the element order does not; rows of 64/128 keep quant blocks whole
     if (s && d && s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) &&
         ggml_nelements(s) == ggml_nelements(d) && s->ne[0] % 64 == 0) return true;
+    // defrag moves of a quantized cache (build_kv_self_defrag, /ref/src/llama-context.cpp:668-711): same type, same shape, contiguous row ranges — cells of a
+    // tensor that is its own pool (run_cpy_cells) or flat bytes (a staged byte copy); f16 moves also pass the plain-type rule below
+    if (s && d && s->type == d->type && kv_type(s->type) && ggml_are_same_shape(s, d) && ggml_is_contiguous(s) && ggml_is_contiguous(d)) return true;
     return supports_cpy_strided(s, d);
 }
 bool supports_cont(const ggml_tensor * op) { return supports_cpy_strided(op->src[0], op) && op->src[0]->type == op->type; }
@@ -436,10 +536,60 @@ const kv_mirror * store_mirror(const ggml_tensor * cpy, int64_t * cell0, int64_t
     *n_cells = n_el / per_cell;
     return &m;
 }
+// whole cells [*c0, *c0 + *nc) of the in-place pool that `t` views as contiguous rows, or NULL
+kv_mirror * in_place_cells(const ggml_tensor * t, int64_t * c0, int64_t * nc) {
+    size_t off = 0;
+    kv_mirror * m = in_place_of(t, &off);
+    if (!m || (int) t->type != m->type || !ggml_is_contiguous(t)) return nullptr;
+    const size_t row_cell = ggml_row_size((ggml_type) m->type, m->D) * m->n_head_kv, nb = ggml_nbytes(t);
+    if (off % row_cell != 0 || nb % row_cell != 0 || (int64_t) ((off + nb) / row_cell) > m->n_cells) return nullptr;
+    *c0 = (int64_t) (off / row_cell); *nc = (int64_t) (nb / row_cell);
+    return m;
+}
+// ggml_cpy between cell ranges of ONE paged cache tensor: the moves of build_kv_self_defrag (/ref/src/llama-context.cpp:668-711: view_2d of nm cell rows at cell i ->
+// the same at cell id).  The tile layout is addressed by cells, so the copy is a gather of the source cells into flat staging rows and a scatter into the
+// destination cells; staging because the two ranges may overlap.  r02 returned FAILED here; kv_self_update ignores graph_compute's status (:773) after defrag_prepare
+// has already moved the cell metadata — the data stayed put under metadata that pointed elsewhere.
+ggml_status run_cpy_cells(backend_ctx * bc, kv_mirror * m, int64_t cs, int64_t cd, int64_t nc) {
+    if (nc == 0 || cs == cd) return GGML_STATUS_SUCCESS;
+    const size_t row_cell = ggml_row_size((ggml_type) m->type, m->D) * m->n_head_kv;
+    std::vector<int32_t> h(4 * (size_t) nc);
+    for (int64_t i = 0; i < nc; ++i) {
+        h[i] = (int32_t) ((cs + i) / BLOCK); h[nc + i] = (int32_t) ((cs + i) % BLOCK);
+        h[2 * nc + i] = (int32_t) ((cd + i) / BLOCK); h[3 * nc + i] = (int32_t) ((cd + i) % BLOCK);
+    }
+    auto up = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+    char * base = (char *) bc->arena(up((size_t) nc * row_cell) + up(h.size() * sizeof(int32_t)));
+    if (!base) return GGML_STATUS_ALLOC_FAILED;
+    int32_t * dt = (int32_t *) (base + up((size_t) nc * row_cell));
+    bool ok = hipMemcpyAsync(dt, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, bc->stream) == hipSuccess;
+    (void) hipStreamSynchronize(bc->stream);               // h is a local
+    ok = ok && pkv_pool_gather_rows(m->pool, m->type, m->is_v, base, dt, dt + nc, (int) nc, m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK &&
+               pkv_pool_scatter_rows(m->pool, m->type, m->is_v, base, dt + 2 * nc, dt + 3 * nc, (int) nc, m->n_head_kv, m->D, BLOCK, bc->stream) == PKV_OK;
+    // no error can reach the caller that matters (kv_self_update drops the status): a failed move of KV cells must not pass silently
+    if (!ok) GGML_ABORT("mi355: moving %lld cells of a paged cache tensor failed: %s", (long long) nc, pkv_last_error());
+    return GGML_STATUS_SUCCESS;
+}
 ggml_status run_cpy_strided(backend_ctx * bc, const ggml_tensor * s, ggml_tensor * d) {
     int64_t nbs[4], nbd[4];
     for (int i = 0; i < 4; ++i) { nbs[i] = (int64_t) s->nb[i]; nbd[i] = (int64_t) d->nb[i]; }
-    if (in_place_of(d) || in_place_of(s)) { MI355_LOG("a strided copy over a paged cache tensor is not supported (defrag / -fa 0 ops on a flash-attention cache)\n"); return GGML_STATUS_FAILED; }
+    if (in_place_of(d) || in_place_of(s)) {
+        int64_t cs, ns, cd, nd;
+        kv_mirror * ms = in_place_cells(s, &cs, &ns), * md = in_place_cells(d, &cd, &nd);
+        if (ms && ms == md && ns == nd) return run_cpy_cells(bc, ms, cs, cd, ns);
+        // anything else over a paged cache tensor (a -fa 0 op on a flash-attention cache, a copy between two tensors) has no meaning in the tile layout: stop,
+        // do not carry on with metadata and data out of step
+        GGML_ABORT("mi355: copy %s -> %s over a paged cache tensor that is not a move of whole cells inside one tensor", s->name, d->name);
+    }
+    if (s->type == d->type && !plain_type(s->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d)) {   // quantized rows of a flat tensor: bytes, staged (ranges may overlap)
+        const size_t nb = ggml_nbytes(s);
+        void * st = bc->arena(nb);
+        if (!st) return GGML_STATUS_ALLOC_FAILED;
+        if (hipMemcpyAsync(st, bc->src_data(s), nb, hipMemcpyDeviceToDevice, bc->stream) != hipSuccess || hipMemcpyAsync(d->data, st, nb, hipMemcpyDeviceToDevice, bc->stream) != hipSuccess)
+            GGML_ABORT("mi355: byte copy %s -> %s failed", s->name, d->name);
+        note_write_all(d);
+        return GGML_STATUS_SUCCESS;
+    }
     const int rc = pkv_cpy_strided(bc->src_data(s), s->type, s->ne, nbs, d->data, d->type, d->ne, nbd, bc->stream);
     if (rc) { MI355_LOG("strided cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
     note_write_all(d);
@@ -524,7 +674,7 @@ ggml_status run_layer_op(backend_ctx * bc, ggml_tensor * op) {
         } break;
         case GGML_OP_UNARY: rc = pkv_silu_f32((const float *) a->data, (float *) op->data, ggml_nelements(a), bc->stream); break;
         case GGML_OP_MUL_MAT:
-            if (mul_mat_2d(op)) rc = pkv_mul_mat(a->data, a->type, (const float *) b->data, (float *) op->data, a->ne[1], a->ne[0], b->ne[1], bc->stream);
+            if (mul_mat_2d(op)) rc = pkv_mul_mat(a->data, wtype(a), (const float *) b->data, (float *) op->data, a->ne[1], a->ne[0], b->ne[1], bc->stream);
             else {
                 int64_t nba[4], nbb[4];
                 for (int i = 0; i < 4; ++i) { nba[i] = (int64_t) a->nb[i]; nbb[i] = (int64_t) b->nb[i]; }
@@ -675,7 +825,23 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 for (int k = i; k < n_nodes && k <= i + 16 && np < 3; ++k) if (!done[k] && kq_col(ggml_graph_node(g, k), col)) prod[np++] = k;
                 ok = np > 0 && prod[0] == i;
             }
-            // epilogue of the chain
+            // epilogue of the chain.  Its output is written EARLY — in the products' launch — so it must not alias anything that launch still reads or also writes
+            // (the column source, the norm weights, and norm_out / col_out, which workgroup 0 writes in the same launch), nor anything a node between the products
+            // and the epilogue node reads or writes (those nodes run AFTER the fused launch): ggml-alloc's in-place placement of today's llama graphs is safe, a
+            // graph cut by cb_eval / OUTPUT flags / adapters need not be
+            bool wtype_uniform = true;                       // one launch = one row layout (plane-layout weights of a WEIGHTS buffer and GGUF-order ones do not mix)
+            for (int q = 1; q < np; ++q) wtype_uniform = wtype_uniform && (wtype(ggml_graph_node(g, prod[q])->src[0]) & PKV_TYPE_PACKED) == (wtype(ggml_graph_node(g, prod[0])->src[0]) & PKV_TYPE_PACKED);
+            if (!wtype_uniform) ok = false;
+            auto early_ok = [&](const ggml_tensor * out, int last_idx, std::initializer_list<int> chain) {
+                if (overlaps(out, xsrc) || (nw && (overlaps(out, nw) || overlaps(out, n) || overlaps(out, col)))) return false;
+                for (int k = i; k <= last_idx && k < n_nodes; ++k) {
+                    if (done[k] || std::find(chain.begin(), chain.end(), k) != chain.end() || std::find(prod, prod + np, k) != prod + np) continue;
+                    const ggml_tensor * nk = ggml_graph_node(g, k);
+                    if (overlaps(out, nk)) return false;
+                    for (int s_ = 0; s_ < GGML_MAX_SRC; ++s_) if (nk->src[s_] && overlaps(out, nk->src[s_])) return false;
+                }
+                return true;
+            };
             int i_silu = -1, i_mulgu = -1, i_add = -1;
             const ggml_tensor * resid = nullptr;
             float * yv[3] = {nullptr, nullptr, nullptr};
@@ -687,7 +853,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 ggml_tensor * mn = um >= 0 ? ggml_graph_node(g, um) : nullptr;
                 if (sn && mn && sn->op == GGML_OP_UNARY && supports_silu(sn) && sn->src[0] == p0 && mn->op == GGML_OP_MUL && us1 == um && !done[us0] && !done[um] &&
                     ((mn->src[0] == sn && mn->src[1] == p1) || (mn->src[1] == sn && mn->src[0] == p1)) && f32c(mn) && ggml_nelements(mn) == p0->ne[0] && p0->ne[0] == p1->ne[0] &&
-                    !overlaps(mn, xsrc) && !(nw && overlaps(mn, nw))) { i_silu = us0; i_mulgu = um; yv[0] = (float *) mn->data; }
+                    early_ok(mn, um, {i_mul, us0, um})) { i_silu = us0; i_mulgu = um; yv[0] = (float *) mn->data; }
             }
             if (ok && np == 1 && (chain_mask & 2)) {   // attn_out / ffn_down + the residual stream
                 ggml_tensor * p0 = ggml_graph_node(g, prod[0]);
@@ -697,7 +863,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                     const ggml_tensor * r = an->src[0] == p0 ? an->src[1] : an->src[0];
                     bool r_ready = true;                     // the other operand exists already: a leaf, or a node that has run
                     for (int q = i; q < n_nodes && r_ready; ++q) if (ggml_graph_node(g, q) == r || (r->view_src && ggml_graph_node(g, q) == r->view_src)) r_ready = done[q] != 0;
-                    if (r_ready && !overlaps(an, xsrc) && alias_ok(an, r)) { i_add = ua; resid = r; yv[0] = (float *) an->data; }
+                    if (r_ready && early_ok(an, ua, {i_mul, ua}) && alias_ok(an, r)) { i_add = ua; resid = r; yv[0] = (float *) an->data; }
                 }
             }
             size_t side_bytes = 0;
@@ -730,7 +896,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                 char * side = side_base + side_used;
                 for (int q = 0; q < np; ++q) {
                     ggml_tensor * pq = ggml_graph_node(g, prod[q]);
-                    gv.type_w[q] = (int32_t) pq->src[0]->type; gv.w[q] = pq->src[0]->data; gv.M[q] = pq->src[0]->ne[1];
+                    gv.type_w[q] = (int32_t) wtype(pq->src[0]); gv.w[q] = pq->src[0]->data; gv.M[q] = pq->src[0]->ne[1];
                     gv.y[q] = yv[q] ? yv[q] : yv[0];
                     if (redirect[q]) { gv.y[q] = (float *) side; bc->moved[pq] = side; side += (ggml_nbytes(pq) + 255) / 256 * 256; }
                 }
@@ -756,7 +922,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             grp[0] = i;
             for (int k = i + 1; k < n_nodes && k <= i + 16 && ngp < PKV_MUL_MAT_MAX; ++k) {
                 ggml_tensor * nk = ggml_graph_node(g, k);
-                if (nk->op != GGML_OP_MUL_MAT || nk->src[1] != n->src[1] || !nk->src[0] || nk->src[0]->type != n->src[0]->type || !supports_mul_mat(nk) || done[k]) continue;
+                if (nk->op != GGML_OP_MUL_MAT || nk->src[1] != n->src[1] || !nk->src[0] || nk->src[0]->type != n->src[0]->type || wtype(nk->src[0]) != wtype(n->src[0]) || !supports_mul_mat(nk) || done[k]) continue;
                 bool safe = true;
                 for (int q = i; q < k && safe; ++q) {
                     const ggml_tensor * nq = ggml_graph_node(g, q);
@@ -784,7 +950,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
                     if (redirect[q]) { yv[q] = (float *) side; bc->moved[nq] = side; side += (ggml_nbytes(nq) + 255) / 256 * 256; }
                     done[grp[q]] = 1;
                 }
-                if (pkv_mul_mat_multi(ngp, wv, (int) n->src[0]->type, (const float *) n->src[1]->data, yv, mv, n->src[0]->ne[0], n->src[1]->ne[1], bc->stream) != PKV_OK) {
+                if (pkv_mul_mat_multi(ngp, wv, wtype(n->src[0]), (const float *) n->src[1]->data, yv, mv, n->src[0]->ne[0], n->src[1]->ne[1], bc->stream) != PKV_OK) {
                     MI355_LOG("mul_mat_multi failed: %s\n", pkv_last_error());
                     return GGML_STATUS_FAILED;
                 }

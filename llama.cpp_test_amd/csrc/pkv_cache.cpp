@@ -131,6 +131,7 @@ int32_t KvCachePaged::alloc_block(bool allow_evict) {
         // Its cells become holes in every owner and trim() drops it from their tables.
         for (size_t i = 0; i < ref_.size(); ++i) {
             if (ref_[i] == 0) continue;
+            if (i < pinned_.size() && pinned_[i]) continue;   // holds tokens of the ubatch being placed (find_slot): never a victim of that same call
             const int32_t b = (int32_t) i;
             for (auto & s : seqs_) {
                 bool hit = false;
@@ -355,23 +356,30 @@ int KvCachePaged::find_slot(int n_tok, const int32_t * seq_id, const int32_t * p
         if (!q.pos.empty() && q.pos.size() % BS != 0 && ref_[q.blocks.back()] > 1) ++need;  // copy-on-write of the tail block
     }
     if (need > n_free_ && !p_.evict_when_full) return PKV_ERR_NO_SPACE;
+    // evict_when_full: a block that has taken a token of THIS ubatch is pinned until the call returns — the lowest-allocated-first policy would
+    // otherwise hand block 0 out again right after filling it: two tokens of one ubatch in the same cell (the store launch races on it) and the
+    // earlier tokens' (block, offset) stale.  No victim left -> PKV_ERR_NO_SPACE with the cache as it was before the call.
+    struct Unpin { std::vector<char> & p; ~Unpin() { p.clear(); } } unpin{pinned_};
+    std::vector<Seq> seqs0; std::vector<int32_t> ref0; int32_t free0 = n_free_; const size_t pend0 = pending.size();
+    if (p_.evict_when_full) { pinned_.assign(ref_.size(), 0); seqs0 = seqs_; ref0 = ref_; }
+    auto fail = [&]() { if (p_.evict_when_full) { seqs_ = seqs0; ref_ = ref0; n_free_ = free0; pending.resize(pend0); } return PKV_ERR_NO_SPACE; };
     // pass 2: place the tokens in batch order
     for (int t = 0; t < n_tok; ++t) {
         Seq & q = seqs_[seq_id[t]];
         // With evict_when_full an allocation can take a block away from q itself (trim() then shortens q.pos / q.blocks),
         // so the slot is (re)computed from the sequence's CURRENT length after every allocation.
         for (int guard = 0;; ++guard) {
-            if (guard > 4) return PKV_ERR_NO_SPACE;
+            if (guard > 4) return fail();
             const size_t lb0 = q.pos.size() / BS;
             if (lb0 == q.blocks.size()) {
                 const int32_t nb = alloc_block();
-                if (nb < 0) return PKV_ERR_NO_SPACE;
+                if (nb < 0) return fail();
                 if (q.pos.size() / BS == q.blocks.size()) { q.blocks.push_back(nb); break; }
                 unref_block(nb);            // q shrank into a partly filled block: that one takes the token
                 continue;
             }
             if (ref_[q.blocks[lb0]] > 1) {
-                if (!cow_block(q, lb0)) return PKV_ERR_NO_SPACE;
+                if (!cow_block(q, lb0)) return fail();
                 continue;                   // re-check: the copy may have evicted from q
             }
             break;
@@ -381,6 +389,7 @@ int KvCachePaged::find_slot(int n_tok, const int32_t * seq_id, const int32_t * p
         q.delta.push_back(0);
         out_block[t] = q.blocks[lb];
         out_off[t]   = (int32_t) (i % BS);
+        if (!pinned_.empty()) pinned_[q.blocks[lb]] = 1;
     }
     return PKV_OK;
 }

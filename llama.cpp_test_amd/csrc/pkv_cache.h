@@ -126,6 +126,7 @@ class KvCachePaged {
         std::vector<int32_t> pos;     // per logical cell; -1 = empty (hole)
         std::vector<int32_t> delta;   // accumulated, not yet applied position shift (llama_kv_cell::delta)
     };
+    std::vector<char> pinned_;                       // find_slot with evict_when_full: blocks that hold tokens of the ubatch being placed
     int32_t alloc_block(bool allow_evict = true);   // fork BlockManager policy: lowest free index first, then (evict_when_full) the lowest allocated
     void    unref_block(int32_t b);
     void    trim(Seq & s);            // drop trailing holes, wholly-empty blocks, release their blocks

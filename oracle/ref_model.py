@@ -46,6 +46,11 @@ def load_backend(so_path: str) -> None:
         raise RuntimeError(f"ggml_backend_load({so_path}) failed")
 
 
+def set_defrag_thold(t: float) -> None:
+    """llama_context_params.defrag_thold of the contexts created from here on (-1 = never, the library default; 0.1 = what llama-cli / llama-server run with)"""
+    _lib().refmodel_set_defrag_thold(C.c_float(t))
+
+
 def set_gpu_layers(n: int) -> None:
     """llama_model_params.n_gpu_layers of the models loaded next (0 = everything on the reference's CPU backend)"""
     _lib().refmodel_set_gpu_layers(n)
@@ -84,6 +89,24 @@ class RefModel:
         L = _lib()
         L.refmodel_state_seq_set.restype = C.c_size_t
         return int(L.refmodel_state_seq_set(self.h, blob, C.c_size_t(len(blob)), seq_id))
+
+    def weight_get(self, name: str, offset: int = 0, size: int = -1):
+        """(bytes of model tensor `name` through ggml_backend_tensor_get, whether its buffer is a device buffer)"""
+        L = _lib()
+        L.refmodel_weight_get.restype = C.c_size_t
+        dev = C.c_int(0)
+        n = L.refmodel_weight_get(self.h, name.encode(), None, C.c_size_t(0), C.c_size_t(0), C.byref(dev))
+        if n == 0:
+            raise KeyError(name)
+        size = n - offset if size < 0 else size
+        buf = (C.c_uint8 * size)()
+        got = L.refmodel_weight_get(self.h, name.encode(), buf, C.c_size_t(size), C.c_size_t(offset), C.byref(dev))
+        return bytes(buf[:got]), bool(dev.value)
+
+    def weight_set(self, name: str, data: bytes, offset: int = 0) -> int:
+        L = _lib()
+        L.refmodel_weight_set.restype = C.c_size_t
+        return int(L.refmodel_weight_set(self.h, name.encode(), data, C.c_size_t(len(data)), C.c_size_t(offset)))
 
     def seq_rm(self, s, p0, p1): _lib().refmodel_seq_rm(self.h, s, p0, p1)
     def seq_cp(self, a, b, p0, p1): _lib().refmodel_seq_cp(self.h, a, b, p0, p1)

@@ -13,6 +13,7 @@
 #include "ggml.h"
 #include "ggml-backend.h"
 #include "gguf.h"
+#include "llama-model.h"   // llama_model::get_tensor (the driver is compiled with -I<reference>/src)
 
 #include <cinttypes>
 #include <cstdio>
@@ -157,6 +158,10 @@ int refmodel_load_backend(const char * so_path) { return ggml_backend_load(so_pa
 
 static int g_n_gpu_layers = 0;
 void refmodel_set_gpu_layers(int n) { g_n_gpu_layers = n; }
+// llama_context_params.defrag_thold for the contexts created from here on (llama_context_default_params: -1 = never; common.h's default for llama-cli /
+// llama-server: 0.1 — the KV cache is defragmented after a decode once kv_self->n >= 2048 and the share of holes exceeds it, /root/reference/src/llama-context.cpp:1465-1478)
+static float g_defrag_thold = -1.0f;
+void refmodel_set_defrag_thold(float t) { g_defrag_thold = t; }
 
 void * refmodel_load(const char * path, int n_ctx, int n_batch, int n_seq_max, int flash_attn, int type_k, int type_v, int n_threads) {
     static bool init = false;
@@ -172,6 +177,7 @@ void * refmodel_load(const char * path, int n_ctx, int n_batch, int n_seq_max, i
     cp.flash_attn = flash_attn != 0; cp.type_k = (ggml_type) type_k; cp.type_v = (ggml_type) type_v;
     cp.cb_eval = cb_eval; cp.cb_eval_user_data = rm;
     cp.no_perf = true;
+    cp.defrag_thold = g_defrag_thold;
     rm->ctx = llama_init_from_model(rm->model, cp);
     if (!rm->ctx) { llama_model_free(rm->model); delete rm; return nullptr; }
     return rm;
@@ -193,6 +199,24 @@ int refmodel_decode(void * h, const int32_t * tokens, const int32_t * pos, const
     const int rc = llama_decode(rm->ctx, b);
     llama_batch_free(b);
     return rc;
+}
+// ggml_backend_tensor_get / _set on a model weight by name: what the plugin's buffer hands out for a tensor it holds in another row layout must be the GGUF's bytes.
+// dst NULL = size only; returns the byte count, 0 when the tensor does not exist; *on_device = 1 when its buffer is not a host buffer
+size_t refmodel_weight_get(void * h, const char * name, void * dst, size_t cap, size_t offset, int * on_device) {
+    const ggml_tensor * t = ((RefModel *) h)->model->get_tensor(name);
+    if (!t) return 0;
+    if (on_device) *on_device = t->buffer && !ggml_backend_buffer_is_host(t->buffer);
+    const size_t n = ggml_nbytes(t);
+    if (!dst) return n;
+    const size_t m = offset >= n ? 0 : (cap < n - offset ? cap : n - offset);
+    ggml_backend_tensor_get(t, dst, offset, m);
+    return m;
+}
+size_t refmodel_weight_set(void * h, const char * name, const void * src, size_t size, size_t offset) {
+    ggml_tensor * t = const_cast<ggml_tensor *>(((RefModel *) h)->model->get_tensor(name));
+    if (!t || offset + size > ggml_nbytes(t)) return 0;
+    ggml_backend_tensor_set(t, src, offset, size);
+    return size;
 }
 // timing runs: the eval callback makes the scheduler compute node by node; a context without it decodes at full speed
 void refmodel_detach_capture(void * h) {

@@ -239,6 +239,31 @@ def test_evict_when_full_own_block(pkv):
     assert all(0 <= b < 64 for b in blk.tolist()) and all(0 <= o < 2 for o in off.tolist())
 
 
+def test_evict_when_full_never_evicts_the_ubatch_being_placed(pkv):
+    """with evict_when_full the lowest-allocated-first policy took block 0 again right after filling it — n_blocks 2, bs 2,
+    find_slot of 6 tokens returned slots (0,0) (0,1) (1,0) (1,1) (0,0) (0,1) with PKV_OK: duplicate cells in ONE ubatch (a race in the store launch) and
+    stale slots for the first two tokens.  Blocks that hold tokens of the call are pinned now: the slots of a ubatch are unique, and a ubatch that cannot fit
+    fails with PKV_ERR_NO_SPACE leaving the cache exactly as it was."""
+    c = mk(pkv, n_blocks=2, bs=2, n_seq=1, evict_when_full=True)
+    with pytest.raises(pkv.PkvError) as e:
+        c.find_slot([0] * 6, list(range(6)))
+    assert e.value.status == pkv.ERR_NO_SPACE
+    assert c.seq_len(0) == 0 and c.n_free_blocks() == 2 and c.get_n_tokens() == 0      # nothing changed
+    blk, off = c.find_slot([0] * 4, list(range(4)))                                     # what fits, fits — each cell once
+    assert sorted(zip(blk.tolist(), off.tolist())) == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    # a full pool of OLD tokens may still be evicted for a new ubatch, block by block, never the ubatch's own blocks
+    c2 = mk(pkv, n_blocks=4, bs=2, n_seq=2, evict_when_full=True)
+    c2.find_slot([0] * 8, list(range(8)))
+    blk, off = c2.find_slot([1] * 5, list(range(5)))
+    slots = list(zip(blk.tolist(), off.tolist()))
+    assert len(set(slots)) == 5 and c2.seq_len(1) == 5
+    assert c2.seq_len(0) == 2 and len(set(c2.seq_blocks(0).tolist()) & set(c2.seq_blocks(1).tolist())) == 0   # seq 0 lost three blocks to it
+    before = (c2.seq_blocks(0).tolist(), c2.seq_blocks(1).tolist(), c2.seq_len(0), c2.seq_len(1), c2.n_free_blocks())
+    with pytest.raises(pkv.PkvError):
+        c2.find_slot([1] * 9, list(range(5, 14)))                                       # 14 tokens of one sequence never fit 4 blocks of 2
+    assert before == (c2.seq_blocks(0).tolist(), c2.seq_blocks(1).tolist(), c2.seq_len(0), c2.seq_len(1), c2.n_free_blocks())
+
+
 def test_evict_when_full_shared_tail_and_shift(pkv):
     """copy-on-write of a shared tail block on a full pool, where the victim of the eviction is a block of the writer
     itself; and seq_add on a full pool (a shift never evicts: shared cells are then shifted in place)"""

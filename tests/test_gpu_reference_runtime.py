@@ -216,3 +216,90 @@ def test_q4_k_m_mix_through_the_plugin_against_exact_arithmetic(pkv, O, tmp_path
         top = np.sort(b)[-2:]
         if top[1] - top[0] > 6.0 * float(np.sqrt(np.mean((a - b) ** 2))):
             assert int(np.argmax(a)) == int(np.argmax(b))
+
+
+@pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
+@pytest.mark.parametrize("tk", [1, 8])
+def test_defrag_moves_cells_of_a_paged_cache_tensor(pkv, tmp_path, tk):
+    """llama-cli / llama-server run with defrag_thold 0.1 (/root/reference/common/common.h); once kv_self->n >= 2048 and the share of holes exceeds
+    it, llama_decode queues a defrag and the NEXT kv_self_update builds ggml_cpy nodes between cell ranges of k_l / v_l (/root/reference/src/llama-context.cpp:668-711)
+    — after defrag_prepare has already moved the cell metadata, and with graph_compute's status ignored (:773).  With the cache tensor being its own paged pool those
+    copies are gather -> staging -> scatter of whole cells (run_cpy_cells).  2300 prompt tokens, 1500 of them removed from the middle (f16 K: plus the context shift
+    that slides the tail down — the in-place K-shift on tiles), then decode steps across the defrag: per-layer kqv_out and logits against the CPU-only run of the same
+    library with the same defrag_thold."""
+    from llama_cpp_test_amd import gguf_synth as G
+    MODEL = MODELS["tiny"]
+    path = str(tmp_path / "m.gguf")
+    G.synth_llama(path, **MODEL)
+    rng = np.random.default_rng(9)
+    n_prompt, lo, hi = 2300, 300, 1800
+    calls = [([0] * min(128, n_prompt - p), list(range(p, min(p + 128, n_prompt)))) for p in range(0, n_prompt, 128)]
+    calls.append("holes")
+    p0 = n_prompt - (hi - lo) if tk == 1 else n_prompt           # f16: the tail was slid down by the removed count
+    calls += [([0], [p0 + i]) for i in range(6)]                 # the first of these requests the defrag, the second runs it
+    toks = [None if c == "holes" else rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
+
+    def run(gpu_layers):
+        R.set_gpu_layers(gpu_layers)
+        R.set_defrag_thold(0.1)
+        try:
+            m = R.RefModel(path, n_ctx=2560, n_batch=128, n_seq_max=1, flash_attn=True, type_k=tk, type_v=tk, n_threads=8)
+        finally:
+            R.set_defrag_thold(-1.0)
+        outs = []
+        for c, t in zip(calls, toks):
+            if c == "holes":
+                m.seq_rm(0, lo, hi)
+                if tk == 1:
+                    m.seq_add(0, hi, -1, -(hi - lo))
+                continue
+            sid, pos = c
+            layers = m.decode(t, pos, sid)
+            if len(sid) == 1:
+                outs.append(([layers[il]["out"].copy() for il in sorted(layers)], m.logits(MODEL["n_vocab"]).copy()))
+        return outs
+    cpu = run(0)
+    R.load_backend(PLUGIN)
+    gpu = run(99)
+    R.set_gpu_layers(0)
+    assert len(cpu) == len(gpu) == 6
+    for ci, ((lc, logit_c), (lg, logit_g)) in enumerate(zip(cpu, gpu)):
+        for il, (a, b) in enumerate(zip(lc, lg)):
+            assert np.isfinite(b).all() and nmse(b, a) <= 5e-4, (ci, il, nmse(b, a))
+        assert nmse(logit_g, logit_c) <= (1e-4 if tk == 1 else 5e-4), (ci, nmse(logit_g, logit_c))
+
+
+@pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
+def test_packed_weights_round_trip_through_tensor_get_and_set(pkv, tmp_path):
+    """K-quant tensors of a WEIGHTS buffer are re-laid inside their own bytes by the plugin's set_tensor (plane layout, csrc/pkv_wlayout.h); ggml_backend_tensor_get must
+    hand the GGUF's bytes back — whole tensors, row-aligned ranges and ranges that start and end inside a row — and a partial ggml_backend_tensor_set must land where the
+    GGUF order says.  (That the products on such tensors equal the CPU run is the llama3_q4k case of test_llama_decode_with_attention_on_the_plugin.)"""
+    from llama_cpp_test_amd import gguf_synth as G
+    MODEL = dict(MODELS["llama3_q4k"], k_mix=True)                 # q4_K + the q6_K tensors of a Q4_K_M file
+    path = str(tmp_path / "m.gguf")
+    G.synth_llama(path, **MODEL)
+    _, tensors, _ = G.read_gguf(path)
+    R.load_backend(PLUGIN)
+    R.set_gpu_layers(99)
+    try:
+        m = R.RefModel(path, n_ctx=256, n_batch=64, n_seq_max=1, flash_attn=True, type_k=1, type_v=1, n_threads=4)
+        seen = set()
+        for name in ("blk.0.attn_q.weight", "blk.0.attn_v.weight", "blk.1.ffn_down.weight", "blk.0.ffn_gate.weight", "blk.1.attn_output.weight"):
+            ne, t, _, data = tensors[name]
+            want = bytes(np.array(data).tobytes())
+            got, on_dev = m.weight_get(name)
+            assert on_dev, name                                  # the layer lives in the plugin's buffer
+            assert got == want, name
+            seen.add(int(t))
+            rb = len(want) // int(ne[1])
+            for off, n in ((rb * 3, rb * 2), (rb * 5 + 7, rb + 11), (1, 5), (len(want) - 9, 9)):
+                assert m.weight_get(name, off, n)[0] == want[off:off + n], (name, off, n)
+            patch = bytes(np.random.default_rng(len(name)).integers(0, 256, rb + 13, dtype=np.uint8))
+            off = rb * 2 + 5
+            assert m.weight_set(name, patch, off) == len(patch)
+            assert m.weight_get(name)[0] == want[:off] + patch + want[off + len(patch):], name
+            assert m.weight_set(name, want[off:off + len(patch)], off) == len(patch)      # restore
+            assert m.weight_get(name)[0] == want
+        assert seen == {12, 14}
+    finally:
+        R.set_gpu_layers(0)
