@@ -239,9 +239,9 @@ def test_defrag_moves_cells_of_a_paged_cache_tensor(pkv, tmp_path, tk):
     calls += [([0], [p0 + i]) for i in range(6)]                 # the first of these requests the defrag, the second runs it
     toks = [None if c == "holes" else rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
 
-    def run(gpu_layers):
+    def run(gpu_layers, thold=0.1):
         R.set_gpu_layers(gpu_layers)
-        R.set_defrag_thold(0.1)
+        R.set_defrag_thold(thold)
         try:
             m = R.RefModel(path, n_ctx=2560, n_batch=128, n_seq_max=1, flash_attn=True, type_k=tk, type_v=tk, n_threads=8)
         finally:
@@ -258,15 +258,24 @@ def test_defrag_moves_cells_of_a_paged_cache_tensor(pkv, tmp_path, tk):
             if len(sid) == 1:
                 outs.append(([layers[il]["out"].copy() for il in sorted(layers)], m.logits(MODEL["n_vocab"]).copy()))
         return outs
-    cpu = run(0)
-    R.load_backend(PLUGIN)
+    # The expected values.  f16 KV: the CPU-only run of the same library with the same defrag_thold.  q8_0 KV: the reference's CPU backend cannot run this graph —
+    # its same-type contiguous copy multiplies the ELEMENT count by the BLOCK size (ggml_compute_forward_dup_same_cont, /root/reference/ggml/src/ggml-cpu/ggml-cpu.c:
+    # 3111-3124: ne = ggml_nelements, nb0 = ggml_type_size = 34 for q8_0), a 32-fold overrun of both views that corrupts the heap (SIGSEGV in the next threadpool
+    # teardown, reproduced in the dev container without the plugin) — so the expected values are the plugin's own run WITHOUT defragmentation: the same cells in
+    # another order, the same attention up to summation order.
+    if tk == 1:
+        want = run(0)
+        R.load_backend(PLUGIN)
+    else:
+        R.load_backend(PLUGIN)
+        want = run(99, thold=-1.0)
     gpu = run(99)
     R.set_gpu_layers(0)
-    assert len(cpu) == len(gpu) == 6
-    for ci, ((lc, logit_c), (lg, logit_g)) in enumerate(zip(cpu, gpu)):
+    assert len(want) == len(gpu) == 6
+    for ci, ((lc, logit_c), (lg, logit_g)) in enumerate(zip(want, gpu)):
         for il, (a, b) in enumerate(zip(lc, lg)):
             assert np.isfinite(b).all() and nmse(b, a) <= 5e-4, (ci, il, nmse(b, a))
-        assert nmse(logit_g, logit_c) <= (1e-4 if tk == 1 else 5e-4), (ci, nmse(logit_g, logit_c))
+        assert nmse(logit_g, logit_c) <= 1e-4, (ci, nmse(logit_g, logit_c))
 
 
 @pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
