@@ -21,6 +21,7 @@
 #include "pkv_rowcodec.h"
 
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 namespace pkv {
 namespace {
@@ -76,10 +77,13 @@ struct DecodeArgs {
     int64_t         mask_stride;   // -inf hides the cell; rides on the SLOTPOS variant of the kernel
     float *         part_o;   // [n_seq][n_head][n_splits][D]
     float *         part_ml;  // [n_seq][n_head][n_splits][2]
-    float *         out;      // [n_seq][n_head][D]
+    float *         out;      // [n_seq][n_head][D]; NULL: leave the partials (PKV_ATTN_NO_COMBINE)
+    float *         out_direct; // the caller's out whatever the flags (the one-workgroup-per-stream form writes it itself)
     unsigned *      counters; // [n_seq][n_head_kv] arrival tickets (fused merge), zero between launches
     int             part_o_bytes, part_ml_bytes;   // extents of the partial slabs (buffer descriptors of the fused merge)
     int   n_head, n_head_kv, block_size, max_blocks, n_splits, bs_shift;  // block_size = WG_TOK << bs_shift
+    int   n_tile;             // MULTI: consecutive 128-token tiles one workgroup walks (n_splits = partials per (sequence, head) = ceil(tiles / n_tile))
+    int   final_out;          // MULTI with n_splits == 1: the workgroup's result IS the head's output -> normalised straight into `out`, no partials, no merge launch
     float scale, softcap;
     // fused decode step (PREP): this step's un-rotated K / V rows, the new token's position, RoPE
     const float *   k_cur;    // [n_seq][n_head_kv][D]
@@ -377,7 +381,7 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int off) 
 #ifndef PKV_OCC
 #define PKV_OCC 1
 #endif
-template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0, int TPWQ = 16>
+template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0, int TPWQ = 16, bool MULTI = false>
 __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn_decode_kernel(const int32_t * p_table, const int32_t * p_lens, int p_max_blocks, int p_bs_shift,
                                                                                                    const DecodeArgs a) {
     // the four leading arguments (= a.block_table, a.seq_lens, a.max_blocks, a.bs_shift) are what the FIRST dependent loads need: as explicit kernel
@@ -413,15 +417,27 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
     __shared__ KCur<KT, D> sKc;                                                     // the new token's rows (fused step)
     __shared__ VCur<D>     sVc;
 
+    static_assert(!MULTI || (!SOFTCAP && !SLOTPOS && !FUSED && STAMP == 0), "the multi-tile form exists for the plain variants only");
+    // MULTI (r03): one workgroup walks a.n_tile CONSECUTIVE 128-token tiles of its (sequence, kv head).  The Q operand is prepared once, every wave keeps an online
+    // softmax state (running max / sum per head, rescaled accumulators) over its 16 tokens of each tile, the K rows of tile i+1 are requested as soon as QK^T has
+    // consumed tile i's (behind tile i's V rows: the memory queue never runs dry), and there is ONE cross-wave merge and ONE partial per workgroup — or, when the
+    // workgroup covers the whole sequence (final_out), the head's normalised output itself: no partials and no merge launch.  No barrier inside the loop.
+    __shared__ __attribute__((aligned(16))) float sAl[MULTI ? NW : 1][G];          // per-wave rescale factors exp(m_old - m_new) of the running accumulators
+
     const int split = blockIdx.x, hk = blockIdx.y, s = blockIdx.z;
-    const int base  = split * WG_TOK;
+    const int tile0 = MULTI ? split * a.n_tile : split;         // first 128-token tile of this workgroup
+    const int base0 = tile0 * WG_TOK;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     // the two scalar loads every KV address depends on are independent of each other: issue both, then branch
     // (the table entry of a split past the end of the sequence is in bounds — grid.x <= max_blocks — and unused)
-    const int lb = split >> p_bs_shift, boff = (split & ((1 << p_bs_shift) - 1)) * WG_TOK;
-    const int phys    = p_table[(size_t) s * p_max_blocks + lb];
+    const int bs_mask = (1 << p_bs_shift) - 1;
+    const int32_t * trow = p_table + (size_t) s * p_max_blocks;
+    const int tile_cap = (p_max_blocks << p_bs_shift) - 1;      // last tile index the table row can address
+    const int phys0   = trow[tile0 >> p_bs_shift];
     const int seq_len = p_lens[s];
+    [[maybe_unused]] int phys_n = 0;                            // MULTI: table entry of the NEXT tile, looked up one tile ahead
+    if constexpr (MULTI) phys_n = trow[min(tile0 + 1, tile_cap) >> p_bs_shift];
 
     // ---- row jobs, loads: they need kernel arguments only, so they go out while the table entry is still on its way, and —
     //      barrier 0 below — before ANY wave of the workgroup has put a K load into the CU's memory queue: a 512-byte row that
@@ -446,29 +462,35 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
     __builtin_amdgcn_sched_barrier(0);  // program order = issue order: the rows are OLDER than the K stream (their wait must not drain it)
     // everything the KV addresses need is requested before the branch (hipcc otherwise sinks the table load and the
     // remaining kernel-argument loads below it, one scalar round trip each)
-    asm volatile("" ::"s"(phys), "s"(seq_len), "s"(a.k_pool), "s"(a.v_pool), "s"(a.q));
+    asm volatile("" ::"s"(phys0), "s"(seq_len), "s"(a.k_pool), "s"(a.v_pool), "s"(a.q));
     ts.at(2);                     // kernel arguments, table entry and sequence length are in SGPRs; row loads issued
-    if (base >= seq_len) return;  // workgroup-uniform
+    if (base0 >= seq_len) {       // workgroup-uniform
+        if constexpr (MULTI) {    // an empty sequence whose only workgroup owns the output: zeros, as the merge launch writes them
+            if (a.final_out && tid < G * D / 4)
+                *reinterpret_cast<float4 *>(&a.out[((size_t) s * a.n_head + hk * G) * D + tid * 4]) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        return;
+    }
     __builtin_amdgcn_s_barrier(); // barrier 0 (no memory to order: a bare s_barrier): every wave's row loads are in the queue
     __builtin_amdgcn_sched_barrier(0);
 
-    const char * ktile = a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(KT, a.block_size, D);
-    const char * vtile = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tile_bytes(VT, a.block_size, D);
-    const int  n_valid = min(WG_TOK, seq_len - base);           // >= 1
-    const bool active  = wv * TPW < n_valid;                    // wave-uniform: a wave past the end only runs its row job
-    const bool is_last = PREP && base + n_valid == seq_len;     // this workgroup's last valid row is the new token
-    const bool owner   = is_last && wv == (n_valid - 1) / TPW;  // ... and this wave's 16 tokens contain it
-
-    // buffer descriptors of the workgroup's 128-token range: records end at the last valid token / token group
-    const int n_grp = (n_valid + V_TL - 1) / V_TL;
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ktile) + (size_t) boff * K_ROWB, 0, n_valid * K_ROWB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vtile) + (size_t) (boff / V_TL) * D * 4, 0, n_grp * D * 4, 0x00020000);
-    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_ks, rs_vs;
-    if constexpr (KT != PKV_TYPE_F16)
-        rs_ks = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ktile) + tile_quant_bytes(KT, a.block_size, D) + (size_t) boff * NB * 2, 0, n_valid * NB * 2, 0x00020000);
-    if constexpr (VT != PKV_TYPE_F16)
-        rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vtile) + tile_quant_bytes(VT, a.block_size, D) + (size_t) (boff / V_TL) * NB * V_TL * 2, 0,
-                                                  n_grp * NB * V_TL * 2, 0x00020000);
+    const int n_tiles_seq = (seq_len + WG_TOK - 1) / WG_TOK;
+    const int n_it = MULTI ? min(a.n_tile, n_tiles_seq - tile0) : 1;   // tiles this workgroup walks (>= 1)
+    const bool is_last = PREP && tile0 + n_it == n_tiles_seq;           // the new token sits in this workgroup's last tile
+    const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
+    const size_t tq_k = tile_quant_bytes(KT, a.block_size, D), tq_v = tile_quant_bytes(VT, a.block_size, D);
+    // buffer descriptors of a tile's 128-token range: records end at the last valid token / token group (n_valid 0: every load returns 0)
+    auto tile_k  = [&](int phys) { return a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k; };
+    auto tile_v  = [&](int phys) { return a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v; };
+    auto mk_rs_k = [&](int phys, int boff, int nv) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(tile_k(phys)) + (size_t) boff * K_ROWB, 0, nv * K_ROWB, 0x00020000); };
+    auto mk_rs_ks = [&](int phys, int boff, int nv) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(tile_k(phys)) + tq_k + (size_t) boff * NB * 2, 0, nv * NB * 2, 0x00020000); };
+    auto mk_rs_v = [&](int phys, int boff, int nv) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(tile_v(phys)) + (size_t) (boff / V_TL) * D * 4, 0, ((nv + V_TL - 1) / V_TL) * D * 4, 0x00020000); };
+    auto mk_rs_vs = [&](int phys, int boff, int nv) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(tile_v(phys)) + tq_v + (size_t) (boff / V_TL) * NB * V_TL * 2, 0,
+                                                 ((nv + V_TL - 1) / V_TL) * NB * V_TL * 2, 0x00020000); };
 
     // ---- the wave's K rows: 16 tokens = K_NL consecutive 1 KiB chunks ---------------------------------------------------
     const int kr = lane / K_LPR, kc = lane % K_LPR;
@@ -476,31 +498,43 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
     const int k_off = (wave * TPW * K_LPR + lane) * 16;
     const int v_off = (wave * (TPW / V_TL) * V_LPR + lane) * 16;
     uint4 kreg[K_NL];
-    float ksc[K_NL];
-#pragma unroll
-    for (int i = 0; i < K_NL; ++i) {
-        kreg[i] = buf_load16(rs_k, k_off + i * 1024);
-        ksc[i]  = 0.0f;
-        if constexpr (KT != PKV_TYPE_F16) {
-            const int row = wave * TPW + i * K_RPL + kr;
-            const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(rs_ks, (row * NB + kc * KT_::E / PKV_QK) * 2, 0, 0);
-            ksc[i] = h_val(hb);                                 // a row past the end reads scale 0
-        }
-    }
-    // quantized V: the block scales of the cells whose logits this lane will own (NVF cells x NB blocks, 2 bytes each), behind the K stream
+    float ksc[K_NL];                                            // single-tile form: block scales as floats
+    [[maybe_unused]] unsigned short ksb[MULTI ? K_NL : 1];      // MULTI: their f16 bits (converted where they are used: no wait at the prefetch)
     constexpr int NVF_ = ((K_NL * G) >> (ilog2(K_LPR) < ilog2(K_NL * G) ? ilog2(K_LPR) : ilog2(K_NL * G)));
     [[maybe_unused]] unsigned short vsb[PQ ? NVF_ : 1][PQ ? NB : 1];
-    if constexpr (PQ) {
-        constexpr int NS_ = ilog2(K_LPR) < ilog2(K_NL * G) ? ilog2(K_LPR) : ilog2(K_NL * G);
-        const int cidx_ = NVF_ * (kc >> (ilog2(K_LPR) - NS_));
+    auto issue_k = [&](__amdgpu_buffer_rsrc_t rk, [[maybe_unused]] __amdgpu_buffer_rsrc_t rks) {
 #pragma unroll
-        for (int j = 0; j < NVF_; ++j) {
-            const int t = wave * TPW + ((cidx_ + j) / G) * K_RPL + kr;          // cell inside the workgroup's 128
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                vsb[j][b] = __builtin_amdgcn_raw_buffer_load_b16(rs_vs, (((t / V_TL) * NB + b) * V_TL + t % V_TL) * 2, 0, 0);   // past the end: 0
+        for (int i = 0; i < K_NL; ++i) {
+            kreg[i] = buf_load16(rk, k_off + i * 1024);
+            if constexpr (!MULTI) ksc[i] = 0.0f;
+            if constexpr (KT != PKV_TYPE_F16) {
+                const int row = wave * TPW + i * K_RPL + kr;
+                const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(rks, (row * NB + kc * KT_::E / PKV_QK) * 2, 0, 0);
+                if constexpr (MULTI) ksb[i] = hb; else ksc[i] = h_val(hb);   // a row past the end reads scale 0
+            }
         }
-    }
+    };
+    // quantized V: the block scales of the cells whose logits this lane will own (NVF cells x NB blocks, 2 bytes each), behind the K stream
+    auto issue_vs = [&]([[maybe_unused]] __amdgpu_buffer_rsrc_t rvs) {
+        if constexpr (PQ) {
+            constexpr int NS_ = ilog2(K_LPR) < ilog2(K_NL * G) ? ilog2(K_LPR) : ilog2(K_NL * G);
+            const int cidx_ = NVF_ * (kc >> (ilog2(K_LPR) - NS_));
+#pragma unroll
+            for (int j = 0; j < NVF_; ++j) {
+                const int t = wave * TPW + ((cidx_ + j) / G) * K_RPL + kr;          // cell inside the tile's 128
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    vsb[j][b] = __builtin_amdgcn_raw_buffer_load_b16(rvs, (((t / V_TL) * NB + b) * V_TL + t % V_TL) * 2, 0, 0);   // past the end: 0
+            }
+        }
+    };
+    int phys = phys0, tile = tile0;
+    int n_valid = min(WG_TOK, seq_len - base0);                 // >= 1
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_ks, rs_vs;
+    if constexpr (KT != PKV_TYPE_F16) rs_ks = mk_rs_ks(phys, (tile & bs_mask) * WG_TOK, n_valid);
+    if constexpr (VT != PKV_TYPE_F16) rs_vs = mk_rs_vs(phys, (tile & bs_mask) * WG_TOK, n_valid);
+    issue_k(mk_rs_k(phys, (tile & bs_mask) * WG_TOK, n_valid), rs_ks);
+    issue_vs(rs_vs);
     __builtin_amdgcn_sched_barrier(0);
     ts.at(3);                           // row and K loads issued
 
@@ -522,7 +556,7 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
                 k_row_to_lds<KT, D>(sKc, lane, curq[k]);
             } else if (job == G + 1 && is_last) {               // ggml_cpy(Vcur) -> v cache
                 curq[k] = quantize<VT>(jx[k], lane);
-                v_row_to_lds<VT, D>(sVc, lane, curq[k], (boff + n_valid - 1) % V_TL);
+                v_row_to_lds<VT, D>(sVc, lane, curq[k], (seq_len - 1) % V_TL);   // (tiles start on multiples of 128: the token's place in its group)
             }
         }
     }
@@ -530,20 +564,37 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
 #define PKV_VSCHED 0
 #endif
     uint4 vreg[V_NL];
+    __amdgpu_buffer_rsrc_t rs_v = mk_rs_v(phys, (tile & bs_mask) * WG_TOK, n_valid);
     auto issue_v = [&](int i) {
         __builtin_amdgcn_sched_barrier(0);                      // program order = issue order
         vreg[i] = buf_load16(rs_v, v_off + i * 1024);
         __builtin_amdgcn_sched_barrier(0);
     };
-    if (PKV_VSCHED == 2) {              // every V chunk right behind the row job, ahead of the barrier (all waves: the counts must not depend on the path)
+    if (PKV_VSCHED == 2 && !MULTI) {    // every V chunk right behind the row job, ahead of the barrier (all waves: the counts must not depend on the path)
 #pragma unroll
         for (int i = 0; i < V_NL; ++i) issue_v(i);
     }
     __syncthreads();                    // the workgroup's FIRST barrier: Q operand (and the new token's rows) visible
 
-    if (active) {   // ======== the wave's 16 tokens ========
+    // state that lives across the tiles of the MULTI form (single-tile: written once)
+    [[maybe_unused]] float mrun[NVF], lrun[NVF];              // running max / sum of this lane's heads (every lane of a head's group holds the same values)
+#pragma unroll
+    for (int j = 0; j < NVF; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.0f; }
+    float acc[G][4];                    // PV: 4 f32 accumulators per query head, lane owns 4 d of TL tokens per load
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[g][j] = 0.0f;
+    const bool active1 = wv * TPW < n_valid;                    // single-tile form, wave-uniform: a wave past the end only runs its row job
     QFrag<KT, D, G> qf;
-    qf.load(sQ, kc);
+    if (MULTI || active1) qf.load(sQ, kc);
+
+    if (MULTI || active1) {   // ======== the wave's 16 tokens of every tile ========
+    for (int it = 0; it < n_it; ++it) {
+    const int  base    = tile * WG_TOK;
+    const bool last_it = !MULTI || it + 1 == n_it;
+    const bool owner   = is_last && last_it && wv == (n_valid - 1) / TPW;   // the new token's row is among this wave's 16 tokens of this tile
+    [[maybe_unused]] int kpatch = -1;
     if constexpr (PREP) {
         if (owner) {   // the new token's K bits replace whatever the pool slot held (its store happens at the end of the kernel)
             const int tl = n_valid - 1;
@@ -551,7 +602,7 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
             for (int i = 0; i < K_NL; ++i)
                 if (wave * TPW + i * K_RPL + kr == tl) {
                     kreg[i] = *reinterpret_cast<const uint4 *>(&sKc.q[kc * 16]);
-                    if constexpr (KT != PKV_TYPE_F16) ksc[i] = sKc.d[kc * KT_::E / PKV_QK];
+                    if constexpr (KT != PKV_TYPE_F16) { if constexpr (MULTI) kpatch = i; else ksc[i] = sKc.d[kc * KT_::E / PKV_QK]; }
                 }
         }
     }
@@ -564,11 +615,28 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
     for (int i = 0; i < (K_NL > V_NL ? K_NL : V_NL); ++i) {
         if (i < K_NL) {
             float sv[G];
-            k_dot<KT, D, G>(kreg[i], ksc[i], qf, sv);
+            float sc = 0.0f;
+            if constexpr (MULTI) {
+                if constexpr (KT != PKV_TYPE_F16) { sc = h_val(ksb[i]); if constexpr (PREP) { if (kpatch == i) sc = sKc.d[kc * KT_::E / PKV_QK]; } }
+            } else sc = ksc[i];
+            k_dot<KT, D, G>(kreg[i], sc, qf, sv);
 #pragma unroll
             for (int g = 0; g < G; ++g) x[i * G + g] = sv[g];
         }
-        if (PKV_VSCHED == 0 && i < V_NL) issue_v(i);            // V chunk i goes out when K chunk i has been consumed
+        if ((MULTI || PKV_VSCHED == 0) && i < V_NL) issue_v(i); // V chunk i goes out when K chunk i has been consumed
+    }
+    [[maybe_unused]] int n_valid_n = 0, phys_nn = 0;
+    if constexpr (MULTI) {
+        // the NEXT tile's K rows, behind this tile's V rows and ahead of this tile's softmax + PV.  Branch-free: past the workgroup's last tile the
+        // descriptor has no records (every load returns 0 without touching memory) — a load behind a branch would make hipcc drain the queue at the join
+        __builtin_amdgcn_sched_barrier(0);
+        n_valid_n = last_it ? 0 : min(WG_TOK, seq_len - base - WG_TOK);
+        const int boff_n = ((tile + 1) & bs_mask) * WG_TOK;
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t rks_n;
+        if constexpr (KT != PKV_TYPE_F16) rks_n = mk_rs_ks(phys_n, boff_n, n_valid_n);
+        issue_k(mk_rs_k(phys_n, boff_n, n_valid_n), rks_n);
+        phys_nn = trow[min(tile + 2, tile_cap) >> p_bs_shift];   // scalar load: the table entry of the tile after next
+        __builtin_amdgcn_sched_barrier(0);
     }
     reduce_scatter<NV, K_LPR>(x, lane);
     ts.at(5);                           // QK^T done, every V load issued
@@ -583,7 +651,7 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
 #pragma unroll
     for (int j = 0; j < NVF; ++j) {
         const int idx = cidx + j;
-        tok[j] = wave * TPW + (idx / G) * K_RPL + kr;         // token inside the workgroup's 128
+        tok[j] = wave * TPW + (idx / G) * K_RPL + kr;         // token inside the tile's 128
         bool ok = tok[j] < n_valid;
         float mv = 0.0f;
         if constexpr (SLOTPOS) {
@@ -607,6 +675,14 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
         for (int w = 1; w < NW; ++w) M = fmaxf(M, sMX[g][w]);
         mg[j] = M;                                            // the WORKGROUP's max: every wave weighs against the same one
 #endif
+        if constexpr (MULTI) {          // online softmax over the tiles: weigh against the running max, rescale what has been accumulated
+            const float m_new = fmaxf(mrun[j], mg[j]);
+            const float al = mrun[j] == m_new ? 1.0f : __expf(mrun[j] - m_new);   // (first tile: exp(-inf) = 0 on accumulators that are 0)
+            if ((lane >> ilog2(64 / TPW)) == 0) sAl[wave][idx % G] = al;
+            lrun[j] *= al;
+            mrun[j] = m_new;
+            mg[j]   = m_new;
+        }
         pj[j] = mg[j] == -INFINITY ? 0.0f : __expf(x[j] - mg[j]);
         if constexpr (P16) pj[j] = (float) (_Float16) pj[j];  // the weight PV really applies; l is summed from the same values
     }
@@ -621,13 +697,19 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float sc = h_val(vsb[j][b]);
-                if constexpr (PREP) { if (is_last && tok[j] == n_valid - 1) sc = sVc.d[b]; }   // the new token: its scale is not in the pool yet
+                if constexpr (PREP) { if (is_last && last_it && tok[j] == n_valid - 1) sc = sVc.d[b]; }   // the new token: its scale is not in the pool yet
                 const float pw = pj[j] == 0.0f ? 0.0f : pj[j] * sc;      // a stale scale of a cell past the end must not reach 0 * NaN
                 reinterpret_cast<_Float16 *>(sP[wave])[((pair * NB + b) * G + g) * 2 + el] = (_Float16) pw;
             }
         }
         const float l = head_reduce2<TPW, false>(pj[j]);      // sums over the token bits of the lane id only
-        if ((lane >> ilog2(64 / TPW)) == 0) *reinterpret_cast<float2 *>(&sML[wave][g][0]) = make_float2(mg[j], l);
+        if constexpr (MULTI) lrun[j] += l;
+        else if ((lane >> ilog2(64 / TPW)) == 0) *reinterpret_cast<float2 *>(&sML[wave][g][0]) = make_float2(mg[j], l);
+    }
+    if constexpr (MULTI && PQ) {        // the next tile's V scales: this tile's have just been used
+        __builtin_amdgcn_sched_barrier(0);
+        issue_vs(mk_rs_vs(phys_n, ((tile + 1) & bs_mask) * WG_TOK, n_valid_n));
+        __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // LDS strip is read back by other lanes of this wave only
     __builtin_amdgcn_wave_barrier();
@@ -653,12 +735,19 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
         }
     }
 
-    // ---- PV: 4 f32 accumulators per query head, lane owns 4 d of TL tokens per load ---------------------------------
-    float acc[G][4];
+    // ---- PV: lane owns 4 d of TL tokens per load ------------------------------------------------------------------------
+    if constexpr (MULTI) {              // what the earlier tiles accumulated is weighed against the new running max (wave-uniform values)
+        float al[G];
+        bool  resc = false;
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g) { al[g] = sAl[wave][g]; resc = resc || al[g] != 1.0f; }
+        if (resc) {                     // after the first tiles the running max rarely moves
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[g][j] = 0.0f;
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][j] *= al[g];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < V_NL; ++i) {
         const int t0 = i * V_RPL + vl * V_TL;                 // first token (inside the wave) of this lane-load
@@ -709,6 +798,22 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
             }
         }
     }
+    if constexpr (MULTI) {              // on to the next tile (scalar state only)
+        if (!last_it) {
+            tile += 1;
+            phys = phys_n; phys_n = phys_nn;
+            n_valid = n_valid_n;
+            rs_v = mk_rs_v(phys, (tile & bs_mask) * WG_TOK, n_valid);
+        }
+    }
+    }   // tiles
+    if constexpr (MULTI) {              // the wave's (max, sum) over all its tiles
+        const int cidx = NVF * (kc >> (ilog2(K_LPR) - NS));
+        if ((lane >> ilog2(64 / TPW)) == 0) {
+#pragma unroll
+            for (int j = 0; j < NVF; ++j) *reinterpret_cast<float2 *>(&sML[wave][(cidx + j) % G][0]) = make_float2(mrun[j], lrun[j]);
+        }
+    }
     // sum the lane-rows of the wave (lanes with equal vc), then hand the wave's partial to the workgroup
     if constexpr (V_LPR <= 16) {
 #pragma unroll
@@ -742,6 +847,10 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
         __syncthreads();                // the mid barrier of the active waves
 #endif
     }
+    // what the epilogue below knows the workgroup's LAST tile by
+    const int boff = (tile & bs_mask) * WG_TOK;
+    const char * ktile = tile_k(phys);
+    const char * vtile = tile_v(phys);
     __syncthreads();
     ts.at(9);                           // every wave of the workgroup has arrived
 
@@ -752,6 +861,7 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
 #ifndef PKV_KV_AUX
 #define PKV_KV_AUX 2
 #endif
+    static_assert(!MULTI || PKV_PART_WIDE != 0, "final_out lives in the wide partial store");
     if constexpr (!FUSED && PKV_PART_WIDE != 0) {   // experiment: the partial leaves as 16-byte stores of G * D / 4 threads (2: write-through, no dirty L2 lines at the end of the kernel)
         constexpr int C4w = G * D / 4;
         if (tid < C4w) {
@@ -773,6 +883,11 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
                 l = fmaf(lw[w], f, l);
             }
             const size_t pi = ((size_t) s * a.n_head + hk * G + g) * a.n_splits + split;
+            bool final_out = false;
+            if constexpr (MULTI) final_out = a.final_out != 0;
+            if (final_out) {            // the only partial of this head: what attn_combine_kernel would make of it (weight exp(0) = 1, acc / l), same bits
+                *reinterpret_cast<float4 *>(&a.out[((size_t) s * a.n_head + hk * G + g) * D + d4 * 4]) = make_float4(o.x / l, o.y / l, o.z / l, o.w / l);
+            } else
             if (PKV_PART_WIDE == 2) {
                 const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.part_o + pi * D, 0, D * 4, 0x00020000);
                 u4_t ov; ov.x = __float_as_uint(o.x); ov.y = __float_as_uint(o.y); ov.z = __float_as_uint(o.z); ov.w = __float_as_uint(o.w);
@@ -965,7 +1080,7 @@ __global__ void __launch_bounds__(64) attn_combine_kernel(const DecodeArgs a) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) pv[u] = *reinterpret_cast<const colv *>(po + (size_t) min(u, nsm) * D);
     const float2 ml0 = *reinterpret_cast<const float2 *>(ml + (size_t) min(lane, nsm) * 2);
-    const int ns = (seq_len + WG_TOK - 1) / WG_TOK;
+    const int ns = ((seq_len + WG_TOK - 1) / WG_TOK + a.n_tile - 1) / a.n_tile;   // partials the decode launch wrote for this sequence
     float * o = a.out + ((size_t) s * a.n_head + h) * D + C * lane;
     if (ns <= 0) { colv z; for (int c = 0; c < C; ++c) z[c] = 0.0f; *reinterpret_cast<colv *>(o) = z; return; }
     float m = lane < ns ? ml0.x : -INFINITY;
@@ -1016,10 +1131,35 @@ void launch_kernel(K kernel, dim3 grid, dim3 block, hipStream_t st, const Decode
     else              hipLaunchKernelGGL(kernel, grid, block, 0, st, da.block_table, da.seq_lens, da.max_blocks, da.bs_shift, da);
 }
 
+// Tiles per workgroup of the multi-tile form (1 = the single-tile form).  A launch of one 128-token tile per workgroup pays its fixed work — scalars, the Q
+// operand, the cross-wave merge, a partial, a share of the merge launch — once per 128 tokens; once the launch has more workgroups than CUs they only queue
+// behind each other.  Measured (profiles/r03_decode_tiles.txt, ms per step of all layers): 70B geometry ctx 16384 (1024 tiles) 1.99 at 1 tile per workgroup,
+// 1.86 at 2, 1.60 at 4 (= 256 workgroups), 2.24 at 8; 32 sequences x ctx 640: 0.657 -> 0.539 with one workgroup per (sequence, kv head) (no partials, no
+// merge launch); 32 x ctx 4096: 2.93 -> 2.82 (8 tiles) / 2.74 (32); q8_0 / q4_0 KV 32 x ctx 4096: 1.98 -> 1.86 / 1.84 -> 1.57 at 8 tiles (1024 4-wave workgroups).
+// Rule: about one 8-wave workgroup per CU, at most DECODE_MAX_TILES tiles each (the bound keeps one long sequence among short ones from serialising the launch).
+constexpr int DECODE_CUS = 256, DECODE_MAX_TILES = 8;
+inline int decode_tiles_per_wg(int n_splits, int n_head_kv, int n_seq) {
+    if (const char * e = getenv("PKV_DECODE_NTILE")) { const int v = atoi(e); if (v >= 1) return v < n_splits ? v : n_splits; }   // experiments
+    const long wg1 = (long) n_head_kv * n_seq * n_splits;
+    if (wg1 < 2 * DECODE_CUS) return 1;
+    long nt = (wg1 + DECODE_CUS / 2) / DECODE_CUS;
+    if (nt > DECODE_MAX_TILES) nt = DECODE_MAX_TILES;
+    if (nt > n_splits) nt = n_splits;
+    return (int) (nt < 1 ? 1 : nt);
+}
+
 template <int KT, int VT, int D, int G>
-int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
-    dim3 grid(da.n_splits, da.n_head_kv, n_seq);
-    const dim3 block(64 * Geo<KT, VT, D>::NW);
+int launch_one(const DecodeArgs & da0, int n_seq, hipStream_t st) {
+    DecodeArgs da = da0;
+    const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr || da.mask != nullptr;
+    // multi-tile form: the plain variants with their own merge launch
+    da.n_tile = 1; da.final_out = 0;
+    if (!cap && !sp && !da.counters && !da.stamps) {
+        da.n_tile    = decode_tiles_per_wg(da.n_splits, da.n_head_kv, n_seq);
+        da.n_splits  = (da.n_splits + da.n_tile - 1) / da.n_tile;
+        da.final_out = da.n_tile > 1 && da.n_splits == 1 && da.out_direct != nullptr;
+        if (da.final_out) da.out = da.out_direct;     // (also under PKV_ATTN_NO_COMBINE: this form has no partials to leave behind)
+    }
     // quantized KV with workgroups to spare: 32 tokens per wave (4-wave workgroups)
     constexpr bool QKV = KT != PKV_TYPE_F16 || VT != PKV_TYPE_F16;
     const bool wide = QKV && (long) da.n_splits * da.n_head_kv * n_seq >= 1024;
@@ -1027,8 +1167,10 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
 #define PKV_TPW_Q4 32
 #endif
     constexpr int TQ = (KT == PKV_TYPE_Q4_0 && VT == PKV_TYPE_Q4_0) ? PKV_TPW_Q4 : 32;   // tokens per wave of the wide form
+    const bool multi = da.n_tile > 1;
+    dim3 grid(da.n_splits, da.n_head_kv, n_seq);
+    const dim3 block(64 * Geo<KT, VT, D>::NW);
     const dim3 block32(64 * Geo<KT, VT, D, TQ>::NW);
-    const bool cap = da.softcap != 0.0f, sp = da.slot_pos != nullptr || da.mask != nullptr;
     if (da.k_cur && da.counters) {   // the whole decode step of a layer in ONE launch
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, true>, grid, block, st, da);
     } else if (da.k_cur) {      // fused decode step: RoPE(Q), RoPE(K) + KV store and the split-KV attention in one launch
@@ -1041,19 +1183,28 @@ int launch_one(const DecodeArgs & da, int n_seq, hipStream_t st) {
             }
         }
         if (da.stamps) { set_error("pkv_attn_decode_stamps: f16 KV, head_dim 128, gqa 4 or 8 only"); return PKV_ERR_UNSUPPORTED; }
-        if constexpr (QKV) { if (wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, TQ>, grid, block32, st, da); }
-        if (!wide) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
-        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
+        if constexpr (QKV) {
+            if (wide && multi)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, TQ, true>, grid, block32, st, da);
+            else if (wide)      launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, TQ>, grid, block32, st, da);
+        }
+        if (!wide && multi) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, 16, true>, grid, block, st, da);
+        else if (!wide)     launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
+        if (da.out && !da.final_out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
     } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, false>, grid, block, st, da);
     } else {
-        if constexpr (QKV) { if (wide && !cap && !sp) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false, 0, TQ>, grid, block32, st, da); }
-        if (wide && !cap && !sp) {}
-        else if (!cap && !sp) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false>, grid, block, st, da);
+        const bool plain = !cap && !sp;
+        if constexpr (QKV) {
+            if (wide && plain && multi) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false, 0, TQ, true>, grid, block32, st, da);
+            else if (wide && plain)     launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false, 0, TQ>, grid, block32, st, da);
+        }
+        if (wide && plain) {}
+        else if (plain && multi) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false, 0, 16, true>, grid, block, st, da);
+        else if (plain)       launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, false>, grid, block, st, da);
         else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false, false>, grid, block, st, da);
         else if (cap && !sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, false, false, false>, grid, block, st, da);
         else                  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, true, false, false>, grid, block, st, da);
-        if (da.out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
+        if (da.out && !da.final_out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
     }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
@@ -1135,6 +1286,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.part_o  = (float *) a.workspace;
     da.part_ml = da.part_o + (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim;
     da.out = (a.flags & PKV_ATTN_NO_COMBINE) ? nullptr : a.out;
+    da.out_direct = a.out;
     da.counters = nullptr;
     const size_t po_bytes = (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim * sizeof(float);
     da.part_o_bytes = (int) po_bytes; da.part_ml_bytes = (int) (po_bytes / a.head_dim * 2);
@@ -1145,6 +1297,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;  // :12290-12292
     da.k_cur = da.v_cur = nullptr; da.rope_cache = nullptr; da.has_rope = 0; da.rope = RopeDev{};
     da.stamps = g_stamps;
+    da.n_tile = 1; da.final_out = 0;
     if (step) {
         PKV_REQUIRE(step->k_cur && step->v_cur, "pkv_attn_decode_step: null pointer");
         PKV_REQUIRE(((uintptr_t) step->k_cur % 8) == 0 && ((uintptr_t) step->v_cur % 8) == 0 && (a.q_stride_head % 2) == 0, "pkv_attn_decode_step: rows must be 8-byte aligned");

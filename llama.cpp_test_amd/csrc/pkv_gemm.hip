@@ -18,6 +18,9 @@
 #include "pkv_common.h"
 
 #include <cstdlib>
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 namespace pkv {
 namespace {
@@ -34,12 +37,14 @@ __device__ __forceinline__ uint4 ldu(const unsigned char * p) { return *reinterp
 // T may carry PKV_TYPE_PACKED: the row is in the plane layout of pkv_wlayout.h (same bytes, same conversion; only load() differs)
 template <int T> struct RawW;
 template <> struct RawW<PKV_TYPE_F16> {
+    static constexpr int NLOADS = 4;   // vector-memory instructions of load() (gemm2_kernel's counted waits)
     uint4 q[4];
     __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + k0 * 2;
         q[0] = ldu(p); q[1] = ldu(p + 16); q[2] = ldu(p + 32); q[3] = ldu(p + 48); }
     __device__ __forceinline__ void to_half(_Float16 * o, int64_t) const { uint4 * d = reinterpret_cast<uint4 *>(o); d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = q[3]; }
 };
 template <> struct RawW<PKV_TYPE_Q8_0> {   // block_q8_0: f16 d, int8 qs[32] (/ref/ggml/src/ggml-common.h:197-203)
+    static constexpr int NLOADS = 3;
     uint4 q[2]; uint16_t d;
     __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 5) * 34;
         d = *reinterpret_cast<const uint16_t *>(p); q[0] = ldu(p + 2); q[1] = ldu(p + 18); }
@@ -51,6 +56,7 @@ template <> struct RawW<PKV_TYPE_Q8_0> {   // block_q8_0: f16 d, int8 qs[32] (/r
     }
 };
 template <> struct RawW<PKV_TYPE_Q4_K> {   // block_q4_K (:279-290): sub-block j = (k0 % 256) / 32: qs[32 (j / 2) + l] nibble j & 1
+    static constexpr int NLOADS = 3;
     uint4 h, q[2];
     __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 8) * 144; const int j = (int) (k0 & 255) >> 5;
         h = ldu(p); q[0] = ldu(p + 16 + 32 * (j >> 1)); q[1] = ldu(p + 32 + 32 * (j >> 1)); }
@@ -72,6 +78,7 @@ template <> struct RawW<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> : RawW<PKV_TYPE_Q4_K>
         h = ldu(row + 32 * gpr + 16 * (g >> 2)); q[0] = ldu(row + 16 * g); q[1] = ldu(row + 16 * gpr + 16 * g); }
 };
 template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 256, n = e0 / 128, j = (e0 % 128) / 32: ql[64 n + 32 (j & 1) + l] nibble j >> 1, qh[32 n + l] bits 2 j
+    static constexpr int NLOADS = 6;
     uint4 ql[2], qh[2]; uint16_t sc2, d;
     __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 8) * 210; const int e0 = (int) (k0 & 255), n = e0 >> 7, j = (e0 & 127) >> 5;
         ql[0] = ldu(p + 64 * n + 32 * (j & 1)); ql[1] = ldu(p + 64 * n + 32 * (j & 1) + 16); qh[0] = ldu(p + 128 + 32 * n); qh[1] = ldu(p + 128 + 32 * n + 16);
@@ -203,6 +210,220 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     }
 }
 
+
+// ======================================================================================================================================================
+// r03: the second form of the product (gemm2_kernel).  What bounded the kernel above (profiles/r02_gemm_bench.txt: 0.08-0.17 of the MFMA peak) was its staging:
+// every workgroup converted its 128 x 64 activation tile from f32 on every K-step (the same tile in every row-tile's workgroup), every operand element went
+// HBM -> VGPR -> VALU -> ds_write, and a 128 x 128 tile of 4 waves re-read each LDS byte for only 64 x 64 of MFMA work.  Here:
+//   * the activations are rounded to f16 ONCE per product (convert pass into a per-stream scratch, 3 % of the product's time at 2048 columns) and their tile
+//     goes HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPRs, no VALU, no ds_write; f16 weights travel the same way;
+//   * quantized weight tiles are dequantized with packed f16 arithmetic (the 0x6400 byte-permute of the attention kernels: two elements per instruction,
+//     the sub-block scale rounded to f16 once) and written as 16-byte chunks;
+//   * LDS rows are 64 halfs = 128 B, unpadded (LDS-DMA writes lane-linear), 16-byte chunk c of row r at position c ^ ((r >> 1) & 7): fragment reads
+//     (16 consecutive rows x one chunk) and the staging writes touch every bank once;
+//   * tiles up to 256 x 256 with 8 waves (2 x 4, wave tile 128 x 64: 128 accumulator registers), two LDS images, one barrier per 64-deep K-step;
+//   * workgroup order: column tiles fastest, so the workgroups that run together share one band of weight rows and each XCD's L2 keeps its own activation tile.
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2v u2h(uint32_t u) { return *reinterpret_cast<const h2v *>(&u); }
+__device__ __forceinline__ uint32_t h2u(h2v h) { return *reinterpret_cast<const uint32_t *>(&h); }
+__device__ __forceinline__ h2v splat(float f) { const _Float16 x = (_Float16) f; return h2v{x, x}; }
+// 4 bytes u (0..255 each) -> 4 halfs (u - bias) * mul + add, in two dwords (elements 0, 1 | 2, 3)
+__device__ __forceinline__ void cvt4(uint32_t b, h2v nbias, h2v mul, h2v add, uint32_t & o01, uint32_t & o23) {
+    o01 = h2u((u2h(__builtin_amdgcn_perm(0x64646464u, b, 0x04010400u)) + nbias) * mul + add);
+    o23 = h2u((u2h(__builtin_amdgcn_perm(0x64646464u, b, 0x04030402u)) + nbias) * mul + add);
+}
+// 32 consecutive weights of a row as 32 halfs in 4 x 16 bytes (k order)
+template <int T> struct Deq;
+template <> struct Deq<PKV_TYPE_Q8_0> { static __device__ __forceinline__ void run(const RawW<PKV_TYPE_Q8_0> & w, int64_t, uint4 * o) {
+    const h2v d = u2h((uint32_t) w.d * 0x10001u), nb = splat(-1152.0f), z = splat(0.0f);   // int8 ^ 0x80 = value + 128 under the 1024 of the magic
+    const uint32_t * q = reinterpret_cast<const uint32_t *>(w.q);
+    uint32_t * ow = reinterpret_cast<uint32_t *>(o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cvt4(q[i] ^ 0x80808080u, nb, d, z, ow[2 * i], ow[2 * i + 1]);
+} };
+template <> struct Deq<PKV_TYPE_Q4_K> { static __device__ __forceinline__ void run(const RawW<PKV_TYPE_Q4_K> & w, int64_t k0, uint4 * o) {
+    const int j = (int) (k0 & 255) >> 5;
+    const float d = hf((uint16_t) (w.h.x & 0xFFFF)), dmin = hf((uint16_t) (w.h.x >> 16));
+    const int sh = 8 * (j & 3);
+    const int b0 = (int) ((w.h.y >> sh) & 0xFF), b1 = (int) ((w.h.z >> sh) & 0xFF), b2 = (int) ((w.h.w >> sh) & 0xFF);   // get_scale_min_k4
+    const int sc = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4)), mn = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
+    const h2v d1 = splat(d * (float) sc), m1 = splat(-(dmin * (float) mn)), nb = splat(-1024.0f);
+    const uint32_t * q = reinterpret_cast<const uint32_t *>(w.q);
+    uint32_t * ow = reinterpret_cast<uint32_t *>(o);
+    const int s4 = 4 * (j & 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cvt4((q[i] >> s4) & 0x0F0F0F0Fu, nb, d1, m1, ow[2 * i], ow[2 * i + 1]);
+} };
+template <> struct Deq<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> { static __device__ __forceinline__ void run(const RawW<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> & w, int64_t k0, uint4 * o) {
+    Deq<PKV_TYPE_Q4_K>::run(w, k0, o); } };
+template <> struct Deq<PKV_TYPE_Q6_K> { static __device__ __forceinline__ void run(const RawW<PKV_TYPE_Q6_K> & w, int64_t k0, uint4 * o) {
+    const int j = ((int) (k0 & 127)) >> 5;
+    const float df = hf(w.d);
+    const h2v s0 = splat(df * (float) (signed char) (w.sc2 & 0xFF)), s1 = splat(df * (float) (signed char) (w.sc2 >> 8)), nb = splat(-1056.0f), z = splat(0.0f);   // 1024 + the 32 of q6_K
+    const uint32_t * l = reinterpret_cast<const uint32_t *>(w.ql), * hh = reinterpret_cast<const uint32_t *>(w.qh);
+    uint32_t * ow = reinterpret_cast<uint32_t *>(o);
+    const int s4 = 4 * (j >> 1), s2 = 2 * j;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cvt4(((l[i] >> s4) & 0x0F0F0F0Fu) | (((hh[i] >> s2) & 0x03030303u) << 4), nb, i < 4 ? s0 : s1, z, ow[2 * i], ow[2 * i + 1]);
+} };
+template <> struct Deq<(PKV_TYPE_Q6_K | PKV_TYPE_PACKED)> { static __device__ __forceinline__ void run(const RawW<(PKV_TYPE_Q6_K | PKV_TYPE_PACKED)> & w, int64_t k0, uint4 * o) {
+    Deq<PKV_TYPE_Q6_K>::run(w, k0, o); } };
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int ROWB2 = BK * 2;                                 // LDS row of the second form: 64 halfs, unpadded
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) gemm2_kernel(const GemmArgs a, const _Float16 * __restrict__ xh) {
+    constexpr int NT = 64 * WM * WN, NWAVE = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr bool ADMA = (T & ~PKV_TYPE_PACKED) == PKV_TYPE_F16;          // f16 weights: no conversion, the tile goes by LDS-DMA like the activations
+    constexpr int IMG = (BM + BN) * ROWB2;
+    static_assert(TM >= 1 && TN >= 1 && BM % (8 * NWAVE) == 0 && BN % (8 * NWAVE) == 0 && (2 * BM) % 64 == 0, "tile shape");
+    static_assert(2 * BM <= NT || ADMA, "one (row, half) item per thread in the register-staged weight tile");
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG];          // [image][A rows | B rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave % WM, wn = wave / WM;
+    const int r = lane & 31, h = lane >> 5;
+    // workgroup -> (row tile of one of the matrices, column tile): blockIdx.x = column tile (fastest), blockIdx.y = row tile over all matrices
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX; ++i) if (i < a.n && (int) blockIdx.y >= a.tile_end[i - 1]) mi = i;
+    const int64_t aM = a.M[mi];
+    const unsigned char * const aw = a.w[mi];
+    float * const ay = a.y[mi];
+    const int64_t m0 = (int64_t) ((int) blockIdx.y - (mi ? a.tile_end[mi - 1] : 0)) * BM, n0 = (int64_t) blockIdx.x * BN;
+
+    // ---- LDS-DMA roles: instruction i of a wave fills rows (wave * NI + i) * 8 .. + 7 of a tile: lane l -> row + l / 8, chunk POSITION l % 8, which holds
+    //      chunk (l % 8) ^ swz(row) of the source row (rows past the end of the operand re-read its last row; their outputs are never stored)
+    constexpr int NIB = BN / 8 / NWAVE, NIA = BM / 8 / NWAVE;
+    const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(xh) + n0 * a.K, 0, (int) (min((int64_t) BN, a.N - n0) * a.K * 2), 0x00020000);
+    int vo_b[NIB];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int row = (wave * NIB + i) * 8 + (lane >> 3);
+        vo_b[i] = (int) (min((int64_t) row, a.N - 1 - n0) * a.K * 2) + (((lane & 7) ^ swz(row)) << 4);
+    }
+    [[maybe_unused]] rsrc_t rs_w;
+    [[maybe_unused]] int vo_a[ADMA ? NIA : 1];
+    if constexpr (ADMA) {
+        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(aw) + m0 * a.row_bytes, 0, (int) (min((int64_t) BM, aM - m0) * a.row_bytes), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int row = (wave * NIA + i) * 8 + (lane >> 3);
+            vo_a[i] = (int) (min((int64_t) row, aM - 1 - m0) * a.row_bytes) + (((lane & 7) ^ swz(row)) << 4);
+        }
+    }
+    auto dma = [&](int64_t k0, char * img) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (ADMA) {
+#pragma unroll
+            for (int i = 0; i < NIA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *) (img + (wave * NIA + i) * 1024), 16, vo_a[i], (int) (k0 * 2), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *) (img + BM * ROWB2 + (wave * NIB + i) * 1024), 16, vo_b[i], (int) (k0 * 2), 0, 0);
+#endif
+    };
+    // ---- register-staged weight tile (quantized types): thread -> row tid >> 1, 32-element half tid & 1
+    const int srow = tid >> 1, shalf = tid & 1;
+    const bool stage_a = !ADMA && srow < BM;
+    const unsigned char * wrow = aw + (size_t) min(m0 + (srow < BM ? srow : 0), aM - 1) * a.row_bytes;
+    RawW<T> rw;
+    auto load_raw = [&](int64_t k0) {
+        if constexpr (!ADMA) {
+            if (stage_a) { if constexpr ((T & PKV_TYPE_PACKED) != 0) rw.load(wrow, k0 + 32 * shalf, a.K); else rw.load(wrow, k0 + 32 * shalf); }
+        }
+    };
+    auto write_a = [&](int64_t k0, char * img) {
+        if constexpr (!ADMA) {
+            if (stage_a) {
+                uint4 o[4];
+                Deq<T>::run(rw, k0 + 32 * shalf, o);
+                char * dst = img + srow * ROWB2;
+                const int key = swz(srow);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(dst + (((4 * shalf + i) ^ key) << 4)) = o[i];
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // fragment addresses: row = wave's first row + 32 i + r; chunk 2 ks + h at position (2 ks + h) ^ swz(row) — swz(row) is the same for every i (32 i is a multiple of 16)
+    const int a_ro = (wm * 32 * TM + r) * ROWB2, b_ro = BM * ROWB2 + (wn * 32 * TN + r) * ROWB2, fkey = swz(r);
+
+    // vector-memory order per step: [raw weight loads of step k+2] ... [LDS-DMA of step k+1] ...; the wait before the barrier leaves the NR youngest
+    // operations — the raw loads just issued — in flight (memory returns in order: everything older, i.e. the LDS-DMA tiles of the next image, has landed)
+    constexpr int NR = ADMA ? 0 : RawW<T>::NLOADS;
+    const bool wave_stages = !ADMA && (wave * 64) / 2 < BM;       // wave-uniform: this wave's threads carry weight rows
+    // (a raw s_barrier behind explicit waits: __syncthreads() would drain the raw loads too — with LDS-DMA in the loop hipcc puts vmcnt(0) in front of it)
+    auto wait_dma_and_barrier = [&]() {
+        if (wave_stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NR) : "memory");
+        else             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    load_raw(0);
+    dma(0, smem);
+    write_a(0, smem);
+    load_raw(BK < a.K ? BK : 0);
+    wait_dma_and_barrier();
+    int it = 0;
+    for (int64_t k0 = 0; k0 < a.K; k0 += BK, ++it) {
+        const char * cur = smem + (it & 1) * IMG;
+        char * nxt = smem + ((it + 1) & 1) * IMG;
+        const bool more = k0 + BK < a.K;
+        if (more) dma(k0 + BK, nxt);                       // the next step's LDS-DMA tiles: in flight under this step's MFMAs (the other image: last read one barrier ago)
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            half8_t af[TM], bf[TN];
+            const int po = (((2 * ks + h) ^ fkey) << 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t *>(cur + a_ro + i * 32 * ROWB2 + po);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8_t *>(cur + b_ro + j * 32 * ROWB2 + po);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) write_a(k0 + BK, nxt);                   // the step loaded a whole step ago: converted and stored behind this step's MFMAs
+        if (k0 + 2 * BK < a.K) load_raw(k0 + 2 * BK);
+        else if (more) load_raw(k0 + BK);                  // (keeps the count of the wait below: a re-load of the last step, never used)
+        if (more) wait_dma_and_barrier();                  // this wave's share of the next image has landed (LDS-DMA is counted in vmcnt) ... and everyone's; everyone is
+    }                                                      // done reading the current image
+    // C: col (token) = lane & 31, row (m) = (reg & 3) + 8 (reg >> 2) + 4 h
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn * 32 * TN + j * 32 + r;
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t m = m0 + wm * 32 * TM + i * 32 + 8 * g + 4 * h;
+                if ((aM & 3) == 0 && m + 3 < aM) *reinterpret_cast<float4 *>(ay + (size_t) n * aM + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                else
+                    for (int e = 0; e < 4; ++e) if (m + e < aM) ay[(size_t) n * aM + m + e] = acc[i][j][4 * g + e];
+            }
+    }
+}
+
+// activations f32 -> f16, once per product
+__global__ void __launch_bounds__(256) cvt_f16_kernel(const float4 * __restrict__ x, uint2 * __restrict__ o, int64_t n4) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t) gridDim.x * 256) {
+        const float4 v = x[i];
+        const _Float16 hv[4] = {(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
+        o[i] = *reinterpret_cast<const uint2 *>(hv);
+    }
+}
+
 }  // namespace
 
 bool gemm_supported(int type_w, int64_t M, int64_t K) {
@@ -210,6 +431,68 @@ bool gemm_supported(int type_w, int64_t M, int64_t K) {
     if (type_w != PKV_TYPE_F16 && type_w != PKV_TYPE_Q8_0 && type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q6_K) return false;
     return M > 0 && K > 0 && K % BK == 0 && (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K ? K % 256 == 0 : true);
 }
+
+// ---- per-stream scratch of the f16 activations (grown on demand; hipFree of the old buffer synchronises) ----
+namespace {
+struct XhScratch { void * p = nullptr; size_t cap = 0; };
+std::mutex g_xh_mu;
+std::unordered_map<hipStream_t, XhScratch> g_xh;
+int xh_scratch(hipStream_t st, size_t bytes, _Float16 ** out) {
+    std::lock_guard<std::mutex> lk(g_xh_mu);
+    XhScratch & s = g_xh[st];
+    if (s.cap < bytes) {
+        if (s.p) PKV_HIP(hipFree(s.p));
+        s.p = nullptr; s.cap = 0;
+        const size_t want = (bytes + (size_t) (8 << 20)) & ~(size_t) ((1 << 20) - 1);
+        PKV_HIP(hipMalloc(&s.p, want));
+        s.cap = want;
+    }
+    *out = (_Float16 *) s.p;
+    return PKV_OK;
+}
+
+// second form (gemm2_kernel): PKV_OK and *done = true when it took the product
+int launch_gemm2(GemmArgs & a, int type_w, int64_t n_cols, hipStream_t st, bool * done) {
+    *done = false;
+    if (getenv("PKV_GEMM_V1")) return PKV_OK;                  // A/B switch: the first form for everything
+    if (n_cols < 64 || (a.K % BK) != 0 || a.K * 2 * 256 >= ((int64_t) 1 << 31)) return PKV_OK;
+    auto tiles = [&](int bm, int bn) { int64_t t = 0; for (int i = 0; i < a.n; ++i) t += (a.M[i] + bm - 1) / bm; return t * ((n_cols + bn - 1) / bn); };
+    // the largest tile that still fills the chip: 256 x 256 / 256 x 128 run one 8-wave workgroup per CU, 128 x 128 / 64 x 128 two 4-wave workgroups
+    int shape;
+    if      (tiles(256, 256) >= 200) shape = 0;
+    else if (tiles(256, 128) >= 200) shape = 1;
+    else if (tiles(128, 128) >= 384) shape = 2;
+    else                             shape = 3;
+    if (const char * e = getenv("PKV_GEMM2_SHAPE")) shape = atoi(e) & 3;   // experiments
+    const int bm = shape <= 1 ? 256 : (shape == 2 ? 128 : 64), bn = shape == 0 ? 256 : 128;
+    int tot = 0;
+    for (int i = 0; i < a.n; ++i) { tot += (int) ((a.M[i] + bm - 1) / bm); a.tile_end[i] = tot; }
+    _Float16 * xh = nullptr;
+    const int rc = xh_scratch(st, (size_t) n_cols * a.K * 2, &xh);
+    if (rc != PKV_OK) return rc;
+    const int64_t n4 = n_cols * a.K / 4;
+    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) std::min<int64_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, (const float4 *) a.x, (uint2 *) xh, n4);
+    a.ksplit = 1;
+    const dim3 grid((unsigned) ((n_cols + bn - 1) / bn), (unsigned) tot);
+#define PKV_GEMM2(T_) do { if (shape == 0) hipLaunchKernelGGL((gemm2_kernel<T_, 256, 256, 2, 4>), grid, dim3(512), 0, st, a, xh); \
+                           else if (shape == 1) hipLaunchKernelGGL((gemm2_kernel<T_, 256, 128, 4, 2>), grid, dim3(512), 0, st, a, xh); \
+                           else if (shape == 2) hipLaunchKernelGGL((gemm2_kernel<T_, 128, 128, 2, 2>), grid, dim3(256), 0, st, a, xh); \
+                           else hipLaunchKernelGGL((gemm2_kernel<T_, 64, 128, 1, 4>), grid, dim3(256), 0, st, a, xh); } while (0)
+    switch (type_w) {
+        case PKV_TYPE_F16:  PKV_GEMM2(PKV_TYPE_F16); break;
+        case PKV_TYPE_Q8_0: PKV_GEMM2(PKV_TYPE_Q8_0); break;
+        case PKV_TYPE_Q4_K: PKV_GEMM2(PKV_TYPE_Q4_K); break;
+        case PKV_TYPE_Q6_K: PKV_GEMM2(PKV_TYPE_Q6_K); break;
+        case PKV_TYPE_Q4_K | PKV_TYPE_PACKED: PKV_GEMM2((PKV_TYPE_Q4_K | PKV_TYPE_PACKED)); break;
+        case PKV_TYPE_Q6_K | PKV_TYPE_PACKED: PKV_GEMM2((PKV_TYPE_Q6_K | PKV_TYPE_PACKED)); break;
+        default: return PKV_OK;
+    }
+#undef PKV_GEMM2
+    PKV_HIP(hipGetLastError());
+    *done = true;
+    return PKV_OK;
+}
+}  // namespace
 
 int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols, hipStream_t st) {
     if (n_cols == 0) return PKV_OK;
@@ -226,6 +509,11 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
         r128 += (M[i] + 127) / 128; r64 += (M[i] + 63) / 64;
     }
     if (a.n == 0) return PKV_OK;
+    {
+        bool done = false;
+        const int rc = launch_gemm2(a, type_w, n_cols, st, &done);
+        if (rc != PKV_OK || done) return rc;
+    }
     // 128 x 128 tiles; 64 x 128, then 64 x 64, where the larger shape would leave CUs without a tile (or with one: a single 4-wave workgroup per CU
     // runs at about half the rate of two)
     const int64_t t128 = r128 * ((n_cols + 127) / 128), t64 = r64 * ((n_cols + 127) / 128);

@@ -66,9 +66,10 @@ def test_prefill_quantized_kv(pkv, O, tk, tv):
     got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=n_qs, D=128, nh=8, nkv=2, tk=tk, tv=tv)
     assert np.isfinite(got).all()
     assert nmse(got, ref) <= 5e-4
-    assert np.abs(got - ref).max() <= 3e-3                   # Q is f16 here, q8_0-quantized in the reference
-    # K/V are dequantized to f16 for the MFMA operands (2^-11 relative rounding per element): bounded absolute distance to exact
-    assert np.abs(got - exact).max() <= 1e-3
+    assert np.abs(got - ref).max() <= 1e-3                   # quantized K: Q takes the reference's q8_0 rounding (r03)
+    # K/V (and the q8_0-rounded Q) reach the MFMA as f16 operands (2^-11 relative rounding per element): never further from exact arithmetic than
+    # the reference itself by more than that
+    assert np.abs(got - exact).max() <= np.abs(ref - exact).max() + 5e-4
 
 
 def test_prefill_equals_decode_for_single_query(pkv, O):
@@ -144,7 +145,7 @@ def test_prefill_general_mask_noncausal(pkv, O, tk, max_bias, softcap):
         ref = O.flash_attn_ext(q.transpose(1, 0, 2), kc, vc, mask, type_k=tk, type_v=tk, scale=D ** -0.5, max_bias=max_bias,
                                softcap=softcap)
         assert nmse(out.cpu().numpy(), ref) <= 5e-4, (n_q,)
-        assert np.abs(out.cpu().numpy() - ref).max() <= 3e-3
+        assert np.abs(out.cpu().numpy() - ref).max() <= 1e-3
 
 
 @pytest.mark.parametrize("tk,nkv,nh", [(1, 2, 8), (8, 1, 8), (1, 8, 32)])
@@ -212,7 +213,7 @@ def test_prefill_other_block_sizes(pkv, O, bs, tk):
     lens, n_qs = [1, 63, 190, 193, 500, 700], [1, 63, 100, 193, 37, 300]
     got, ref, exact = run_prefill(pkv, O, rng, lens=lens, n_qs=n_qs, D=128, nh=8, nkv=2, tk=tk, tv=tk, bs=bs)
     assert np.isfinite(got).all()
-    assert np.abs(got - ref).max() <= (np.abs(ref - exact).max() + 3e-4 if tk == 1 else 3e-3) and nmse(got, ref) <= 5e-4
+    assert np.abs(got - ref).max() <= (np.abs(ref - exact).max() + 3e-4 if tk == 1 else 1e-3) and nmse(got, ref) <= 5e-4
 
 
 @pytest.mark.parametrize("D,nh,nkv", [(128, 8, 2), (64, 32, 4), (128, 64, 8)])

@@ -50,8 +50,7 @@ def test_runner_matches_dense_model(pkv, O, tk):
                 err = np.abs(got[t] - ref).max()
                 if err > 1e-3:
                     exact = O.flash_attn_f64(qr[t][:, None, :], kc, vc, None, type_k=tk, type_v=tk, scale=D ** -0.5)[0]
-                    # (quantized KV: the prefill kernel keeps Q in f16 where the reference quantizes it to q8_0 — the stated deviation and bar of tests/test_gpu_prefill.py)
-                    assert np.abs(got[t] - exact).max() <= np.abs(ref - exact).max() and err <= (2e-3 if tk == 1 else 3e-3), (il, t, s, err)
+                    assert np.abs(got[t] - exact).max() <= np.abs(ref - exact).max() and err <= 2e-3, (il, t, s, err)
                 assert nmse(got[t], ref) <= 5e-4
 
     # three prompts in ONE ubatch (prefill kernel, ragged)
@@ -108,7 +107,11 @@ def test_tinyllama_tg128_from_empty_cache(pkv, O):
                 kc, vc = np.stack(ks[il]).transpose(1, 0, 2), np.stack(vs[il]).transpose(1, 0, 2)
                 ref = O.flash_attn_ext(qr[:, None, :], kc, vc, None, type_k=1, type_v=1, scale=D ** -0.5)[0]
                 got = outs[il].cpu().numpy()[0]
-                assert np.abs(got - ref).max() <= 2.5e-3 and nmse(got, ref) <= 5e-4, (t, il)
+                err = np.abs(got - ref).max()
+                if err > 1e-3:     # f16 V: the reference accumulates V in f16 (ggml-cpu.c:12374-12388); beyond 1e-3 the kernel must be the one closer to exact arithmetic
+                    exact = O.flash_attn_f64(qr[:, None, :], kc, vc, None, type_k=1, type_v=1, scale=D ** -0.5)[0]
+                    assert np.abs(got - exact).max() <= np.abs(ref - exact).max() and err <= 2.5e-3, (t, il, err)
+                assert nmse(got, ref) <= 5e-4, (t, il)
     assert r.cache.seq_len(0) == 131 and len(r.cache.seq_blocks(0)) == 2
     r.close()
 
