@@ -466,6 +466,10 @@ def timed_config(pkv, torch, *, model, ctx, n_seq, kv_type, steps, warmup, reps,
            "bytes_launch": bytes_launch, "achieved": achieved,
            "kernel_us": {"mean": round(k_used * 1e6, 3), "event_bound_mean": round(k_mean * 1e6, 3), "event_bound_median": round(k_med * 1e6, 3), "event_bound_min": round(k_min * 1e6, 3)},
            "k_graph": k_graph is not None}
+    tiles = 1 if fused_merge else pkv.attn_decode_tiles(ctx, g["n_head_kv"], n_seq)
+    rec["tiles_per_workgroup"] = tiles
+    rec["merge"] = ("in-kernel (last-arriving workgroup)" if fused_merge else
+                    "none: one workgroup per (sequence, kv head) walks the whole sequence and writes the output" if (tiles > 1 and tiles >= -(-ctx // 128)) else "second launch")
     if not keep:
         del w
         torch.cuda.empty_cache()
@@ -484,7 +488,8 @@ def configs_record(pkv, torch, *, reps, kernel_reps):
             r = timed_config(pkv, torch, reps=reps, kernel_reps=max(3, kernel_reps // 4), **kw)
             out[name] = {"value": round(r["tok_s"], 2), "unit": "tok/s", "ms_per_step": round(r["dt"] / kw["steps"] * 1e3, 5), "steps": kw["steps"], "repetitions": r["reps"],
                          "roofline": {"bound": "hbm", "achieved": round(r["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(r["achieved"] / HBM_PEAK_GBS, 4),
-                                      "algorithmic_bytes_per_launch": r["bytes_launch"], "kernel_us": r["kernel_us"]}}
+                                      "algorithmic_bytes_per_launch": r["bytes_launch"], "kernel_us": r["kernel_us"]},
+                         "tiles_per_workgroup": r["tiles_per_workgroup"], "merge": r["merge"]}
         except Exception as e:   # one configuration must not take the line down
             out[name] = {"error": f"{type(e).__name__}: {e}"}
     try:
@@ -599,7 +604,7 @@ def main(argv=None):
         "config": {"workload": f"Llama-3-{args.model.upper()} geometry, {args.n_seq} seq/GPU, ctx {args.ctx} paged decode "
                                f"(block_size 128, {args.kv_type} KV), attention path of all {g['n_layer']} layers per token",
                    "n_layer": g["n_layer"], "n_head": g["n_head"], "n_head_kv": g["n_head_kv"], "head_dim": 128, "block_size": 128, "ctx": args.ctx,
-                   "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "hipGraph" if r["graph"] else "eager", "merge": "in-kernel (last-arriving workgroup)" if args.fused_merge else "second launch",
+                   "kv_type": args.kv_type, "seqs_per_gpu": args.n_seq, "launch": "hipGraph" if r["graph"] else "eager", "merge": r["merge"], "tiles_per_workgroup": r["tiles_per_workgroup"],
                    "step": "pkv_attn_decode_step (RoPE + KV store inside the decode launch) + merge" if w.fused_step else "pkv_qkv_prepare + pkv_attn_decode",
                    "parallelism": f"replicas x{world} (no collective on the data path)"},
         "repetitions": r["reps"],

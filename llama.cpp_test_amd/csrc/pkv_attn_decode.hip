@@ -1244,6 +1244,10 @@ int launch_v(const DecodeArgs & da, int VT, int D, int G, int n_seq, hipStream_t
 
 }  // namespace
 
+int decode_tiles_for(int max_seq_len, int n_head_kv, int n_seq) {
+    return decode_tiles_per_wg((max_seq_len + WG_TOK - 1) / WG_TOK, n_head_kv, n_seq);
+}
+
 // [part_o f32 n_tok*n_head*ns*D][part_ml f32 n_tok*n_head*ns*2][tickets u32 n_tok*n_head][rope cache f32 n_tok*D, 16-byte aligned]
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len) {
     const size_t ns = (size_t) (max_seq_len + WG_TOK - 1) / WG_TOK;

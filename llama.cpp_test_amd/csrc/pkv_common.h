@@ -119,6 +119,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * rope_cache = nullptr);   // rope_cache: RoPE(Q) fused in (NORM pairs)
 int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
+int decode_tiles_for(int max_seq_len, int n_head_kv, int n_seq);   // tiles per workgroup the plain decode launch of this shape takes
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);
 void set_prefill_stamps(void * dev_u64);  // diagnostic
 int launch_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,

@@ -1,4 +1,6 @@
 """helpers shared by the -m gpu tests: build paged pools in the oracle's numpy form and mirror them on the device"""
+import os
+
 import numpy as np
 import torch
 
@@ -34,3 +36,23 @@ def nmse(a, b):
     """tests/test-backend-ops.cpp:177-190"""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30))
+
+
+class forced_tiles:
+    """PKV_DECODE_NTILE for the launches inside the block (the library reads it per launch): tiles one decode workgroup walks; None = the library's choice"""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.old = os.environ.get("PKV_DECODE_NTILE")
+        if self.n is None:
+            os.environ.pop("PKV_DECODE_NTILE", None)
+        else:
+            os.environ["PKV_DECODE_NTILE"] = str(self.n)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("PKV_DECODE_NTILE", None)
+        else:
+            os.environ["PKV_DECODE_NTILE"] = self.old

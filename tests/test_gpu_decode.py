@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import cases_of
-from gpu_util import dev, make_paged_case, nmse
+from gpu_util import dev, forced_tiles, make_paged_case, nmse
 
 pytestmark = pytest.mark.gpu
 TYPES = {"f16": 1, "q8_0": 8, "q4_0": 2}
@@ -192,7 +192,8 @@ def test_decode_fused_merge_matches_two_launch(pkv, O, tk):
     lens = [4096, 1, 129, 640, 128, 2000]
     kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
     q = rng.uniform(-1, 1, (len(lens), nh, D)).astype(np.float32)
-    base = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=nkv, tk=tk, tv=tk)
+    with forced_tiles(1):     # (the two-launch path in its one-tile-per-workgroup form: the partition the in-kernel merge keeps)
+        base = run_decode(pkv, q, kp, vp, bt, sl, n_head_kv=nkv, tk=tk, tv=tk)
     # quantized KV: a launch of this size (1536 workgroups) runs the two-launch kernel with 32 tokens per wave, the in-kernel merge keeps 16 — other wave
     # maxima, so the f16 weights P * d_V round differently (both within the oracle bars, tests above); f16 KV: the same partition, f32 sums only
     tol = 2e-6 if tk == 1 else 1e-4
@@ -205,7 +206,8 @@ def test_decode_fused_merge_matches_two_launch(pkv, O, tk):
         assert np.abs(out.cpu().numpy() - base).max() <= tol, it
     # shorter sequences afterwards: fewer arrivals per ticket, still consistent
     sl2 = np.minimum(sl, 200).astype(np.int32)
-    base2 = run_decode(pkv, q, kp, vp, bt, sl2, n_head_kv=nkv, tk=tk, tv=tk)
+    with forced_tiles(1):
+        base2 = run_decode(pkv, q, kp, vp, bt, sl2, n_head_kv=nkv, tk=tk, tv=tk)
     out2 = pkv.attn_decode(dq, dk, dv, dbt, dev(sl2), n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5,
                            max_seq_len=int(sl.max()), workspace=ws, flags=pkv.ATTN_FUSED_COMBINE)
     torch.cuda.synchronize()

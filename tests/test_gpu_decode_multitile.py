@@ -5,35 +5,15 @@ The library picks the tiles per workgroup from the launch shape; PKV_DECODE_NTIL
 form meets the same bars on the same ragged inputs: oracle max-abs <= 1e-3 and NMSE <= 5e-4 (tests/test-backend-ops.cpp:3216),
 never worse than twice the reference's own distance to f64; the fused step (RoPE + KV store inside the launch) leaves the same
 pool bytes whatever the tile count, and physical block order never changes a bit (the table is logical -> physical)."""
-import os
-
 import numpy as np
 import pytest
 import torch
 
-from gpu_util import dev, make_paged_case, nmse
+from gpu_util import dev, forced_tiles, make_paged_case, nmse
 from test_gpu_decode_step import _case, _fused
 
 pytestmark = pytest.mark.gpu
 TYPES = {"f16": 1, "q8_0": 8, "q4_0": 2}
-
-
-class forced_tiles:
-    def __init__(self, n):
-        self.n = n
-
-    def __enter__(self):
-        self.old = os.environ.get("PKV_DECODE_NTILE")
-        if self.n is None:
-            os.environ.pop("PKV_DECODE_NTILE", None)
-        else:
-            os.environ["PKV_DECODE_NTILE"] = str(self.n)
-
-    def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("PKV_DECODE_NTILE", None)
-        else:
-            os.environ["PKV_DECODE_NTILE"] = self.old
 
 
 def _decode(pkv, q, kp, vp, bt, sl, nkv, tk, tv):

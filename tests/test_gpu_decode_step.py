@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import dev, make_paged_case, nmse
+from gpu_util import dev, forced_tiles, make_paged_case, nmse
 
 pytestmark = pytest.mark.gpu
 TYPES = {"f16": 1, "q8_0": 8, "q4_0": 2}
@@ -139,7 +139,8 @@ def test_step_with_in_kernel_merge(pkv, O, tk, tv, D, nh, nkv):
     lens = [1, 127, 128, 129, 640, 4096, 4500, 2000]
     kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, lens, D, nh, nkv, tk, tv)
     rope = pkv.rope_params(n_dims=D, mode=0, freq_base=500000.0)
-    base = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=tk, tv=tv)
+    with forced_tiles(1):     # (the two-launch path in its one-tile-per-workgroup form: the partition the in-kernel merge keeps)
+        base = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=tk, tv=tv)
     ws = pkv.attn_workspace(len(lens), nh, D, int(sl.max()), 128)
     for it in range(3):
         dq, dkp, dvp = dev(q), dev(kp), dev(vp)
