@@ -494,12 +494,15 @@ def configs_record(pkv, torch, *, reps, kernel_reps):
             out[name] = {"error": f"{type(e).__name__}: {e}"}
     try:
         out["8b_batched_bench_32x_pp512_tg128_f16"] = batched_bench_record(pkv, torch, npl=32, npp=512, ntg=128, n_batch=2048, kv_type="f16", reps=reps)
+        h = batched_bench_record(pkv, torch, npl=32, npp=512, ntg=128, n_batch=2048, kv_type="f16", reps=reps, pp_f16=True)
+        out["8b_batched_bench_32x_pp512_tg128_f16"].update({"S_PP_f16_io": h["S_PP"], "S_PP_f16_io_stdev": h["S_PP_stdev"],
+                                                            "S_PP_f16_io_note": "same run with the prompt ubatches' Q handed over / O taken back as f16 (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16)"})
     except Exception as e:
         out["8b_batched_bench_32x_pp512_tg128_f16"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
-def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps):
+def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps, pp_f16=False):
     """llama-batched-bench semantics over the attention path (/root/reference/examples/batched-bench/batched-bench.cpp:150-175): per repetition clear the cache (block alloc /
     free churn), prefill PP tokens for each of B sequences in ubatches of n_batch tokens, then TG decode steps of B tokens, host block manager in the loop, eager launches;
     S_PP = B PP / T_PP, S_TG = B TG / T_TG; 1 warm-up + `reps` repetitions, mean +- stdev"""
@@ -515,12 +518,16 @@ def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps):
     k = [torch.rand((nmax, HK, D), generator=gen, device="cuda") * 2 - 1 for _ in range(L)]
     v = [torch.rand((nmax, HK, D), generator=gen, device="cuda") * 2 - 1 for _ in range(L)]
     out = [torch.empty((nmax, H, D), device="cuda") for _ in range(L)]
+    # pp_f16: the prompt ubatches hand Q over and take O back as f16 (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16, the own runner's boundary; decode steps stay f32)
+    qp = [x.to(torch.float16) for x in q] if pp_f16 else q
+    outp = [torch.empty((nmax, H, D), device="cuda", dtype=torch.float16) for _ in range(L)] if pp_f16 else out
 
-    def run(seq_ids, poss):
+    def run(seq_ids, poss, prompt=False):
         n = len(seq_ids)
         plan = r.plan(seq_ids, poss)
+        qq, oo = (qp, outp) if prompt else (q, out)
         for il in range(L):
-            r.layer(il, plan, q[il][:n], k[il][:n], v[il][:n], out[il][:n])
+            r.layer(il, plan, qq[il][:n], k[il][:n], v[il][:n], oo[il][:n])
     spp, stg = [], []
     for rep in range(reps + 1):
         r.clear()
@@ -529,7 +536,7 @@ def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps):
         toks = [(s, p) for s in range(npl) for p in range(npp)]              # sequence-major like batched-bench's prompt batch
         for i in range(0, len(toks), n_batch):
             chunk = toks[i:i + n_batch]
-            run([s for s, _ in chunk], [p for _, p in chunk])
+            run([s for s, _ in chunk], [p for _, p in chunk], prompt=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(ntg):
@@ -540,11 +547,12 @@ def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps):
             spp.append(npl * npp / (t1 - t0))
             stg.append(npl * ntg / (t2 - t1))
     r.close() if hasattr(r, "close") else None
-    del q, k, v, out
+    del q, k, v, out, qp, outp
     torch.cuda.empty_cache()
     sd = lambda a: round(float(np.std(a, ddof=1)), 1) if len(a) > 1 else 0.0   # noqa: E731
     return {"S_PP": round(float(np.mean(spp)), 1), "S_PP_stdev": sd(spp), "S_TG": round(float(np.mean(stg)), 1), "S_TG_stdev": sd(stg), "unit": "tok/s", "repetitions": reps,
-            "workload": f"batched-bench semantics, B={npl} PP={npp} TG={ntg} n_batch={n_batch}, {kv_type} KV, attention path of all {L} layers, host block manager in the loop, eager launches"}
+            "workload": f"batched-bench semantics, B={npl} PP={npp} TG={ntg} n_batch={n_batch}, {kv_type} KV, attention path of all {L} layers, host block manager in the loop, eager launches"
+                        + (", prompt ubatches with f16 Q in / f16 O out" if pp_f16 else "")}
 
 
 def main(argv=None):

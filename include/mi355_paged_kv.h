@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PKV_ABI_VERSION 1
+#define PKV_ABI_VERSION 2   /* 2 (r03): PKV_ATTN_Q_F16 / PKV_ATTN_OUT_F16, pkv_attn_decode_tiles */
 
 /* values follow enum ggml_type (/ref/ggml/include/ggml.h:351-360) */
 enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8,
@@ -186,6 +186,12 @@ typedef struct pkv_attn_args {
 #define PKV_ATTN_FUSED_COMBINE 2
 /* pkv_attn_prefill: every query sees all seq_lens[s] cells (no causal structure); masking, if any, comes from `mask` */
 #define PKV_ATTN_NONCAUSAL 4
+/* pkv_attn_prefill / pkv_attn_prefill_step: q (out) is f16, strides in elements — half the boundary traffic of a prompt ubatch (32 x 512 tokens of an
+ * 8B layer move 268 MB of f32 Q in and as much O out for 67 MB of KV).  For f16 K the reference rounds Q to f16 anyway (GGML_FP32_TO_FP16 in its
+ * q_to_vec_dot, /ref/ggml/src/ggml-cpu/ggml-cpu.c:12343): an f16 Q changes nothing; an f16 O is the f32 result rounded once (relative 2^-11).  The
+ * ggml-backend plugin keeps the f32 contract of ggml_flash_attn_ext; the own runner uses these. */
+#define PKV_ATTN_Q_F16 8
+#define PKV_ATTN_OUT_F16 16
 
 size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq_len, int block_size);
 /* what pkv_attn_prefill alone can use (its split-KV mode for small launches over a long past; 0 above 2048 tokens).  A

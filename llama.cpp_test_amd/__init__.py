@@ -34,6 +34,9 @@ PACKED = 0x100          # PKV_TYPE_PACKED: K-quant rows in the plane layout (csr
 ATTN_NO_COMBINE = 1
 ATTN_FUSED_COMBINE = 2
 ATTN_NONCAUSAL = 4
+ABI_VERSION = 2      # == PKV_ABI_VERSION of include/mi355_paged_kv.h
+ATTN_Q_F16 = 8      # attn_prefill / attn_prefill_step: q is f16 (set from q.dtype)
+ATTN_OUT_F16 = 16   # ... out is f16 (out_dtype=torch.float16 or an f16 `out`)
 
 
 class PkvError(RuntimeError):
@@ -120,8 +123,8 @@ def lib() -> C.CDLL:
         for f in ("pkv_cache_free", "pkv_cache_clear", "pkv_cache_seq_cp", "pkv_cache_seq_keep", "pkv_cache_seq_add",
                   "pkv_cache_seq_div", "pkv_cache_defrag", "pkv_toy_bm_free", "pkv_toy_bm_release", "pkv_toy_kvm_free"):
             getattr(L, f).restype = None
-        if L.pkv_abi_version() != 1:
-            raise RuntimeError("libmi355_paged_kv.so ABI version mismatch")
+        if L.pkv_abi_version() != ABI_VERSION:   # (a stale build would read an f16 q as f32: refuse it here, not in a kernel)
+            raise RuntimeError(f"libmi355_paged_kv.so is ABI version {L.pkv_abi_version()}, this binding needs {ABI_VERSION}: rebuild (make -C llama.cpp_test_amd/csrc)")
         _lib = L
     return _lib
 
@@ -222,11 +225,15 @@ def attn_prefill_workspace_bytes(n_tok: int, n_head: int, head_dim: int) -> int:
 
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
-          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None, stamps=None, slots=None):
+          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None, stamps=None, slots=None, out_dtype=None):
     import torch
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
-    out = torch.empty((n_tok, n_head, D), dtype=torch.float32, device=q.device) if out is None else out
+    out = torch.empty((n_tok, n_head, D), dtype=out_dtype or torch.float32, device=q.device) if out is None else out
+    if q.dtype == torch.float16:
+        flags |= ATTN_Q_F16
+    if out.dtype == torch.float16:
+        flags |= ATTN_OUT_F16
     # decode: per-block partials of the split-KV kernel; prefill: scratch of its split-KV mode (small launches only)
     need = (attn_workspace_bytes(n_tok, n_head, D, max_seq_len, block_size) if q_start is None
             else attn_prefill_workspace_bytes(n_tok, n_head, D))

@@ -382,7 +382,7 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int off) 
 #define PKV_OCC 1
 #endif
 template <int KT, int VT, int D, int G, bool SOFTCAP, bool SLOTPOS, bool FUSED, bool PREP, int STAMP = 0, int TPWQ = 16, bool MULTI = false>
-__global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn_decode_kernel(const int32_t * p_table, const int32_t * p_lens, int p_max_blocks, int p_bs_shift,
+__global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn_decode_kernel(const int32_t * __restrict__ p_table, const int32_t * __restrict__ p_lens, int p_max_blocks, int p_bs_shift,
                                                                                                    const DecodeArgs a) {
     // the four leading arguments (= a.block_table, a.seq_lens, a.max_blocks, a.bs_shift) are what the FIRST dependent loads need: as explicit kernel
     // arguments they are preloaded into SGPRs at dispatch (-mllvm -amdgpu-kernarg-preload-count, csrc/Makefile), one scalar round trip less on the
@@ -528,8 +528,8 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
             }
         }
     };
-    int phys = phys0, tile = tile0;
-    int n_valid = min(WG_TOK, seq_len - base0);                 // >= 1
+    int phys = phys0, tile = tile0;                             // (scalar state of the tile loop: kept in SGPRs by construction — a table entry fetched with a
+    int n_valid = min(WG_TOK, seq_len - base0);                 //  VECTOR load inside the loop made hipcc wait for the whole K prefetch right behind it; >= 1)
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_ks, rs_vs;
     if constexpr (KT != PKV_TYPE_F16) rs_ks = mk_rs_ks(phys, (tile & bs_mask) * WG_TOK, n_valid);
     if constexpr (VT != PKV_TYPE_F16) rs_vs = mk_rs_vs(phys, (tile & bs_mask) * WG_TOK, n_valid);
@@ -591,6 +591,10 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
 
     if (MULTI || active1) {   // ======== the wave's 16 tokens of every tile ========
     for (int it = 0; it < n_it; ++it) {
+    if constexpr (MULTI) {
+        tile    = __builtin_amdgcn_readfirstlane(tile0 + it);
+        n_valid = __builtin_amdgcn_readfirstlane(min(WG_TOK, seq_len - tile * WG_TOK));
+    }
     const int  base    = tile * WG_TOK;
     const bool last_it = !MULTI || it + 1 == n_it;
     const bool owner   = is_last && last_it && wv == (n_valid - 1) / TPW;   // the new token's row is among this wave's 16 tokens of this tile
@@ -630,12 +634,15 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
         // the NEXT tile's K rows, behind this tile's V rows and ahead of this tile's softmax + PV.  Branch-free: past the workgroup's last tile the
         // descriptor has no records (every load returns 0 without touching memory) — a load behind a branch would make hipcc drain the queue at the join
         __builtin_amdgcn_sched_barrier(0);
+        // the table entry of the tile after next FIRST: if hipcc makes it a vector load (it does behind the loop's LDS fence), it must be OLDER than the K
+        // prefetch — the wait for it at the end of the iteration then leaves the K rows in flight
+        phys_nn = trow[__builtin_amdgcn_readfirstlane(min(tile0 + it + 2, tile_cap) >> p_bs_shift)];
+        __builtin_amdgcn_sched_barrier(0);
         n_valid_n = last_it ? 0 : min(WG_TOK, seq_len - base - WG_TOK);
         const int boff_n = ((tile + 1) & bs_mask) * WG_TOK;
         [[maybe_unused]] __amdgpu_buffer_rsrc_t rks_n;
         if constexpr (KT != PKV_TYPE_F16) rks_n = mk_rs_ks(phys_n, boff_n, n_valid_n);
         issue_k(mk_rs_k(phys_n, boff_n, n_valid_n), rks_n);
-        phys_nn = trow[min(tile + 2, tile_cap) >> p_bs_shift];   // scalar load: the table entry of the tile after next
         __builtin_amdgcn_sched_barrier(0);
     }
     reduce_scatter<NV, K_LPR>(x, lane);
@@ -800,10 +807,8 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
     }
     if constexpr (MULTI) {              // on to the next tile (scalar state only)
         if (!last_it) {
-            tile += 1;
-            phys = phys_n; phys_n = phys_nn;
-            n_valid = n_valid_n;
-            rs_v = mk_rs_v(phys, (tile & bs_mask) * WG_TOK, n_valid);
+            phys = __builtin_amdgcn_readfirstlane(phys_n); phys_n = __builtin_amdgcn_readfirstlane(phys_nn);
+            rs_v = mk_rs_v(phys, ((tile + 1) & bs_mask) * WG_TOK, n_valid_n);
         }
     }
     }   // tiles
@@ -1264,6 +1269,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     PKV_REQUIRE(a.max_seq_len > 0 && a.max_seq_len <= a.max_blocks * a.block_size, "pkv_attn_decode: max_seq_len out of range");
     PKV_REQUIRE((a.q_stride_head % 4) == 0 && (a.q_stride_tok % 4) == 0 && ((uintptr_t) a.q % 16) == 0, "pkv_attn_decode: q must be 16-byte aligned");
     PKV_REQUIRE(a.slot_pos == nullptr || a.q_pos != nullptr, "pkv_attn_decode: slot_pos needs q_pos");
+    if (a.flags & (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16)) { set_error("pkv_attn_decode: f16 q / out are a pkv_attn_prefill mode (a decode step moves 2 rows per head)"); return PKV_ERR_UNSUPPORTED; }
     if (a.max_bias != 0.0f || (a.flags & PKV_ATTN_NONCAUSAL) || (a.mask && (a.slot_pos || step))) {
         set_error("pkv_attn_decode: ALiBi / non-causal go through pkv_attn_prefill; a mask excludes slot_pos and the fused step");
         return PKV_ERR_UNSUPPORTED;

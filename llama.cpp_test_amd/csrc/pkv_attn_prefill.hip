@@ -65,6 +65,7 @@ struct PrefillArgs {
     int   mask_align8;            // mask rows start on 8-byte boundaries (base and row stride)
     const float * rope_cache;     // pkv_attn_prefill_step: (cos, sin) rows of the ubatch's tokens [n_tok][D/2][2] (pkv_rope_cache), NORM pairs: Q arrives
                                   // un-rotated and is rotated on its way into the QK^T operand; NULL = q is used as given
+    int   q_f16, out_f16;         // PKV_ATTN_Q_F16 / PKV_ATTN_OUT_F16: q / out are f16 (strides in elements): half the boundary traffic of a prompt ubatch
     float scale, softcap;
     const _Float16 * mask;        // optional additive mask f16 [>= n_tok rows][mask_stride], row = token index, col = kv cell
     int64_t mask_stride;
@@ -540,21 +541,30 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
     {
         char * strip = smem + (QFREE ? IMG : 0) + g * (QT * D * 2);   // [32 rows][D halfs], 16-byte chunk c of row q at c ^ (q & 15); one block at a time
         static_assert(G * QT * D * 2 <= 4 * IMG, "Q strips must fit the tile images");
-        const long long qsb = (long long) a.q_stride_tok * 4;
+        const int esz = a.q_f16 ? 2 : 4;                              // bytes per element of q
+        const long long qsb = (long long) a.q_stride_tok * esz;
         constexpr int LPR = D / 4, RPI = 64 / LPR, NQ = QT / RPI;   // lanes per row, rows per instruction, instructions
-        const int lr = lane / LPR, lc = lane % LPR;                   // row inside the instruction's group, float4 column
+        const int lr = lane / LPR, lc = lane % LPR;                   // row inside the instruction's group, 4-element column
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const rsrc_t rq = mk_rsrc(a.q + (size_t) (tok0 + tile * QTW + qb * QT) * a.q_stride_tok + (size_t) head * a.q_stride_head,
-                                      (long long) (n_rows - qb * QT - 1) * qsb + D * 4);   // (a block past the end of the tile: no bytes, reads as 0)
+            const rsrc_t rq = mk_rsrc(reinterpret_cast<const char *>(a.q) + ((size_t) (tok0 + tile * QTW + qb * QT) * a.q_stride_tok + (size_t) head * a.q_stride_head) * esz,
+                                      (long long) (n_rows - qb * QT - 1) * qsb + D * esz);   // (a block past the end of the tile: no bytes, reads as 0)
             // fused RoPE(Q): the rows' (cos, sin) pairs, same shape as the rows themselves at half the bytes (float4 = the two pairs of the lane's 4 elements)
             const rsrc_t rc = mk_rsrc(a.rope_cache ? a.rope_cache + (size_t) (tok0 + tile * QTW + qb * QT) * D : nullptr,
                                       a.rope_cache ? (long long) (n_rows - qb * QT) * D * 4 : 0);
 #pragma unroll
             for (int b = 0; b < NQ; b += 8) {
                 u4_t x[8], cs[8];
+                if (a.q_f16) {   // (workgroup-uniform) 8 bytes = the lane's 4 halfs
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int) (((b + i) * RPI + lr) * qsb) + lc * 16, 0, 0);
+                    for (int i = 0; i < 8; ++i) {
+                        const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(rq, (int) (((b + i) * RPI + lr) * qsb) + lc * 8, 0, 0);
+                        x[i].x = v.x; x[i].y = v.y; x[i].z = 0; x[i].w = 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (int) (((b + i) * RPI + lr) * qsb) + lc * 16, 0, 0);
+                }
                 if (a.rope_cache) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) cs[i] = __builtin_amdgcn_raw_buffer_load_b128(rc, (((b + i) * RPI + lr) * D + lc * 4) * 4, 0, 0);
@@ -562,7 +572,13 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = (b + i) * RPI + lr;
-                    float x0 = __uint_as_float(x[i].x), x1 = __uint_as_float(x[i].y), x2 = __uint_as_float(x[i].z), x3 = __uint_as_float(x[i].w);
+                    float x0, x1, x2, x3;
+                    if (a.q_f16) {
+                        const h2_t lo = as_h2(x[i].x), hi = as_h2(x[i].y);
+                        x0 = (float) lo[0]; x1 = (float) lo[1]; x2 = (float) hi[0]; x3 = (float) hi[1];
+                    } else {
+                        x0 = __uint_as_float(x[i].x); x1 = __uint_as_float(x[i].y); x2 = __uint_as_float(x[i].z); x3 = __uint_as_float(x[i].w);
+                    }
                     if (a.rope_cache) {   // the rotation of kv_store_kernel's Q plane (rot0 / rot1: every product and the sum rounded on its own)
                         const float c0 = __uint_as_float(cs[i].x), s0 = __uint_as_float(cs[i].y), c1 = __uint_as_float(cs[i].z), s1 = __uint_as_float(cs[i].w);
                         const float y0 = rot0(x0, x1, c0, s0), y1 = rot1(x0, x1, c0, s0), y2 = rot0(x2, x3, c1, s1), y3 = rot1(x2, x3, c1, s1);
@@ -775,7 +791,9 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
         static_assert(32 * DH * 4 * G <= 4 * IMG, "per-wave output strips must fit the tile images");
         float * strip = reinterpret_cast<float *>(smem) + g * 32 * DH;
         const bool  partial = a.n_split > 1;
-        const long long rowb = (long long) a.n_head * (partial ? a.n_split : 1) * D * 4;   // bytes between two tokens' rows
+        const bool  o16 = a.out_f16 && !partial;                // the tile's result leaves as f16 rows (the split-KV partials stay f32; their merge converts)
+        const int   osz = o16 ? 2 : 4;
+        const long long rowb = (long long) a.n_head * (partial ? a.n_split : 1) * D * osz;   // bytes between two tokens' rows
         __syncthreads();                                       // every wave is done reading the last K/V tile
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -791,7 +809,8 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
                 ml[1] = l_all;
             }
             const size_t th0 = (size_t) (tok0 + tile * QTW + qb * QT) * a.n_head + head;   // (token, head) row of the block's first query
-            const rsrc_t ro = mk_rsrc(partial ? a.part_o + (th0 * a.n_split + sp) * D : a.out + th0 * D, (n_rows - qb * QT - 1) * rowb + D * 4);
+            const rsrc_t ro = mk_rsrc(partial ? reinterpret_cast<char *>(a.part_o + (th0 * a.n_split + sp) * D) : reinterpret_cast<char *>(a.out) + th0 * D * osz,
+                                      (n_rows - qb * QT - 1) * rowb + D * osz);
 #pragma unroll
             for (int pass = 0; pass < D / DH; ++pass) {
 #pragma unroll
@@ -816,8 +835,13 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int e = (b + i) * 64 + lane, row = e / CPRW, c = e % CPRW;
-                        u4_t w; w.x = __float_as_uint(v[i].x); w.y = __float_as_uint(v[i].y); w.z = __float_as_uint(v[i].z); w.w = __float_as_uint(v[i].w);
-                        __builtin_amdgcn_raw_buffer_store_b128(w, ro, (int) (row * rowb) + (pass * DH + c * 4) * 4, 0, 0);
+                        if (o16) {
+                            const _Float16 hv[4] = {(_Float16) v[i].x, (_Float16) v[i].y, (_Float16) v[i].z, (_Float16) v[i].w};
+                            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u2_t *>(hv), ro, (int) (row * rowb) + (pass * DH + c * 4) * 2, 0, 0);
+                        } else {
+                            u4_t w; w.x = __float_as_uint(v[i].x); w.y = __float_as_uint(v[i].y); w.z = __float_as_uint(v[i].z); w.w = __float_as_uint(v[i].w);
+                            __builtin_amdgcn_raw_buffer_store_b128(w, ro, (int) (row * rowb) + (pass * DH + c * 4) * 4, 0, 0);
+                        }
                     }
                 }
                 if (pass + 1 < D / DH || qb + 1 < QB) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -854,6 +878,10 @@ __global__ void __launch_bounds__(D / 4) prefill_combine_kernel(const PrefillArg
         L = fmaf(ml[2 * j + 1], w, L);
     }
     const float inv = 1.0f / L;   // every cell masked -> 0 * inf = NaN, as the single-share kernel's 1 / 0
+    if (a.out_f16) {
+        const _Float16 hv[4] = {(_Float16) (acc.x * inv), (_Float16) (acc.y * inv), (_Float16) (acc.z * inv), (_Float16) (acc.w * inv)};
+        *reinterpret_cast<uint2 *>(reinterpret_cast<_Float16 *>(a.out) + th * D + c * 4) = *reinterpret_cast<const uint2 *>(hv);
+    } else
     *reinterpret_cast<float4 *>(a.out + th * D + c * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
@@ -937,6 +965,7 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * r
     PKV_REQUIRE(a.max_seq_len > 0 && a.max_seq_len <= a.max_blocks * a.block_size, "pkv_attn_prefill: max_seq_len out of range");
     PKV_REQUIRE((a.q_stride_head % 4) == 0 && (a.q_stride_tok % 4) == 0 && ((uintptr_t) a.q % 16) == 0 && ((uintptr_t) a.out % 16) == 0,
                 "pkv_attn_prefill: q/out must be 16-byte aligned");
+    PKV_REQUIRE(!(a.flags & (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16)) || !g_prefill_stamps, "pkv_attn_prefill: the stamp build takes f32 q / out");
     if (a.slot_pos) { set_error("pkv_attn_prefill: irregular sequences (slot_pos) are not supported yet; defrag first"); return PKV_ERR_UNSUPPORTED; }
     PrefillArgs pa;
     pa.q = a.q; pa.q_stride_tok = a.q_stride_tok; pa.q_stride_head = a.q_stride_head; pa.out = a.out;
@@ -952,6 +981,7 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * r
     pa.rope_cache = rope_cache;
     PKV_REQUIRE(((uintptr_t) rope_cache % 16) == 0, "pkv_attn_prefill_step: rope_cache must be 16-byte aligned");
     pa.causal = (a.flags & PKV_ATTN_NONCAUSAL) ? 0 : 1;
+    pa.q_f16 = (a.flags & PKV_ATTN_Q_F16) ? 1 : 0; pa.out_f16 = (a.flags & PKV_ATTN_OUT_F16) ? 1 : 0;
     PKV_REQUIRE(a.max_bias == 0.0f || a.mask, "pkv_attn_prefill: max_bias (ALiBi) needs a mask");
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
     const int G = a.n_head / a.n_head_kv;

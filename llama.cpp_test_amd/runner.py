@@ -113,6 +113,8 @@ class AttnPathRunner:
 
     def layer(self, il: int, plan, q, k_cur, v_cur, out=None):
         """device half, one layer: q f32 [n_tok][n_head][D], k_cur/v_cur f32 [n_tok][n_head_kv][D], all un-rotated.
+        A prompt ubatch through the fused step may hand q over as f16 and take `out` back as f16 (PKV_ATTN_Q_F16 / PKV_ATTN_OUT_F16: half the
+        boundary traffic; for f16 K the reference rounds Q to f16 itself).
         Decode ubatches (one token per sequence) and fused prefill ubatches (NORM rope pairs) leave q untouched; prefill ubatches with
         NEOX pairs (fused_prefill False) rotate it in place."""
         c = self.cache
@@ -124,6 +126,8 @@ class AttnPathRunner:
         if self.fused_prefill and plan["rope_cache"] is not None:   # q stays un-rotated: RoPE(Q) happens in the attention kernel's Q fetch
             return attn_prefill_step(q, k_cur, v_cur, plan["pos"], self.rope, c.k_pool(il), c.v_pool(il), plan["block_table"], plan["seq_lens"],
                                      plan["q_start"], plan["slot_block"], plan["slot_off"], rope_cache=plan["rope_cache"], max_q_per_seq=plan["max_q"], **kw)
+        if q.dtype != self.torch.float32:
+            raise PkvError(-4, "f16 q needs the fused prefill step (NORM rope pairs): pkv_qkv_prepare rotates an f32 q in place")
         qkv_prepare(q, k_cur, v_cur, c.k_pool(il), c.v_pool(il), type_k=self.tk, type_v=self.tv, slot_block=plan["slot_block"],
                     slot_off=plan["slot_off"], block_size=self.BS, pos=plan["pos"], rope=self.rope)
         return attn_prefill(q, c.k_pool(il), c.v_pool(il), plan["block_table"], plan["seq_lens"], plan["q_start"],

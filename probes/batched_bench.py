@@ -11,7 +11,8 @@ from llama_cpp_test_amd.runner import AttnPathRunner
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--npl", type=int, default=32); ap.add_argument("--npp", type=int, default=512); ap.add_argument("--ntg", type=int, default=128)
-ap.add_argument("--n-batch", type=int, default=2048); ap.add_argument("--kv-type", default="f16"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--graph", action="store_true", help="AttnPathRunner.decode_captured: one cached hipGraph per ubatch shape instead of per-layer launches (measured: no faster, the GPU is the bound)")
+ap.add_argument("--n-batch", type=int, default=2048); ap.add_argument("--kv-type", default="f16"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--pp-f16", action="store_true", help="prompt ubatches hand Q over / take O back as f16 (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16)")
+ap.add_argument("--graph", action="store_true", help="AttnPathRunner.decode_captured: one cached hipGraph per ubatch shape instead of per-layer launches (measured: no faster, the GPU is the bound)")
 a = ap.parse_args()
 L, H, HK, D, BS = 32, 32, 8, 128, 128
 t = pkv.TYPE_BY_NAME[a.kv_type]
@@ -24,15 +25,18 @@ q = [torch.rand((nmax, H, D), generator=gen, device="cuda") * 2 - 1 for _ in ran
 k = [torch.rand((nmax, HK, D), generator=gen, device="cuda") * 2 - 1 for _ in range(L)]
 v = [torch.rand((nmax, HK, D), generator=gen, device="cuda") * 2 - 1 for _ in range(L)]
 out = [torch.empty((nmax, H, D), device="cuda") for _ in range(L)]
+qp = [x.to(torch.float16) for x in q] if a.pp_f16 else q
+outp = [torch.empty((nmax, H, D), device="cuda", dtype=torch.float16) for _ in range(L)] if a.pp_f16 else out
 
-def run(seq_ids, poss):
+def run(seq_ids, poss, prompt=False):
     n = len(seq_ids)
+    qq, oo = (qp, outp) if prompt else (q, out)
     if a.graph:
-        r.decode_captured(seq_ids, poss, [x[:n] for x in q], [x[:n] for x in k], [x[:n] for x in v], [x[:n] for x in out])
+        r.decode_captured(seq_ids, poss, [x[:n] for x in qq], [x[:n] for x in k], [x[:n] for x in v], [x[:n] for x in oo])
         return
     plan = r.plan(seq_ids, poss)
     for il in range(L):
-        r.layer(il, plan, q[il][:n], k[il][:n], v[il][:n], out[il][:n])
+        r.layer(il, plan, qq[il][:n], k[il][:n], v[il][:n], oo[il][:n])
 
 res = []
 for rep in range(a.reps + 1):
@@ -41,7 +45,7 @@ for rep in range(a.reps + 1):
     toks = [(s, p) for s in range(a.npl) for p in range(a.npp)]          # sequence-major like batched-bench's prompt batch
     for i in range(0, len(toks), a.n_batch):
         chunk = toks[i:i + a.n_batch]
-        run([s for s, _ in chunk], [p for _, p in chunk])
+        run([s for s, _ in chunk], [p for _, p in chunk], prompt=True)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     for i in range(a.ntg):
         run(list(range(a.npl)), [a.npp + i] * a.npl)
@@ -49,5 +53,5 @@ for rep in range(a.reps + 1):
     if rep:
         res.append((t1 - t0, t2 - t1))
 tpp, ttg = np.median([x[0] for x in res]), np.median([x[1] for x in res])
-print(f"{a.kv_type} B={a.npl} PP={a.npp} TG={a.ntg} n_batch={a.n_batch}: T_PP {tpp*1e3:.1f} ms  S_PP {a.npl*a.npp/tpp:.0f} t/s | "
+print(f"{a.kv_type}{' (prompt Q / O f16)' if a.pp_f16 else ''} B={a.npl} PP={a.npp} TG={a.ntg} n_batch={a.n_batch}: T_PP {tpp*1e3:.1f} ms  S_PP {a.npl*a.npp/tpp:.0f} t/s | "
       f"T_TG {ttg*1e3:.1f} ms  S_TG {a.npl*a.ntg/ttg:.0f} t/s  ({ttg/a.ntg*1e3:.3f} ms/step, {'one cached hipGraph per ubatch shape' if a.graph else 'eager launches'}, host block manager in the loop)")

@@ -39,6 +39,7 @@ SHAPES = [  # name, [(type, M)], K, norm, residual, silu
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", nargs="*", default=[]); ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--hot", type=int, default=0, help="cycle through only this many weight buffers (1-2: the weights stay in the 256 MiB Infinity Cache): what a product would take if its weights had been prefetched")
     ap.add_argument("--packed", action="store_true", help="second arm: the same library on plane-layout rows (type | PKV_TYPE_PACKED; random bytes, timing only)")
     a = ap.parse_args()
     mods = {"this tree": load_pkg("pkv_a", None)}
@@ -56,6 +57,7 @@ def main():
     for name, mats, K, norm, resid, silu in SHAPES:
         nbytes = sum(M * (K // 256) * rs[t] for t, M in mats)
         n_buf = max(2, min(32, int(600e6 // nbytes) + 1))
+        if a.hot: n_buf = a.hot
         n_launch = 32 if nbytes < 200e6 else 8
         ws = [[torch.randint(0, 256, (M * (K // 256) * rs[t],), dtype=torch.uint8, device=dev, generator=gen) for t, M in mats] for _ in range(n_buf)]
         x = torch.randn(K, device=dev, generator=gen)

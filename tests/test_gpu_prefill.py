@@ -2,9 +2,9 @@
 
 Bar: f16 KV — NMSE <= 5e-4 vs the reference semantics (tests/test-backend-ops.cpp:3216); max-abs distance to the
 reference no larger than the reference's own distance to exact (f64) arithmetic + 3e-4 (the reference accumulates f16-V
-in f16: on short rows with O(1) outputs its own error reaches 1e-3), and at least as close to exact as the reference.  Quantized KV: the kernel keeps Q in f16 where the
-reference quantizes Q to q8_0 (ggml-cpu.c:12343), so it is compared with NMSE <= 5e-4 against the reference semantics
-and max-abs <= 1e-3 against the f64 result (K/V are dequantized to f16 for the MFMA operands)."""
+in f16: on short rows with O(1) outputs its own error reaches 1e-3), and at least as close to exact as the reference.  Quantized K: the Q rows take the
+reference's q8_0 rounding (ggml-cpu.c:12343, r03), so the output is held to max-abs <= 1e-3 and NMSE <= 5e-4 against the reference semantics, and is never further
+from the f64 result than the reference is by more than the f16 rounding of the MFMA operands."""
 import numpy as np
 import pytest
 import torch
@@ -255,3 +255,54 @@ def test_prefill_step_equals_prepare_plus_prefill(pkv, O, tk, tv, D, nh, nkv):
         assert torch.isfinite(o2).all() and torch.equal(o1, o2), n_dims
     with pytest.raises(pkv.PkvError):                                  # NEOX pairs are not fused
         pkv.attn_prefill_step(q2, dev(k), dev(v), dev(pos), pkv.rope_params(n_dims=D, mode=2), pools[1][0], pools[1][1], dev(bt), dev(sl), dev(q_start), dev(sb), dev(so), rope_cache=cache, **kw)
+
+
+@pytest.mark.parametrize("tk", [1, 8])
+@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (64, 8, 2), (128, 8, 1)])
+def test_prefill_f16_q_in_f16_out(pkv, O, tk, D, nh, nkv):
+    """PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16 (the own runner's boundary for prompt ubatches): an f16 Q is what the f32 call makes of the same values
+    (for f16 K the reference rounds Q to f16 itself) — the f32 output is bit-identical when Q is f16-representable; the f16 output is that result
+    rounded once.  Also through the split-KV mode (a small ubatch over a long past) and the fused step (RoPE(Q) in the Q fetch: the rotation
+    starts from the f16 values)."""
+    rng = np.random.default_rng(5 + tk + D + nkv)
+    for lens, n_qs in (([300, 64, 513, 1], [300, 64, 130, 1]), ([3000], [96])):
+        kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
+        q_start = np.concatenate([[0], np.cumsum(n_qs)]).astype(np.int32)
+        qh = rng.uniform(-1, 1, (int(q_start[-1]), nh, D)).astype(np.float16)
+        kw = dict(n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()), max_q_per_seq=max(n_qs))
+        args = (dev(kp), dev(vp), dev(bt), dev(sl), dev(q_start))
+        base = pkv.attn_prefill(dev(qh.astype(np.float32)), *args, **kw).cpu().numpy()                      # f32 in, f32 out
+        a = pkv.attn_prefill(dev(qh), *args, **kw)                                                          # f16 in, f32 out
+        b = pkv.attn_prefill(dev(qh), *args, out_dtype=torch.float16, **kw)                                 # f16 in, f16 out
+        c = pkv.attn_prefill(dev(qh.astype(np.float32)), *args, out_dtype=torch.float16, **kw)              # f32 in, f16 out
+        torch.cuda.synchronize()
+        assert a.dtype == torch.float32 and b.dtype == torch.float16 and c.dtype == torch.float16
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), base.view(np.uint32))
+        want = base.astype(np.float16)
+        assert np.array_equal(b.cpu().numpy().view(np.uint16), want.view(np.uint16))
+        assert np.array_equal(c.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    # the fused prefill step on f16 q: same pools, output = the f32 call on the same (f16-representable) q
+    lens = [200, 130]
+    kp, vp, bt, sl = make_paged_case(O, rng, lens=lens, D=D, n_head=nh, n_head_kv=nkv, type_k=tk, type_v=tk)
+    q_start = np.array([0, 200, 330], np.int32)
+    n_tok = 330
+    qh = rng.uniform(-1, 1, (n_tok, nh, D)).astype(np.float16)
+    kc = rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32)
+    vc = rng.uniform(-1, 1, (n_tok, nkv, D)).astype(np.float32)
+    pos = np.concatenate([np.arange(n) for n in lens]).astype(np.int32)
+    sb = np.concatenate([bt[s][np.arange(n) // 128] for s, n in enumerate(lens)]).astype(np.int32)
+    so = (pos % 128).astype(np.int32)
+    rope = pkv.rope_params(n_dims=D, mode=0, freq_base=10000.0)
+    res = []
+    for qq, od in ((qh.astype(np.float32), None), (qh, torch.float16)):
+        dkp, dvp, dpos = dev(kp), dev(vp), dev(pos)
+        cache = pkv.rope_cache(dpos, rope, D)
+        o = pkv.attn_prefill_step(dev(qq), dev(kc), dev(vc), dpos, rope, dkp, dvp, dev(bt), dev(sl), dev(q_start), dev(sb), dev(so), rope_cache=cache,
+                                  n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=D ** -0.5, max_seq_len=int(sl.max()), max_q_per_seq=200, out_dtype=od)
+        torch.cuda.synchronize()
+        res.append((o.cpu().numpy(), dkp.cpu().numpy(), dvp.cpu().numpy()))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.array_equal(res[1][0].view(np.uint16), res[0][0].astype(np.float16).view(np.uint16))
+    # and the decode path says no
+    with pytest.raises(pkv.PkvError):
+        pkv.attn_decode(dev(qh[:2]), dev(kp), dev(vp), dev(bt), dev(sl), n_head_kv=nkv, type_k=tk, type_v=tk, block_size=128, scale=1.0, max_seq_len=int(sl.max()))
