@@ -415,6 +415,222 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm2_kernel(const GemmArgs a, c
     }
 }
 
+// ======================================================================================================================================================
+// Third form (gemm3_kernel): the second form for the shapes whose K-step is too short to hide a memory round trip.  With 64 x 128 / 128 x 128 tiles a workgroup
+// multiplies for 250-500 cycles per 64-deep step and then stands at the barrier until the next step's tiles — requested at the top of the same step — have
+// landed: one memory latency per step, ~0.9 us (4096 x 4096 x 512 at 0.12 of the MFMA peak).  Here every global -> LDS transfer is requested TWO steps before
+// its first use, and nothing in the loop is a VGPR load (hipcc waits vmcnt(0) for those whenever LDS-DMA is in flight: it cannot count the two kinds together):
+//   * activations (f16 scratch) and f16 weights: LDS-DMA into a ring of THREE tile images, requested at step k for step k + 2;
+//   * packed q4_K weights (pkv_wlayout.h planes): the step's RAW bytes — 16 B of qa, 16 B of qb and the block's 16-B header per row — go by LDS-DMA into a ring
+//     of three raw buffers, requested at step k for step k + 3; at step k + 2 they are read back from LDS, dequantized (packed f16 arithmetic, as the second
+//     form) and written into one of TWO f16 weight images for step k + 3;
+//   * one barrier per step; the wait in front of it leaves exactly the transfers requested in this step in flight (s_waitcnt vmcnt(N), memory returns in order).
+template <int T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) gemm3_kernel(const GemmArgs a, const _Float16 * __restrict__ xh) {
+    constexpr int NT = 64 * WM * WN, NWAVE = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr bool ADMA = (T & ~PKV_TYPE_PACKED) == PKV_TYPE_F16;
+    static_assert(ADMA || T == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED), "third form: f16 and packed q4_K weights");
+    static_assert(TM >= 1 && TN >= 1 && BM % 64 == 0 && BN % (8 * NWAVE) == 0 && (!ADMA || BM % (8 * NWAVE) == 0) && 2 * BM <= NT, "tile shape");   // (2 * BM <= NT: every row-half has a thread)
+    constexpr int AIMG = BM * ROWB2, BIMG = BN * ROWB2, NA = ADMA ? 3 : 2;           // f16 tile images: weights (ring of 3 by DMA, or 2 by conversion), activations (3)
+    constexpr int RAWB = ADMA ? 0 : 3 * BM * 16;                                      // one raw buffer: planes qa | qb | header, 16 B per row each
+    constexpr int OFF_B = NA * AIMG, OFF_R = OFF_B + 3 * BIMG;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_R + 3 * RAWB];             // ONE LDS object (a second one can make hipcc wait vmcnt(0) before every ds_read)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave % WM, wn = wave / WM;
+    const int r = lane & 31, h = lane >> 5;
+    int mi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX; ++i) if (i < a.n && (int) blockIdx.y >= a.tile_end[i - 1]) mi = i;
+    const int64_t aM = a.M[mi];
+    const unsigned char * const aw = a.w[mi];
+    float * const ay = a.y[mi];
+    const int64_t m0 = (int64_t) ((int) blockIdx.y - (mi ? a.tile_end[mi - 1] : 0)) * BM, n0 = (int64_t) blockIdx.x * BN;
+    const int nsteps = (int) (a.K / BK);
+
+    // ---- LDS-DMA roles (as the second form): instruction i of a wave fills 8 rows of a tile image, lane l -> row + l / 8, chunk position l % 8 = source chunk (l % 8) ^ swz(row)
+    constexpr int NIB = BN / 8 / NWAVE, NIA = ADMA ? BM / 8 / NWAVE : 0;
+    const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(xh) + n0 * a.K, 0, (int) (min((int64_t) BN, a.N - n0) * a.K * 2), 0x00020000);
+    int vo_b[NIB];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+        const int row = (wave * NIB + i) * 8 + (lane >> 3);
+        vo_b[i] = (int) (min((int64_t) row, a.N - 1 - n0) * a.K * 2) + (((lane & 7) ^ swz(row)) << 4);
+    }
+    const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(aw) + m0 * a.row_bytes, 0, (int) (min((int64_t) BM, aM - m0) * a.row_bytes), 0x00020000);
+    [[maybe_unused]] int vo_a[ADMA ? NIA : 1];
+    if constexpr (ADMA) {
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int row = (wave * NIA + i) * 8 + (lane >> 3);
+            vo_a[i] = (int) (min((int64_t) row, aM - 1 - m0) * a.row_bytes) + (((lane & 7) ^ swz(row)) << 4);
+        }
+    }
+    // raw q4_K granules of a step: instruction j (0 .. 3 BM / 64) = plane j / (BM / 64), rows 64 (j % (BM / 64)) + lane.  Wave w issues instructions w, w + NWAVE, ...
+    constexpr int NRI = ADMA ? 0 : 3 * BM / 64, NRW = (NRI + NWAVE - 1) / NWAVE;     // per step, per wave (the last round may be short)
+    const int gpr = (int) (a.K >> 6);
+    [[maybe_unused]] int vo_r[NRW > 0 ? NRW : 1];
+    if constexpr (!ADMA) {
+#pragma unroll
+        for (int i = 0; i < NRW; ++i) {
+            const int j = wave + i * NWAVE, plane = j / (BM / 64), row = 64 * (j % (BM / 64)) + lane;
+            vo_r[i] = (int) (min((int64_t) row, aM - 1 - m0) * a.row_bytes) + plane * 16 * gpr;          // (+ 16 g for qa / qb, 16 (g >> 2) for the header: the step's soffset)
+        }
+    }
+    const int n_raw = ADMA ? 0 : (NRI - wave + NWAVE - 1) / NWAVE;                     // raw instructions this wave issues per step (wave-uniform): NRW or NRW - 1
+    auto dma_tiles = [&](int step, int slot) {            // B (and f16 A) of `step` into image ring slot `slot`
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int so = step * (BK * 2);
+        if constexpr (ADMA) {
+#pragma unroll
+            for (int i = 0; i < NIA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *) (smem + slot * AIMG + (wave * NIA + i) * 1024), 16, vo_a[i], so, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void *) (smem + OFF_B + slot * BIMG + (wave * NIB + i) * 1024), 16, vo_b[i], so, 0, 0);
+#endif
+    };
+    auto dma_raw = [&](int step, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (!ADMA) {
+#pragma unroll
+            for (int i = 0; i < NRW; ++i) {
+                const int j = wave + i * NWAVE;            // wave-uniform
+                if (j < NRI) {
+                    const int plane = j / (BM / 64);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *) (smem + OFF_R + slot * RAWB + j * 1024), 16, vo_r[i],
+                                                             plane < 2 ? step * 16 : (step >> 2) * 16, 0, 0);
+                }
+            }
+        }
+#endif
+    };
+    // conversion of a landed raw buffer into a weight image: IPR threads per row (2: a 32-element half each; 4, where the tile has fewer rows than half the
+    // threads: a 16-element quarter each — qa or qb of the row, low or high nibbles).  The raw bytes come back through ds_reads hipcc does not see (loads and
+    // their wait in ONE asm statement, early-clobber outputs: cdna_hip_programming.md §5.7 form (i)): for a ds_read it can see while LDS-DMA is in flight it
+    // waits vmcnt(0) first — it cannot tell that the bytes being read landed a step ago — and that drains the transfers this step has just requested (seen in
+    // the ISA of the first build of this kernel); the converted chunks leave through asm ds_writes for the same reason.
+    constexpr int IPR = ADMA ? 2 : (4 * BM <= NT ? 4 : 2);
+    const int srow = tid / IPR, sq = tid % IPR;
+    auto convert = [&](int step, int rslot, int aslot) {
+        if constexpr (!ADMA) {
+            if (srow < BM) {
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+#if defined(__HIP_DEVICE_COMPILE__)
+                const unsigned ra = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char *) (smem + OFF_R + rslot * RAWB + srow * 16);   // LDS byte addresses
+                const unsigned wa = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char *) (smem + aslot * AIMG + srow * ROWB2);
+#else
+                const unsigned ra = 0, wa = 0;
+#endif
+                const int key = swz(srow);
+                if constexpr (IPR == 2) {
+                    u4v r0, r1, r2;
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%4\n\tds_read_b128 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(ra), "n"(BM * 16), "n"(2 * BM * 16) : "memory");
+                    RawW<PKV_TYPE_Q4_K> rw;
+                    rw.q[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); rw.q[1] = make_uint4(r1.x, r1.y, r1.z, r1.w); rw.h = make_uint4(r2.x, r2.y, r2.z, r2.w);
+                    uint4 o[4];
+                    Deq<PKV_TYPE_Q4_K>::run(rw, (int64_t) step * BK + 32 * sq, o);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u4v x = {o[i].x, o[i].y, o[i].z, o[i].w};
+                        asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" :: "v"(wa + (unsigned) (((4 * sq + i) ^ key) << 4)), "v"(x) : "memory");
+                    }
+                } else {   // quarter sq = 2 hsel + pl: the 16 bytes of plane pl (qa / qb), nibble hsel -> elements 32 hsel + 16 pl + [0, 16) of the step
+                    const int hsel = sq >> 1, pl = sq & 1;
+                    u4v qv, hv;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(qv), "=&v"(hv) : "v"(ra + (unsigned) (pl * BM * 16)), "v"(ra), "n"(2 * BM * 16) : "memory");
+                    const int j = 2 * (step & 3) + hsel;                                                    // sub-block of the 256-block
+                    const float d = hf((uint16_t) (hv.x & 0xFFFF)), dmin = hf((uint16_t) (hv.x >> 16));
+                    const int sh = 8 * (j & 3);
+                    const int b0 = (int) ((hv.y >> sh) & 0xFF), b1 = (int) ((hv.z >> sh) & 0xFF), b2 = (int) ((hv.w >> sh) & 0xFF);   // get_scale_min_k4
+                    const int sc = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4)), mn = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
+                    const h2v d1 = splat(d * (float) sc), m1 = splat(-(dmin * (float) mn)), nb = splat(-1024.0f);
+                    const int s4 = 4 * hsel;
+                    uint32_t e[8];
+                    cvt4((qv.x >> s4) & 0x0F0F0F0Fu, nb, d1, m1, e[0], e[1]); cvt4((qv.y >> s4) & 0x0F0F0F0Fu, nb, d1, m1, e[2], e[3]);
+                    cvt4((qv.z >> s4) & 0x0F0F0F0Fu, nb, d1, m1, e[4], e[5]); cvt4((qv.w >> s4) & 0x0F0F0F0Fu, nb, d1, m1, e[6], e[7]);
+                    const u4v x0 = {e[0], e[1], e[2], e[3]}, x1 = {e[4], e[5], e[6], e[7]};
+                    const int c0 = 4 * hsel + 2 * pl;
+                    asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" :: "v"(wa + (unsigned) (((c0) ^ key) << 4)), "v"(x0) : "memory");
+                    asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" :: "v"(wa + (unsigned) (((c0 + 1) ^ key) << 4)), "v"(x1) : "memory");
+                }
+            }
+        }
+    };
+    // wait until only this step's requests are in flight, then the barrier (raw s_barrier: __syncthreads() would drain the DMA)
+    auto wait_and_barrier = [&]() {
+        constexpr int N0 = NIB + NIA;
+        if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N0) : "memory");
+        else {
+            if (n_raw == NRW) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N0 + NRW) : "memory");
+            else              asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N0 + NRW - 1) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto clampst = [&](int st) { return st < nsteps ? st : nsteps - 1; };   // past the last step: a valid re-load into a slot nobody reads again (keeps the counts)
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int a_ro = (wm * 32 * TM + r) * ROWB2, b_ro = OFF_B + (wn * 32 * TN + r) * ROWB2, fkey = swz(r);
+
+    // prologue: raw 0, 1, 2 and tiles 0, 1 requested; everything landed; weight image 0 converted
+    dma_raw(0, 0); dma_raw(clampst(1), 1); dma_raw(clampst(2), 2);
+    dma_tiles(0, 0); dma_tiles(clampst(1), 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    convert(0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int s3 = 0, s2 = 0;                                    // k % 3, k % 2
+    for (int k = 0; k < nsteps; ++k) {
+        const int s3n = s3 == 2 ? 0 : s3 + 1, s3nn = s3n == 2 ? 0 : s3n + 1;
+        dma_raw(clampst(k + 3), s3);                       // raw(k + 3) -> raw slot (k + 3) % 3 = k % 3 (raw(k) was converted at step k - 1)
+        dma_tiles(clampst(k + 2), s3nn);                   // tiles(k + 2) -> slot (k + 2) % 3 (last read at step k - 1)
+        if (k + 1 < nsteps) convert(k + 1, s3n, s2 ^ 1);   // raw(k + 1) (landed before the last barrier) -> weight image (k + 1) % 2
+        const char * sA = smem + (ADMA ? s3 : s2) * AIMG;
+        const char * sB = smem + s3 * BIMG;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            half8_t af[TM], bf[TN];
+            const int po = (((2 * ks + h) ^ fkey) << 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t *>(sA + a_ro + i * 32 * ROWB2 + po);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const half8_t *>(sB + b_ro + j * 32 * ROWB2 + po);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        wait_and_barrier();
+        s3 = s3n; s2 ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's re-loads
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn * 32 * TN + j * 32 + r;
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t m = m0 + wm * 32 * TM + i * 32 + 8 * g + 4 * h;
+                if ((aM & 3) == 0 && m + 3 < aM) *reinterpret_cast<float4 *>(ay + (size_t) n * aM + m) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                else
+                    for (int e = 0; e < 4; ++e) if (m + e < aM) ay[(size_t) n * aM + m + e] = acc[i][j][4 * g + e];
+            }
+    }
+}
+
 // activations f32 -> f16, once per product
 __global__ void __launch_bounds__(256) cvt_f16_kernel(const float4 * __restrict__ x, uint2 * __restrict__ o, int64_t n4) {
     for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t) gridDim.x * 256) {
@@ -474,6 +690,18 @@ int launch_gemm2(GemmArgs & a, int type_w, int64_t n_cols, hipStream_t st, bool 
     hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) std::min<int64_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, (const float4 *) a.x, (uint2 *) xh, n4);
     a.ksplit = 1;
     const dim3 grid((unsigned) ((n_cols + bn - 1) / bn), (unsigned) tot);
+    // third form (transfers two steps ahead) for the shapes with short K-steps; the 256 x 256 tile stays on the second form (three of its images do not fit LDS)
+    const bool deep = shape != 0 && (type_w == PKV_TYPE_F16 || type_w == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED)) && a.K / BK >= 4 && !getenv("PKV_GEMM_NO_DEEP");
+    if (deep) {
+#define PKV_GEMM3(T_) do { if (shape == 1) hipLaunchKernelGGL((gemm3_kernel<T_, 256, 128, 4, 2>), grid, dim3(512), 0, st, a, xh); \
+                           else if (shape == 2) hipLaunchKernelGGL((gemm3_kernel<T_, 128, 128, 2, 2>), grid, dim3(256), 0, st, a, xh); \
+                           else hipLaunchKernelGGL((gemm3_kernel<T_, 64, 128, 1, 4>), grid, dim3(256), 0, st, a, xh); } while (0)
+        if (type_w == PKV_TYPE_F16) PKV_GEMM3(PKV_TYPE_F16); else PKV_GEMM3((PKV_TYPE_Q4_K | PKV_TYPE_PACKED));
+#undef PKV_GEMM3
+        PKV_HIP(hipGetLastError());
+        *done = true;
+        return PKV_OK;
+    }
 #define PKV_GEMM2(T_) do { if (shape == 0) hipLaunchKernelGGL((gemm2_kernel<T_, 256, 256, 2, 4>), grid, dim3(512), 0, st, a, xh); \
                            else if (shape == 1) hipLaunchKernelGGL((gemm2_kernel<T_, 256, 128, 4, 2>), grid, dim3(512), 0, st, a, xh); \
                            else if (shape == 2) hipLaunchKernelGGL((gemm2_kernel<T_, 128, 128, 2, 2>), grid, dim3(256), 0, st, a, xh); \

@@ -9,15 +9,15 @@ pkv = _load_pkg.load(); pkv.lib()
 dev = torch.device("cuda")
 gen = torch.Generator(device=dev).manual_seed(0)
 rs = {1: lambda K: 2 * K, 8: lambda K: K // 32 * 34, 12: lambda K: K // 256 * 144, 14: lambda K: K // 256 * 210}
-for tname, t in (("f16", 1), ("q8_0", 8), ("q4_K", 12), ("q6_K", 14)):
-    SHAPES = ((4096, 4096, 512), (14336, 4096, 512), (4096, 14336, 512), (14336, 4096, 2048), (4096, 4096, 32))
+for tname, t in (("f16", 1), ("q8_0", 8), ("q4_K", 12), ("q4_Kp", 12 | 0x100), ("q6_K", 14), ("q6_Kp", 14 | 0x100)):   # ..p: plane-layout rows (what the plugin keeps), random bytes
+    SHAPES = ((4096, 4096, 512), (6144, 4096, 512), (14336, 4096, 512), (28672, 4096, 512), (4096, 14336, 512), (14336, 4096, 2048), (4096, 4096, 32))
     if os.environ.get("GEMM_TINY"):   # TinyLlama-1.1B layer shapes
         SHAPES = ((2048, 2048, 512), (5632, 2048, 512), (2048, 5632, 512), (32000, 2048, 512))
     for M, K, N in SHAPES:
         if t == 1:
             w = (torch.randn((M, K), device=dev, generator=gen) / K ** 0.5).to(torch.float16).view(torch.uint8).reshape(-1)
         else:
-            w = torch.randint(0, 256, (M * rs[t](K),), dtype=torch.uint8, device=dev, generator=gen)
+            w = torch.randint(0, 256, (M * rs[t & 0xFF](K),), dtype=torch.uint8, device=dev, generator=gen)
         x = torch.randn((N, K), device=dev, generator=gen)
         out = torch.empty((N, M), device=dev)
         for _ in range(3): pkv.mul_mat(w, t, M, K, x, out=out)
