@@ -175,6 +175,11 @@ typedef struct pkv_attn_args {
     void *  ev_start;             /* optional hipEvent_t pair bound to the split-KV decode launch itself          */
     void *  ev_stop;              /* (hipExtLaunchKernel): elapsed = the dispatch's own GPU duration, as rocprofv3 */
                                   /* --kernel-trace reports it.  NULL = plain launch.                              */
+    void *  out_image;            /* pkv_attn_decode / _step, optional (r03): ALSO leave every out row as the q8_K activation image  */
+                                  /* pkv_gemv_q takes as `xq` ([n_tok][pkv_act_image_bytes(n_head*head_dim)], the bytes pkv_quantize_act */
+                                  /* makes of the row): the merge launch quantizes what it has just normalised, and the wo product of */
+                                  /* the layer starts from 5 KB of integers instead of reading, scaling and rounding 16 KB of floats  */
+                                  /* in every workgroup.  Needs 256 % head_dim == 0 and no PKV_ATTN_NO_COMBINE / _FUSED_COMBINE.      */
 } pkv_attn_args;
 
 /* leave the per-block (m, l, O) partials in `workspace` and skip the merge launch (measurement / callers that

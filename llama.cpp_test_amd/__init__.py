@@ -78,7 +78,7 @@ class AttnArgs(C.Structure):
                 ("type_k", C.c_int32), ("type_v", C.c_int32), ("scale", C.c_float), ("logit_softcap", C.c_float),
                 ("max_seq_len", C.c_int32), ("flags", C.c_int32),
                 ("mask", C.c_void_p), ("mask_stride", C.c_int64), ("max_bias", C.c_float),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("out_image", C.c_void_p)]
 
 
 class Gemv(C.Structure):
@@ -225,7 +225,7 @@ def attn_prefill_workspace_bytes(n_tok: int, n_head: int, head_dim: int) -> int:
 
 def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, type_v, block_size, scale, max_seq_len,
           q_start=None, max_q_per_seq=1, slot_pos=None, q_pos=None, logit_softcap=0.0, out=None, workspace=None,
-          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None, stamps=None, slots=None, out_dtype=None):
+          stream=None, flags=0, events=None, mask=None, max_bias=0.0, step=None, stamps=None, slots=None, out_dtype=None, out_image=None):
     import torch
     n_tok, n_head, D = q.shape
     n_seq, max_blocks = block_table.shape
@@ -243,7 +243,7 @@ def _attn(fn, q, k_pool, v_pool, block_table, seq_lens, *, n_head_kv, type_k, ty
                  _ptr(seq_lens), _ptr(q_start), _ptr(slot_pos), _ptr(q_pos), _ptr(workspace), workspace.numel(),
                  n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
                  scale, logit_softcap, max_seq_len, flags, _ptr(mask), mask.stride(0) if mask is not None else 0, max_bias,
-                 events[0] if events else None, events[1] if events else None)
+                 events[0] if events else None, events[1] if events else None, _ptr(out_image))
     if step is not None:
         k_cur, v_cur, pos, rope, rope_cache = step
         st = StepArgs(_ptr(k_cur), _ptr(v_cur), _ptr(pos), C.pointer(rope) if rope is not None else None, _ptr(rope_cache))

@@ -79,6 +79,8 @@ struct DecodeArgs {
     float *         part_ml;  // [n_seq][n_head][n_splits][2]
     float *         out;      // [n_seq][n_head][D]; NULL: leave the partials (PKV_ATTN_NO_COMBINE)
     float *         out_direct; // the caller's out whatever the flags (the one-workgroup-per-stream form writes it itself)
+    char *          out_image;  // optional: q8_K activation image of every out row (attn_combine_kernel<D, true>), image_bytes per token
+    int             image_bytes;
     unsigned *      counters; // [n_seq][n_head_kv] arrival tickets (fused merge), zero between launches
     int             part_o_bytes, part_ml_bytes;   // extents of the partial slabs (buffer descriptors of the fused merge)
     int   n_head, n_head_kv, block_size, max_blocks, n_splits, bs_shift;  // block_size = WG_TOK << bs_shift
@@ -1067,13 +1069,18 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
 // weights handed round through LDS; 4.6 us per launch against a 1.8 us empty launch): lane j < 32 owns split j of a pass exactly as thread j
 // did, the maximum and the sum of the weights are wave reductions, weight u reaches every lane as an SGPR (v_readlane) — the same additions in
 // the same order as before, bit for bit, with half the load instructions (D = 128: 8-byte loads) and a quarter of the waves.
-template <int D>
-__global__ void __launch_bounds__(64) attn_combine_kernel(const DecodeArgs a) {
+// IMG (r03, pkv_attn_args::out_image): the workgroup is the 256 / D waves whose heads make up one 256-element block of the token's row, and the row ALSO leaves
+// as the q8_K activation image of pkv_gemv.hip (quantize_row_q8_K_ref as quant_block_q8k states it: iscale = -127 / amax over the block, q = rint(iscale x),
+// d = 1 / iscale, sums of q per 32) — the bytes pkv_quantize_act would make of `out`, so the layer's wo product starts from integers.
+template <int D, bool IMG = false>
+__global__ void __launch_bounds__(IMG ? 256 / D * 64 : 64) attn_combine_kernel(const DecodeArgs a) {
     constexpr int CH = 32;  // splits per pass (ctx 4096 = one pass)
     constexpr int C = D / 64;                                   // columns per lane
     static_assert(D % 64 == 0 && (C == 1 || C == 2 || C == 4), "head size");
     typedef float colv __attribute__((ext_vector_type(C)));
-    const int h = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    constexpr int HPB = IMG ? 256 / D : 1;                      // heads (= waves) per workgroup
+    const int lane = threadIdx.x & 63, wv = (int) (threadIdx.x >> 6);
+    const int h = blockIdx.x * HPB + wv, s = blockIdx.y;
     const int seq_len = a.seq_lens[s];
     const float * ml = a.part_ml + ((size_t) s * a.n_head + h) * a.n_splits * 2;
     const float * po = a.part_o + ((size_t) s * a.n_head + h) * a.n_splits * D + C * lane;
@@ -1087,7 +1094,9 @@ __global__ void __launch_bounds__(64) attn_combine_kernel(const DecodeArgs a) {
     const float2 ml0 = *reinterpret_cast<const float2 *>(ml + (size_t) min(lane, nsm) * 2);
     const int ns = ((seq_len + WG_TOK - 1) / WG_TOK + a.n_tile - 1) / a.n_tile;   // partials the decode launch wrote for this sequence
     float * o = a.out + ((size_t) s * a.n_head + h) * D + C * lane;
-    if (ns <= 0) { colv z; for (int c = 0; c < C; ++c) z[c] = 0.0f; *reinterpret_cast<colv *>(o) = z; return; }
+    colv r;
+    if (ns <= 0) { for (int c = 0; c < C; ++c) r[c] = 0.0f; *reinterpret_cast<colv *>(o) = r; if constexpr (!IMG) return; }
+    else {
     float m = lane < ns ? ml0.x : -INFINITY;
     for (int j = lane + 64; j < ns; j += 64) m = fmaxf(m, ml[j * 2]);
     const float M = wave_max(m);
@@ -1118,10 +1127,40 @@ __global__ void __launch_bounds__(64) attn_combine_kernel(const DecodeArgs a) {
         }
     }
     const float Ls = wave_sum(L);
-    colv r;
 #pragma unroll
     for (int c = 0; c < C; ++c) r[c] = acc[c] / Ls;  // all cells masked -> 0/0 = NaN, like the reference's 1/S with S == 0
     *reinterpret_cast<colv *>(o) = r;
+    }
+    if constexpr (IMG) {
+        __shared__ float sAm[HPB];
+        float am = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) am = fmaxf(am, fabsf(r[c]));
+        am = wave_max(am);
+        if (lane == 0) sAm[wv] = am;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < HPB; ++w) am = fmaxf(am, sAm[w]);
+        const float iscale = am != 0.0f ? -127.0f / am : 0.0f;
+        char * img = a.out_image + (size_t) s * a.image_bytes;
+        const int K = a.n_head * D, e0 = h * D + C * lane;       // this lane's first element of the row
+        int q[C], qs = 0;
+        uint32_t pk = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { q[c] = (int) __builtin_rintf(iscale * r[c]); qs += q[c]; pk |= (uint32_t) (q[c] & 0xFF) << (8 * c); }
+        if constexpr (C == 1) reinterpret_cast<uint8_t *>(img)[e0] = (uint8_t) pk;
+        else if constexpr (C == 2) *reinterpret_cast<uint16_t *>(img + e0) = (uint16_t) pk;
+        else *reinterpret_cast<uint32_t *>(img + e0) = pk;
+        // sums per 32 elements = 32 / C lanes: DPP inside the row of 16, one permlane swap more where 32 lanes share a sum
+        qs += __builtin_amdgcn_update_dpp(0, qs, 0xB1, 0xf, 0xf, true);
+        qs += __builtin_amdgcn_update_dpp(0, qs, 0x4E, 0xf, 0xf, true);
+        qs += __builtin_amdgcn_update_dpp(0, qs, 0x141, 0xf, 0xf, true);
+        if constexpr (C <= 2) qs += __builtin_amdgcn_update_dpp(0, qs, 0x140, 0xf, 0xf, true);          // 16 lanes
+        if constexpr (C == 1) { auto t = __builtin_amdgcn_permlane16_swap((unsigned) qs, (unsigned) qs, false, false); qs = (int) t[0] + (int) t[1]; }   // 32 lanes
+        constexpr int LPS = 32 / C;                               // lanes per sum
+        if (lane % LPS == 0) reinterpret_cast<int *>(img + K + (K >> 8) * 4)[e0 >> 5] = qs;
+        if (threadIdx.x == 0) reinterpret_cast<float *>(img + K)[blockIdx.x] = am != 0.0f ? 1.0f / iscale : 0.0f;
+    }
 }
 
 // measurement hook (pkv_attn_decode_profiled): when set, the split-KV kernel is launched with start/stop events that
@@ -1153,6 +1192,14 @@ inline int decode_tiles_per_wg(int n_splits, int n_head_kv, int n_seq) {
     return (int) (nt < 1 ? 1 : nt);
 }
 
+template <int D>
+void launch_combine(const DecodeArgs & da, int n_seq, hipStream_t st) {
+    if constexpr (256 % D == 0) {
+        if (da.out_image) { hipLaunchKernelGGL((attn_combine_kernel<D, true>), dim3(da.n_head * D / 256, n_seq), dim3(256 / D * 64), 0, st, da); return; }
+    }
+    hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
+}
+
 template <int KT, int VT, int D, int G>
 int launch_one(const DecodeArgs & da0, int n_seq, hipStream_t st) {
     DecodeArgs da = da0;
@@ -1162,7 +1209,7 @@ int launch_one(const DecodeArgs & da0, int n_seq, hipStream_t st) {
     if (!cap && !sp && !da.counters && !da.stamps) {
         da.n_tile    = decode_tiles_per_wg(da.n_splits, da.n_head_kv, n_seq);
         da.n_splits  = (da.n_splits + da.n_tile - 1) / da.n_tile;
-        da.final_out = da.n_tile > 1 && da.n_splits == 1 && da.out_direct != nullptr;
+        da.final_out = da.n_tile > 1 && da.n_splits == 1 && da.out_direct != nullptr && da.out_image == nullptr;   // (the image is made by the merge launch)
         if (da.final_out) da.out = da.out_direct;     // (also under PKV_ATTN_NO_COMBINE: this form has no partials to leave behind)
     }
     // quantized KV with workgroups to spare: 32 tokens per wave (4-wave workgroups)
@@ -1194,7 +1241,7 @@ int launch_one(const DecodeArgs & da0, int n_seq, hipStream_t st) {
         }
         if (!wide && multi) launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true, 0, 16, true>, grid, block, st, da);
         else if (!wide)     launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, false, true>, grid, block, st, da);
-        if (da.out && !da.final_out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
+        if (da.out && !da.final_out) launch_combine<D>(da, n_seq, st);
     } else if (da.counters) {   // fused merge (no second launch); softcap / irregular sequences take the two-launch path
         launch_kernel(attn_decode_kernel<KT, VT, D, G, false, false, true, false>, grid, block, st, da);
     } else {
@@ -1209,7 +1256,7 @@ int launch_one(const DecodeArgs & da0, int n_seq, hipStream_t st) {
         else if (!cap && sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, false, true, false, false>, grid, block, st, da);
         else if (cap && !sp)  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, false, false, false>, grid, block, st, da);
         else                  launch_kernel(attn_decode_kernel<KT, VT, D, G, true, true, false, false>, grid, block, st, da);
-        if (da.out && !da.final_out) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(da.n_head, n_seq), dim3(64), 0, st, da);
+        if (da.out && !da.final_out) launch_combine<D>(da, n_seq, st);
     }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
@@ -1297,6 +1344,13 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.part_ml = da.part_o + (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim;
     da.out = (a.flags & PKV_ATTN_NO_COMBINE) ? nullptr : a.out;
     da.out_direct = a.out;
+    da.out_image = (char *) a.out_image; da.image_bytes = 0;
+    if (a.out_image) {
+        const int64_t Krow = (int64_t) a.n_head * a.head_dim;
+        PKV_REQUIRE(256 % a.head_dim == 0 && Krow % 256 == 0 && !(a.flags & (PKV_ATTN_NO_COMBINE | PKV_ATTN_FUSED_COMBINE)),
+                    "pkv_attn_decode: out_image needs 256 %% head_dim == 0, whole 256-blocks per row and the merge launch");
+        da.image_bytes = (int) act_image_bytes(Krow);
+    }
     da.counters = nullptr;
     const size_t po_bytes = (size_t) a.n_tok * a.n_head * da.n_splits * a.head_dim * sizeof(float);
     da.part_o_bytes = (int) po_bytes; da.part_ml_bytes = (int) (po_bytes / a.head_dim * 2);

@@ -347,6 +347,19 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict
             }
         }
     }
+    // r03: an image made by the producer of the column (the attention merge launch: pkv_attn_args::out_image) goes out ahead of the weights as well
+    constexpr int NIQ = 4;                                           // image dwords per thread held in registers (K <= 16 NT), else the loop further down
+    const bool imgk = PKV_GEMV_ABLATE != 2 && aimg != nullptr && n4 <= NIQ * NT && (aK >> 5) <= NT;
+    uint32_t iq[NIQ];
+    float dpre = 0.0f;
+    int   bpre = 0;
+    if (imgk) {
+        const uint32_t * qi = reinterpret_cast<const uint32_t *>(aimg);
+#pragma unroll
+        for (int j = 0; j < NIQ; ++j) { const int i = threadIdx.x + NT * j; iq[j] = i < n4 ? qi[i] : 0u; }
+        if ((int) threadIdx.x < (aK >> 8)) dpre = reinterpret_cast<const float *>(aimg + aK)[threadIdx.x];
+        if ((int) threadIdx.x < (aK >> 5)) bpre = reinterpret_cast<const int *>(aimg + aK + (aK >> 8) * 4)[threadIdx.x];
+    }
     __builtin_amdgcn_sched_barrier(0);
     constexpr int TAIL = MODE == PKV_TYPE_Q4_K ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
     const int gpr = aK >> 6;
@@ -409,7 +422,28 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict
         if ((i & 15) == 0) r[2] = __float_as_uint(d);                 // the 256-block's scale, once per 64-group
     };
     if (PKV_GEMV_ABLATE == 2) {} else
-    if (aimg) {
+    if (imgk) {
+        // the image sits in registers (requested ahead of the weights): K / 4 dwords of int8, the 256-block scales, the per-32 sums
+#pragma unroll
+        for (int j = 0; j < NIQ; ++j) {
+            const int i = threadIdx.x + NT * j;
+            if (i - lane < n4) {                                      // wave-uniform (n4 % 64 == 0)
+                const uint32_t w = iq[j];
+                sq[(i >> 4) * REC + (i & 15)] = w;
+                if constexpr (TAIL == 1) {
+                    int x = __builtin_amdgcn_sdot4((int) w, 0x01010101, 0, false);
+                    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+                    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+                    if ((i & 3) == 0) reinterpret_cast<uint16_t *>(sq + (i >> 4) * REC + 16)[(i >> 2) & 3] = (uint16_t) x;
+                }
+            }
+        }
+        if ((int) threadIdx.x < (aK >> 8)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sq[(4 * threadIdx.x + k) * REC + 18] = __float_as_uint(dpre);
+        }
+        if constexpr (TAIL == 0) { if ((int) threadIdx.x < (aK >> 5)) sq[(threadIdx.x >> 1) * REC + 16 + (threadIdx.x & 1)] = (uint32_t) bpre; }
+    } else if (aimg) {
         // the column image was made by a launch of its own: K / 4 dwords of int8, the 256-block scales, the per-32 sums
         const uint32_t * qi = reinterpret_cast<const uint32_t *>(aimg);
         const float * dd = reinterpret_cast<const float *>(aimg + aK);

@@ -24,7 +24,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from . import (F16, Q4_K, Q6_K, PACKED, weights_pack, PagedKVCache, PkvError, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add, rms_norm_mul, rope_cache,
+from . import (F16, Q4_K, Q6_K, PACKED, act_image, weights_pack, PagedKVCache, PkvError, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add, rms_norm_mul, rope_cache,
                rope_params, silu_mul, kv_store)
 from .gguf_synth import read_gguf, row_bytes
 
@@ -85,6 +85,16 @@ class LlamaDecoder:
         self.graph_len = 0
         self.trace = None
         self.attn_flags = 0                 # e.g. ATTN_FUSED_COMBINE: the split-KV merge inside the decode launch (measured)
+        # opt-in experiment (use_attn_image()): the attention merge launch also leaves its row as the q8_K image the wo product streams against
+        # (pkv_attn_args::out_image).  Measured end to end in one process (probes/e2e_profile.py [--no-image], 8B Q4_K_M mix, ctx 4096): 604 tok/s
+        # with it, 608.5 without — the wo product's quantization of its column already hides under the latency of its first weight unit
+        # (5.04 vs 5.11 us per launch), and the merge launch is not the cheaper for writing 5 KB more.  Off.
+        self.attn_img = None
+
+    def use_attn_image(self, on: bool = True):
+        ok = (256 % self.D == 0 and (self.n_head * self.D) % 256 == 0 and self._kq(["blk.0.attn_output.weight"]))
+        self.attn_img = act_image(self.n_head * self.D, self.dev) if (on and ok) else None
+        self.graph = None
 
     # ---- model bytes ---------------------------------------------------------------------------------------------------------
     def weight_bytes(self) -> int:
@@ -105,14 +115,15 @@ class LlamaDecoder:
         return (all((self.w[n][1] & ~PACKED) in _KQ for n in names) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
                 and len({self.w[n][1] & PACKED for n in names}) == 1)
 
-    def _products(self, names, outs, x_f32, *, norm=None, residual=None, silu=False):
+    def _products(self, names, outs, x_f32, *, norm=None, residual=None, silu=False, image=None):
         """outs[i] = W_i x' (+ residual | SwiGLU) with x' = x, or rms_norm(x) * norm weights: ONE pkv_gemv_q launch for K-quant rows (the column is
         normalised and quantized inside it), pkv_rms_norm_mul_f32 / pkv_mul_mat + element-wise launches otherwise"""
         ws = [self.w[n] for n in names]
         K = ws[0][2][0]
         nw = self.w[norm][0].view(self.torch.float32) if norm is not None else None
         if self._kq(names) and (nw is None or K <= 8192):
-            gemv_q([w[0] for w in ws], [w[1] for w in ws], [w[2][1] for w in ws], K, None, outs, residual=residual, silu_mul=silu,
+            # image: the column as the q8_K activation image its producer left (the attention merge launch: pkv_attn_args::out_image)
+            gemv_q([w[0] for w in ws], [w[1] for w in ws], [w[2][1] for w in ws], K, image if nw is None else None, outs, residual=residual, silu_mul=silu,
                    x=x_f32, norm_w=nw, eps=self.eps)
             return
         if nw is not None:
@@ -144,10 +155,11 @@ class LlamaDecoder:
                            [self.q.reshape(-1), self.k_cur.reshape(-1), self.v_cur.reshape(-1)], self.h, norm=p + "attn_norm.weight")
             attn_decode_step(self.q, self.k_cur, self.v_cur, self.pos, self.rope, self.cache.k_pool(l), self.cache.v_pool(l), self.block_table,
                              self.seq_lens, n_head_kv=self.n_head_kv, type_k=self.tk, type_v=self.tv, block_size=self.BS, scale=self.scale,
-                             max_seq_len=msl, out=self.attn, workspace=self.ws, rope_cache=self.rope_cs, flags=self.attn_flags)
+                             max_seq_len=msl, out=self.attn, workspace=self.ws, rope_cache=self.rope_cs, flags=self.attn_flags,
+                             out_image=self.attn_img if not self.attn_flags else None)
             if self.trace is not None:   # debugging aid (eager launches only): per-layer copies of the attention path's inputs and output
                 self.trace.append({k: getattr(self, k).detach().clone() for k in ("q", "k_cur", "v_cur", "attn")})
-            self._products([p + "attn_output.weight"], [self.h], self.attn.reshape(-1), residual=self.h)
+            self._products([p + "attn_output.weight"], [self.h], self.attn.reshape(-1), residual=self.h, image=self.attn_img if not self.attn_flags else None)
             self._products([p + "ffn_gate.weight", p + "ffn_up.weight"], [self.act], self.h, norm=p + "ffn_norm.weight", silu=True)
             self._products([p + "ffn_down.weight"], [self.h], self.act, residual=self.h)
         self._products(["output.weight"], [self.logits], self.h, norm="output_norm.weight")

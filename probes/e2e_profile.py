@@ -10,7 +10,7 @@ import bench
 pkv = _load_pkg.load(); pkv.lib()
 from llama_cpp_test_amd import gguf_synth as G
 from llama_cpp_test_amd.decoder import LlamaDecoder
-ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--eager", action="store_true"); ap.add_argument("--ctx", type=int, default=4096); ap.add_argument("--fused-merge", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--eager", action="store_true"); ap.add_argument("--ctx", type=int, default=4096); ap.add_argument("--fused-merge", action="store_true"); ap.add_argument("--image", action="store_true", help="opt-in: the attention merge launch leaves the q8_K image the wo product streams against (pkv_attn_args::out_image)")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp(dir="/tmp", prefix="pkv_e2e_")
 path = os.path.join(tmp, "m.gguf")
@@ -18,6 +18,7 @@ try:
     G.synth_llama(path, wtype=G.GGML_Q4_K, k_mix=True, seed=8, **bench.LLAMA3_8B)
     dec = LlamaDecoder(path, n_ctx=a.ctx)
     if a.fused_merge: dec.attn_flags = pkv.ATTN_FUSED_COMBINE
+    if a.image: dec.use_attn_image()
     dec.fill_kv_synthetic(a.ctx - 1, seed=3)
     dec._place(12345, a.ctx - 1)
     if a.eager:

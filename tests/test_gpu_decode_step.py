@@ -183,3 +183,40 @@ def test_step_with_llama3_rope_frequency_factors(pkv, O):
     O.pool_store(vp, 8, 1, O.from_float(8, vc), sb, so, D=D, block_size=128)
     ref = O.attn_paged(qr[:, :, None, :], kp, vp, bt, sl, n_q=1, type_k=8, type_v=8, block_size=128, scale=D ** -0.5)[:, 0]
     assert np.abs(b[0] - ref).max() <= 1e-3 and nmse(b[0], ref) <= 5e-4
+
+
+@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (64, 32, 4), (128, 4, 2)])
+def test_step_leaves_the_activation_image_of_its_output(pkv, O, D, nh, nkv):
+    """pkv_attn_args::out_image (r03): the merge launch also writes every out row as the q8_K activation image of the decode-step products — the
+    bytes pkv_quantize_act makes of that row — and a product fed the image equals the product that quantizes the f32 row itself, bit for bit."""
+    rng = np.random.default_rng(17 + D + nh)
+    lens = [1, 129, 640, 4096, 0 + 300]
+    kp, vp, bt, sl, q, kc, vc, pos = _case(O, rng, lens, D, nh, nkv, 1, 1)
+    rope = pkv.rope_params(n_dims=D, mode=0, freq_base=10000.0)
+    K = nh * D
+    n = len(lens)
+    nbytes = pkv.lib().pkv_act_image_bytes(K)
+    img = torch.zeros((n, nbytes), dtype=torch.uint8, device="cuda")
+    plain = _fused(pkv, q, kc, vc, pos, rope, kp, vp, bt, sl, nkv=nkv, tk=1, tv=1, shared_cache=True)
+    dq, dkp, dvp, dpos = dev(q), dev(kp), dev(vp), dev(pos)
+    out = pkv.attn_decode_step(dq, dev(kc), dev(vc), None, rope, dkp, dvp, dev(bt), dev(sl), n_head_kv=nkv, type_k=1, type_v=1, block_size=128,
+                               scale=D ** -0.5, max_seq_len=int(sl.max()), rope_cache=pkv.rope_cache(dpos, rope, D), out_image=img)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), plain[0].view(np.uint32))          # the f32 output is what it was
+    for s in range(n):
+        want = pkv.quantize_act(out[s].reshape(-1).contiguous())
+        torch.cuda.synchronize()
+        assert np.array_equal(img[s].cpu().numpy(), want.cpu().numpy()), s
+    # a product on the image == the product on the f32 row (q4_K rows, residual epilogue: the wo product of a layer)
+    if K % 256 == 0 and K >= 1024:
+        from llama_cpp_test_amd import gguf_synth as G
+        M = 512
+        raw = np.frombuffer(G.random_q4_K(rng, M, K), np.uint8).copy()
+        w = dev(raw)
+        res = dev(rng.standard_normal(M).astype(np.float32))
+        a = torch.zeros(M, device="cuda")
+        b = torch.zeros(M, device="cuda")
+        pkv.gemv_q([w], [12], [M], K, None, [a], residual=res, x=out[3].reshape(-1).contiguous())
+        pkv.gemv_q([w], [12], [M], K, img[3], [b], residual=res, x=out[3].reshape(-1).contiguous())
+        torch.cuda.synchronize()
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))

@@ -82,6 +82,14 @@ def test_own_loop_reproduces_reference_logits(pkv, gen, model_path, kv):
         lg2 = d2.eval(int(tok[i]), i)
     assert np.array_equal(lg2.cpu().numpy(), eager)
     d2.close()
+    # the opt-in image path (the merge launch hands the wo product its q8_K column, pkv_attn_args::out_image): same integers, same logits
+    d3 = LlamaDecoder(model_path, n_ctx=256, type_k=t, type_v=t)
+    d3.use_attn_image()
+    if d3.attn_img is not None:
+        for i in range(last + 1):
+            lg3 = d3.eval(int(tok[i]), i)
+        assert np.array_equal(lg3.cpu().numpy(), eager)
+    d3.close()
 
 
 def test_weight_types_and_bytes(pkv, model_path):
