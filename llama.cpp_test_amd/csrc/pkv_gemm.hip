@@ -429,10 +429,14 @@ template <int T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN) gemm3_kernel(const GemmArgs a, const _Float16 * __restrict__ xh) {
     constexpr int NT = 64 * WM * WN, NWAVE = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr bool ADMA = (T & ~PKV_TYPE_PACKED) == PKV_TYPE_F16;
-    static_assert(ADMA || T == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED), "third form: f16 and packed q4_K weights");
+    constexpr bool Q6 = T == (PKV_TYPE_Q6_K | PKV_TYPE_PACKED);
+    static_assert(ADMA || Q6 || T == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED), "third form: f16, packed q4_K and packed q6_K weights");
     static_assert(TM >= 1 && TN >= 1 && BM % 64 == 0 && BN % (8 * NWAVE) == 0 && (!ADMA || BM % (8 * NWAVE) == 0) && 2 * BM <= NT, "tile shape");   // (2 * BM <= NT: every row-half has a thread)
     constexpr int AIMG = BM * ROWB2, BIMG = BN * ROWB2, NA = ADMA ? 3 : 2;           // f16 tile images: weights (ring of 3 by DMA, or 2 by conversion), activations (3)
-    constexpr int RAWB = ADMA ? 0 : 3 * BM * 16;                                      // one raw buffer: planes qa | qb | header, 16 B per row each
+    // one raw buffer: q4_K planes qa | qb | header, 16 B per row each; q6_K planes la0 | la1 | lb0 | lb1 | hh0 | hh1 | scales (16 B per row each) and a 4-byte plane with the
+    // dword that holds the block's f16 d (item (b, n, is) of pkv_wlayout.h: a 64-deep step = half n of block b needs both `is` items of la, lb and hh)
+    constexpr int NPL = ADMA ? 0 : (Q6 ? 7 : 3);                                      // 16-byte granule planes
+    constexpr int RAWB = ADMA ? 0 : NPL * BM * 16 + (Q6 ? BM * 4 : 0);
     constexpr int OFF_B = NA * AIMG, OFF_R = OFF_B + 3 * BIMG;
     __shared__ __attribute__((aligned(16))) char smem[OFF_R + 3 * RAWB];             // ONE LDS object (a second one can make hipcc wait vmcnt(0) before every ds_read)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave % WM, wn = wave / WM;
@@ -465,14 +469,17 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm3_kernel(const GemmArgs a, c
         }
     }
     // raw q4_K granules of a step: instruction j (0 .. 3 BM / 64) = plane j / (BM / 64), rows 64 (j % (BM / 64)) + lane.  Wave w issues instructions w, w + NWAVE, ...
-    constexpr int NRI = ADMA ? 0 : 3 * BM / 64, NRW = (NRI + NWAVE - 1) / NWAVE;     // per step, per wave (the last round may be short)
+    constexpr int NRG = NPL * BM / 64;                                               // 16-byte granule instructions per step
+    constexpr int NRI = ADMA ? 0 : NRG + (Q6 ? BM / 64 : 0), NRW = (NRI + NWAVE - 1) / NWAVE;     // + the 4-byte d plane; per step, per wave (the last round may be short)
     const int gpr = (int) (a.K >> 6);
     [[maybe_unused]] int vo_r[NRW > 0 ? NRW : 1];
     if constexpr (!ADMA) {
 #pragma unroll
         for (int i = 0; i < NRW; ++i) {
             const int j = wave + i * NWAVE, plane = j / (BM / 64), row = 64 * (j % (BM / 64)) + lane;
-            vo_r[i] = (int) (min((int64_t) row, aM - 1 - m0) * a.row_bytes) + plane * 16 * gpr;          // (+ 16 g for qa / qb, 16 (g >> 2) for the header: the step's soffset)
+            const int rb = (int) (min((int64_t) row, aM - 1 - m0) * a.row_bytes);
+            if constexpr (Q6) vo_r[i] = rb + (plane < 6 ? (plane >> 1) * 16 * gpr + (plane & 1) * 16 : (plane == 6 ? 48 * gpr : 52 * gpr));   // la / lb / hh (is = plane & 1), scales, d
+            else              vo_r[i] = rb + plane * 16 * gpr;       // (+ 16 g for qa / qb, 16 (g >> 2) for the header: the step's soffset)
         }
     }
     const int n_raw = ADMA ? 0 : (NRI - wave + NWAVE - 1) / NWAVE;                     // raw instructions this wave issues per step (wave-uniform): NRW or NRW - 1
@@ -497,6 +504,13 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm3_kernel(const GemmArgs a, c
                 const int j = wave + i * NWAVE;            // wave-uniform
                 if (j < NRI) {
                     const int plane = j / (BM / 64);
+                    if constexpr (Q6) {
+                        const int b = step >> 2, it0 = 4 * b + 2 * ((step >> 1) & 1);                     // block, first item of its half n
+                        if (j < NRG) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *) (smem + OFF_R + slot * RAWB + j * 1024), 16, vo_r[i],
+                                                                              plane < 6 ? it0 * 16 : b * 16, 0, 0);
+                        else         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *) (smem + OFF_R + slot * RAWB + NRG * 1024 + (j - NRG) * 256), 4, vo_r[i],
+                                                                              (2 * b) & ~3, 0, 0);        // the aligned dword around the block's d
+                    } else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *) (smem + OFF_R + slot * RAWB + j * 1024), 16, vo_r[i],
                                                              plane < 2 ? step * 16 : (step >> 2) * 16, 0, 0);
                 }
@@ -509,7 +523,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm3_kernel(const GemmArgs a, c
     // their wait in ONE asm statement, early-clobber outputs: cdna_hip_programming.md §5.7 form (i)): for a ds_read it can see while LDS-DMA is in flight it
     // waits vmcnt(0) first — it cannot tell that the bytes being read landed a step ago — and that drains the transfers this step has just requested (seen in
     // the ISA of the first build of this kernel); the converted chunks leave through asm ds_writes for the same reason.
-    constexpr int IPR = ADMA ? 2 : (4 * BM <= NT ? 4 : 2);
+    constexpr int IPR = (ADMA || Q6) ? 2 : (4 * BM <= NT ? 4 : 2);
     const int srow = tid / IPR, sq = tid % IPR;
     auto convert = [&](int step, int rslot, int aslot) {
         if constexpr (!ADMA) {
@@ -522,6 +536,30 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm3_kernel(const GemmArgs a, c
                 const unsigned ra = 0, wa = 0;
 #endif
                 const int key = swz(srow);
+                if constexpr (Q6) {   // half sq of the step = sub-block j = 2 m + sq of half n: la (sq 0) or lb (sq 1), both `is` items; hh; scales 8 n + 2 j, + 1; d
+                    const int m = step & 1, n = (step >> 1) & 1, j = 2 * m + sq;
+                    u4v l0, l1, h0, h1, sc;
+                    unsigned dd;
+                    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:%9\n\tds_read_b128 %2, %7 offset:%10\n\tds_read_b128 %3, %7 offset:%11\n\t"
+                                 "ds_read_b128 %4, %7 offset:%12\n\tds_read_b32 %5, %8 offset:%13\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(l0), "=&v"(l1), "=&v"(h0), "=&v"(h1), "=&v"(sc), "=&v"(dd)
+                                 : "v"(ra + (unsigned) (sq * 2 * BM * 16)), "v"(ra), "v"(ra - (unsigned) (srow * 12)),
+                                   "n"(BM * 16), "n"(4 * BM * 16), "n"(5 * BM * 16), "n"(6 * BM * 16), "n"(7 * BM * 16) : "memory");
+                    RawW<PKV_TYPE_Q6_K> rw;
+                    rw.ql[0] = make_uint4(l0.x, l0.y, l0.z, l0.w); rw.ql[1] = make_uint4(l1.x, l1.y, l1.z, l1.w);
+                    rw.qh[0] = make_uint4(h0.x, h0.y, h0.z, h0.w); rw.qh[1] = make_uint4(h1.x, h1.y, h1.z, h1.w);
+                    const unsigned scw[4] = {sc.x, sc.y, sc.z, sc.w};
+                    const int si = 8 * n + 2 * j;                                                          // even: both scales sit in one dword
+                    rw.sc2 = (uint16_t) ((scw[si >> 2] >> (8 * (si & 3))) & 0xFFFF);
+                    rw.d   = (uint16_t) (((step >> 2) & 1) ? (dd >> 16) : (dd & 0xFFFF));
+                    uint4 o[4];
+                    Deq<PKV_TYPE_Q6_K>::run(rw, (int64_t) step * BK + 32 * sq, o);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u4v x = {o[i].x, o[i].y, o[i].z, o[i].w};
+                        asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" :: "v"(wa + (unsigned) (((4 * sq + i) ^ key) << 4)), "v"(x) : "memory");
+                    }
+                } else
                 if constexpr (IPR == 2) {
                     u4v r0, r1, r2;
                     asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%4\n\tds_read_b128 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
@@ -691,12 +729,21 @@ int launch_gemm2(GemmArgs & a, int type_w, int64_t n_cols, hipStream_t st, bool 
     a.ksplit = 1;
     const dim3 grid((unsigned) ((n_cols + bn - 1) / bn), (unsigned) tot);
     // third form (transfers two steps ahead) for the shapes with short K-steps; the 256 x 256 tile stays on the second form (three of its images do not fit LDS)
-    const bool deep = shape != 0 && (type_w == PKV_TYPE_F16 || type_w == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED)) && a.K / BK >= 4 && !getenv("PKV_GEMM_NO_DEEP");
+    // packed q6_K: its raw ring (7 planes) does not fit beside a 256-row tile and leaves room for ONE workgroup per CU — it pays where the launch is a single round of
+    // workgroups anyway (4096 x 4096 x 512: 199 -> 243 TFLOP/s, 4096 x 14336 x 512: 202 -> 268; 6144 rows = 384 workgroups: 280 -> 193, stays on the second form);
+    // rows 16-byte aligned: K % 2048 == 0 (pkv_wlayout.h)
+    const bool q6p = type_w == (PKV_TYPE_Q6_K | PKV_TYPE_PACKED);
+    const bool q6deep = q6p && shape >= 2 && a.K % 2048 == 0 && (int64_t) tot * ((n_cols + bn - 1) / bn) <= 256;
+    const bool deep = shape != 0 && (type_w == PKV_TYPE_F16 || type_w == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED) || q6deep) && a.K / BK >= 4 && !getenv("PKV_GEMM_NO_DEEP");
     if (deep) {
 #define PKV_GEMM3(T_) do { if (shape == 1) hipLaunchKernelGGL((gemm3_kernel<T_, 256, 128, 4, 2>), grid, dim3(512), 0, st, a, xh); \
                            else if (shape == 2) hipLaunchKernelGGL((gemm3_kernel<T_, 128, 128, 2, 2>), grid, dim3(256), 0, st, a, xh); \
                            else hipLaunchKernelGGL((gemm3_kernel<T_, 64, 128, 1, 4>), grid, dim3(256), 0, st, a, xh); } while (0)
-        if (type_w == PKV_TYPE_F16) PKV_GEMM3(PKV_TYPE_F16); else PKV_GEMM3((PKV_TYPE_Q4_K | PKV_TYPE_PACKED));
+        if (type_w == PKV_TYPE_F16) PKV_GEMM3(PKV_TYPE_F16);
+        else if (q6p) {
+            if (shape == 2) hipLaunchKernelGGL((gemm3_kernel<(PKV_TYPE_Q6_K | PKV_TYPE_PACKED), 128, 128, 2, 2>), grid, dim3(256), 0, st, a, xh);
+            else            hipLaunchKernelGGL((gemm3_kernel<(PKV_TYPE_Q6_K | PKV_TYPE_PACKED), 64, 128, 1, 4>), grid, dim3(256), 0, st, a, xh);
+        } else PKV_GEMM3((PKV_TYPE_Q4_K | PKV_TYPE_PACKED));
 #undef PKV_GEMM3
         PKV_HIP(hipGetLastError());
         *done = true;

@@ -73,7 +73,9 @@ def test_swiglu_packed_equals_gguf_order(pkv):
 
 
 @pytest.mark.parametrize("tname,M,K,n_cols", [("q4_K", 1024, 4096, 1), ("q4_K", 1024, 4096, 3), ("q4_K", 1000, 768, 7), ("q4_K", 1024, 4096, 64), ("q4_K", 2048, 14336, 200),
-                                              ("q6_K", 1024, 4096, 1), ("q6_K", 1024, 4096, 5), ("q6_K", 1024, 4096, 96), ("q6_K", 300, 1024, 33)])
+                                              ("q6_K", 1024, 4096, 1), ("q6_K", 1024, 4096, 5), ("q6_K", 1024, 4096, 96), ("q6_K", 300, 1024, 33),
+                                              # the third form of the MFMA product (raw planes by LDS-DMA): 64 x 128 tiles, 128 x 128 tiles (2048 rows x 3072 columns), a long K
+                                              ("q4_K", 2048, 4096, 3072), ("q6_K", 2048, 4096, 3072), ("q6_K", 1024, 14336, 512), ("q6_K", 1000, 2048, 130)])
 def test_mul_mat_packed_equals_gguf_order(pkv, tname, M, K, n_cols):
     """pkv_mul_mat on a packed tensor: one column (decode product), a few (q4_K: the LDS-staged kernel), many (MFMA)"""
     from llama_cpp_test_amd import gguf_synth as G
