@@ -43,3 +43,22 @@ def test_compute_refuses_without_device(pkv):
     assert pkv.lib().pkv_kv_store(x, x, x, x, pkv.F16, pkv.F16, x, x, x, None, 1, 1, 128, 128, None) == pkv.ERR_NO_DEVICE
     with pytest.raises(pkv.PkvError):
         pkv.PagedKVCache(n_blocks=4, n_layer=2)       # device pools need a device
+
+
+def test_decode_launch_shapes(pkv, monkeypatch):
+    """pkv_attn_decode_tiles (host logic, no device): how a decode launch is cut into workgroups for BASELINE's shapes — one 128-token tile per
+    workgroup while the launch has fewer than two workgroups per CU, otherwise about one 8-wave workgroup per CU with at most 8 tiles each; a
+    workgroup that covers its whole sequence means no partials and no merge launch (bench.py reports the choice)."""
+    monkeypatch.delenv("PKV_DECODE_NTILE", raising=False)
+    t = pkv.attn_decode_tiles
+    assert t(4096, 8, 1) == 1            # config 2: 32 x 8 = 256 workgroups, one per CU
+    assert t(16384, 8, 1) == 4           # config 5 (70B geometry): 1024 tiles -> 256 workgroups of 4
+    assert t(640, 8, 32) == 5            # config 3's decode step: one workgroup per (sequence, kv head) walks all 5 tiles
+    assert t(4096, 8, 32) == 8           # 8192 tiles: capped (a long sequence among short ones must not serialise the launch)
+    assert t(1, 8, 1) == 1 and t(128, 1, 1) == 1 and t(129, 8, 31) == 1      # (496 workgroups: below two per CU)
+    assert t(256, 8, 32) == 2
+    for msl, nkv, ns in ((100, 2, 3), (5000, 8, 7), (131072, 8, 1), (640, 8, 256)):
+        n = t(msl, nkv, ns)
+        assert 1 <= n <= min(8, -(-msl // 128))
+    monkeypatch.setenv("PKV_DECODE_NTILE", "3")                              # the experiments' override, clamped to the sequence's tiles
+    assert t(4096, 8, 1) == 3 and t(200, 8, 1) == 2
