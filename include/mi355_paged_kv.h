@@ -49,6 +49,7 @@ extern "C" {
 /* values follow enum ggml_type (/ref/ggml/include/ggml.h:351-360) */
 enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8,
                 PKV_TYPE_Q4_K = 12, /* weights of pkv_mul_mat / pkv_gemv_q only (block_q4_K, /ref/ggml/src/ggml-common.h:279-290); not a KV type */
+                PKV_TYPE_Q5_K = 13, /* weights of pkv_mul_mat / pkv_get_rows (block_q5_K, :291-308; Q5_K_M files): every column count through the MFMA product */
                 PKV_TYPE_Q6_K = 14  /* weights of pkv_gemv_q / pkv_get_rows only (block_q6_K, :309-319): what a Q4_K_M file mixes in          */ };
 
 enum pkv_status {

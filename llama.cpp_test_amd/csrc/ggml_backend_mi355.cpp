@@ -642,10 +642,10 @@ bool supports_silu(const ggml_tensor * op) { return ggml_get_unary_op(op) == GGM
 bool mul_mat_2d(const ggml_tensor * op) {
     const ggml_tensor * w = op->src[0], * x = op->src[1];
     if (!w || !f32c(x) || !f32c(op) || !ggml_is_contiguous(w)) return false;
-    if (w->type != GGML_TYPE_F32 && w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q8_0 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q6_K) return false;
+    if (w->type != GGML_TYPE_F32 && w->type != GGML_TYPE_F16 && w->type != GGML_TYPE_Q8_0 && w->type != GGML_TYPE_Q4_K && w->type != GGML_TYPE_Q5_K && w->type != GGML_TYPE_Q6_K) return false;
     if (w->ne[2] != 1 || w->ne[3] != 1 || x->ne[2] != 1 || x->ne[3] != 1) return false;   // plain 2-D products only
     if (w->type == GGML_TYPE_Q6_K && (w->ne[0] % 256 != 0 || (x->ne[1] == 1 && w->ne[1] % 2 != 0))) return false;   // q6_K: the decode product (row pairs) or the MFMA product
-    return w->ne[0] == x->ne[0] && w->ne[0] % (w->type == GGML_TYPE_F32 ? 4 : (w->type == GGML_TYPE_F16 ? 8 : ((w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) ? 256 : 32))) == 0;
+    return w->ne[0] == x->ne[0] && w->ne[0] % (w->type == GGML_TYPE_F32 ? 4 : (w->type == GGML_TYPE_F16 ? 8 : ((w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K) ? 256 : 32))) == 0;
 }
 // kq = mul_mat(k, q) and kqv = mul_mat(v, kq) of a -fa 0 graph: f16 views of the cache (permuted / transposed, broadcast over the query heads of a kv
 // head) against permuted f32 activations (/ref/src/llama-graph.cpp:1201-1230)

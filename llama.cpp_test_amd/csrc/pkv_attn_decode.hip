@@ -1175,22 +1175,7 @@ void launch_kernel(K kernel, dim3 grid, dim3 block, hipStream_t st, const Decode
     else              hipLaunchKernelGGL(kernel, grid, block, 0, st, da.block_table, da.seq_lens, da.max_blocks, da.bs_shift, da);
 }
 
-// Tiles per workgroup of the multi-tile form (1 = the single-tile form).  A launch of one 128-token tile per workgroup pays its fixed work — scalars, the Q
-// operand, the cross-wave merge, a partial, a share of the merge launch — once per 128 tokens; once the launch has more workgroups than CUs they only queue
-// behind each other.  Measured (profiles/r03_decode_tiles.txt, ms per step of all layers): 70B geometry ctx 16384 (1024 tiles) 1.99 at 1 tile per workgroup,
-// 1.86 at 2, 1.60 at 4 (= 256 workgroups), 2.24 at 8; 32 sequences x ctx 640: 0.657 -> 0.539 with one workgroup per (sequence, kv head) (no partials, no
-// merge launch); 32 x ctx 4096: 2.93 -> 2.82 (8 tiles) / 2.74 (32); q8_0 / q4_0 KV 32 x ctx 4096: 1.98 -> 1.86 / 1.84 -> 1.57 at 8 tiles (1024 4-wave workgroups).
-// Rule: about one 8-wave workgroup per CU, at most DECODE_MAX_TILES tiles each (the bound keeps one long sequence among short ones from serialising the launch).
-constexpr int DECODE_CUS = 256, DECODE_MAX_TILES = 8;
-inline int decode_tiles_per_wg(int n_splits, int n_head_kv, int n_seq) {
-    if (const char * e = getenv("PKV_DECODE_NTILE")) { const int v = atoi(e); if (v >= 1) return v < n_splits ? v : n_splits; }   // experiments
-    const long wg1 = (long) n_head_kv * n_seq * n_splits;
-    if (wg1 < 2 * DECODE_CUS) return 1;
-    long nt = (wg1 + DECODE_CUS / 2) / DECODE_CUS;
-    if (nt > DECODE_MAX_TILES) nt = DECODE_MAX_TILES;
-    if (nt > n_splits) nt = n_splits;
-    return (int) (nt < 1 ? 1 : nt);
-}
+// (decode_tiles_per_wg: pkv_common.h — host logic, shared with the C ABI's pkv_attn_decode_tiles and the sanitizer build)
 
 template <int D>
 void launch_combine(const DecodeArgs & da, int n_seq, hipStream_t st) {
@@ -1295,10 +1280,6 @@ int launch_v(const DecodeArgs & da, int VT, int D, int G, int n_seq, hipStream_t
 }
 
 }  // namespace
-
-int decode_tiles_for(int max_seq_len, int n_head_kv, int n_seq) {
-    return decode_tiles_per_wg((max_seq_len + WG_TOK - 1) / WG_TOK, n_head_kv, n_seq);
-}
 
 // [part_o f32 n_tok*n_head*ns*D][part_ml f32 n_tok*n_head*ns*2][tickets u32 n_tok*n_head][rope cache f32 n_tok*D, 16-byte aligned]
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len) {

@@ -577,7 +577,7 @@ int pkv_mul_mat(const void * w, int type_wf, const float * x, float * y, int64_t
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0 && packed_type_ok(type_wf), "pkv_mul_mat: bad arguments");
     const int type_w = type_wf & ~PKV_TYPE_PACKED;
-    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : ((type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K) ? 256 : PKV_QK))) == 0 &&
+    PKV_REQUIRE(K % (type_w == PKV_TYPE_F32 ? 4 : (type_w == PKV_TYPE_F16 ? 8 : ((type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q5_K || type_w == PKV_TYPE_Q6_K) ? 256 : PKV_QK))) == 0 &&
                 ((uintptr_t) x % 16) == 0 && ((uintptr_t) w % ((type_w == PKV_TYPE_Q8_0 || type_w == PKV_TYPE_Q6_K) ? 2 : 16)) == 0, "pkv_mul_mat: K / alignment not supported");
     return launch_mul_mat(w, type_wf, x, y, M, K, n_cols, (hipStream_t) stream);
 }
@@ -620,7 +620,7 @@ int pkv_get_rows(const void * w, int type_w, const int32_t * ids, float * out, i
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(w && ids && out && n_ids >= 0 && K > 0 && n_rows_w > 0, "pkv_get_rows: bad arguments");
     { const int bt = type_w & ~PKV_TYPE_PACKED;
-      PKV_REQUIRE(packed_type_ok(type_w) && K % (bt == PKV_TYPE_Q4_K || bt == PKV_TYPE_Q6_K ? 256 : (bt == PKV_TYPE_Q8_0 ? 32 : 1)) == 0, "pkv_get_rows: K does not fill whole blocks"); }
+      PKV_REQUIRE(packed_type_ok(type_w) && K % (bt == PKV_TYPE_Q4_K || bt == PKV_TYPE_Q5_K || bt == PKV_TYPE_Q6_K ? 256 : (bt == PKV_TYPE_Q8_0 ? 32 : 1)) == 0, "pkv_get_rows: K does not fill whole blocks"); }
     return launch_get_rows(w, type_w, ids, out, n_ids, K, n_rows_w, (hipStream_t) stream);
 }
 

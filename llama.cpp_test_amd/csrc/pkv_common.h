@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mi355_paged_kv.h"
 
@@ -41,6 +42,7 @@ __host__ __device__ inline size_t row_size(int type, int64_t ne) {
          : type == PKV_TYPE_Q8_0 ? (size_t) (ne / PKV_QK) * 34
          : type == PKV_TYPE_Q4_0 ? (size_t) (ne / PKV_QK) * 18
          : type == PKV_TYPE_Q4_K ? (size_t) (ne / 256) * 144
+         : type == PKV_TYPE_Q5_K ? (size_t) (ne / 256) * 176
          : type == PKV_TYPE_Q6_K ? (size_t) (ne / 256) * 210 : 0;
 }
 inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0; }
@@ -99,6 +101,28 @@ __device__ __forceinline__ float rms_scale(const double * block_sums, int n_bloc
 }
 #endif
 
+// ---- how a decode launch is cut into workgroups (host logic) ------------------------------------------
+// Tiles per workgroup of the multi-tile form (1 = the single-tile form).  A launch of one 128-token tile per workgroup pays its fixed work — scalars, the Q
+// operand, the cross-wave merge, a partial, a share of the merge launch — once per 128 tokens; once the launch has more workgroups than CUs they only queue
+// behind each other.  Measured (profiles/r03_decode_tiles.txt, ms per step of all layers): 70B geometry ctx 16384 (1024 tiles) 1.99 at 1 tile per workgroup,
+// 1.86 at 2, 1.60 at 4 (= 256 workgroups), 2.24 at 8; 32 sequences x ctx 640: 0.657 -> 0.539 with one workgroup per (sequence, kv head) (no partials, no
+// merge launch); 32 x ctx 4096: 2.93 -> 2.82 (8 tiles) / 2.74 (32); q8_0 / q4_0 KV 32 x ctx 4096: 1.98 -> 1.86 / 1.84 -> 1.57 at 8 tiles (1024 4-wave workgroups).
+// Rule: about one 8-wave workgroup per CU, at most DECODE_MAX_TILES tiles each (the bound keeps one long sequence among short ones from serialising the launch).
+constexpr int DECODE_CUS = 256, DECODE_MAX_TILES = 8, DECODE_TILE_TOKENS = 128;
+inline int decode_tiles_per_wg(int n_splits, int n_head_kv, int n_seq) {
+    if (const char * e = getenv("PKV_DECODE_NTILE")) { const int v = atoi(e); if (v >= 1) return v < n_splits ? v : n_splits; }   // experiments
+    const long wg1 = (long) n_head_kv * n_seq * n_splits;
+    if (wg1 < 2 * DECODE_CUS) return 1;
+    long nt = (wg1 + DECODE_CUS / 2) / DECODE_CUS;
+    if (nt > DECODE_MAX_TILES) nt = DECODE_MAX_TILES;
+    if (nt > n_splits) nt = n_splits;
+    return (int) (nt < 1 ? 1 : nt);
+}
+
+inline int decode_tiles_for(int max_seq_len, int n_head_kv, int n_seq) {   // pkv_attn_decode_tiles
+    return decode_tiles_per_wg((max_seq_len + DECODE_TILE_TOKENS - 1) / DECODE_TILE_TOKENS, n_head_kv, n_seq);
+}
+
 // ---- kernel launchers (pkv_kernels_*.hip) ---------------------------------------------------------
 struct RopeDev {  // pkv_rope_params resolved on the host (corr dims = ggml_rope_yarn_corr_dims, /ref/ggml/src/ggml.c:3739)
     int   n_dims, mode;
@@ -119,7 +143,6 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * rope_cache = nullptr);   // rope_cache: RoPE(Q) fused in (NORM pairs)
 int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
-int decode_tiles_for(int max_seq_len, int n_head_kv, int n_seq);   // tiles per workgroup the plain decode launch of this shape takes
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);
 void set_prefill_stamps(void * dev_u64);  // diagnostic
 int launch_k_shift(void * k_pool, int type_k, const int32_t * cell_block, const int32_t * cell_off,

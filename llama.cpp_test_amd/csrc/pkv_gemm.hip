@@ -77,6 +77,24 @@ template <> struct RawW<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> : RawW<PKV_TYPE_Q4_K>
     __device__ __forceinline__ void load(const unsigned char * row, int64_t k0, int64_t K) { const size_t gpr = (size_t) (K >> 6), g = (size_t) (k0 >> 6);   // group g = 4 b + (j >> 1)
         h = ldu(row + 32 * gpr + 16 * (g >> 2)); q[0] = ldu(row + 16 * g); q[1] = ldu(row + 16 * gpr + 16 * g); }
 };
+template <> struct RawW<PKV_TYPE_Q5_K> {   // block_q5_K (:291-308): header {d, dmin, scales[12]}, qh[32] (bit j of byte l = the fifth bit of element 32 j + l), qs[128] as q4_K
+    static constexpr int NLOADS = 5;
+    uint4 h, qh[2], q[2];
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0) { const unsigned char * p = row + (k0 >> 8) * 176; const int j = (int) (k0 & 255) >> 5;
+        h = ldu(p); qh[0] = ldu(p + 16); qh[1] = ldu(p + 32); q[0] = ldu(p + 48 + 32 * (j >> 1)); q[1] = ldu(p + 64 + 32 * (j >> 1)); }
+    __device__ __forceinline__ void to_half(_Float16 * o, int64_t k0) const {   // dequantize_row_q5_K (/ref/ggml/src/ggml-quants.c:1482-1507)
+        const int j = (int) (k0 & 255) >> 5;
+        const float d = hf((uint16_t) (h.x & 0xFFFF)), dmin = hf((uint16_t) (h.x >> 16));
+        const int sh = 8 * (j & 3);
+        const int b0 = (int) ((h.y >> sh) & 0xFF), b1 = (int) ((h.z >> sh) & 0xFF), b2 = (int) ((h.w >> sh) & 0xFF);   // get_scale_min_k4
+        const int sc = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4)), mn = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
+        const float d1 = d * (float) sc, m1 = dmin * (float) mn;
+        const unsigned char * b = reinterpret_cast<const unsigned char *>(q), * hb = reinterpret_cast<const unsigned char *>(qh);
+        const int s4 = 4 * (j & 1);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) o[i] = (_Float16) (d1 * (float) (((b[i] >> s4) & 0xF) | (((hb[i] >> j) & 1) << 4)) - m1);
+    }
+};
 template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 256, n = e0 / 128, j = (e0 % 128) / 32: ql[64 n + 32 (j & 1) + l] nibble j >> 1, qh[32 n + l] bits 2 j
     static constexpr int NLOADS = 6;
     uint4 ql[2], qh[2]; uint16_t sc2, d;
@@ -253,6 +271,19 @@ template <> struct Deq<PKV_TYPE_Q4_K> { static __device__ __forceinline__ void r
     const int s4 = 4 * (j & 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) cvt4((q[i] >> s4) & 0x0F0F0F0Fu, nb, d1, m1, ow[2 * i], ow[2 * i + 1]);
+} };
+template <> struct Deq<PKV_TYPE_Q5_K> { static __device__ __forceinline__ void run(const RawW<PKV_TYPE_Q5_K> & w, int64_t k0, uint4 * o) {
+    const int j = (int) (k0 & 255) >> 5;
+    const float d = hf((uint16_t) (w.h.x & 0xFFFF)), dmin = hf((uint16_t) (w.h.x >> 16));
+    const int sh = 8 * (j & 3);
+    const int b0 = (int) ((w.h.y >> sh) & 0xFF), b1 = (int) ((w.h.z >> sh) & 0xFF), b2 = (int) ((w.h.w >> sh) & 0xFF);   // get_scale_min_k4
+    const int sc = j < 4 ? (b0 & 63) : ((b2 & 0xF) | ((b0 >> 6) << 4)), mn = j < 4 ? (b1 & 63) : ((b2 >> 4) | ((b1 >> 6) << 4));
+    const h2v d1 = splat(d * (float) sc), m1 = splat(-(dmin * (float) mn)), nb = splat(-1024.0f);
+    const uint32_t * q = reinterpret_cast<const uint32_t *>(w.q), * hh = reinterpret_cast<const uint32_t *>(w.qh);
+    uint32_t * ow = reinterpret_cast<uint32_t *>(o);
+    const int s4 = 4 * (j & 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cvt4(((q[i] >> s4) & 0x0F0F0F0Fu) | (((hh[i] >> j) & 0x01010101u) << 4), nb, d1, m1, ow[2 * i], ow[2 * i + 1]);   // 5-bit quants 0..31
 } };
 template <> struct Deq<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> { static __device__ __forceinline__ void run(const RawW<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> & w, int64_t k0, uint4 * o) {
     Deq<PKV_TYPE_Q4_K>::run(w, k0, o); } };
@@ -682,8 +713,8 @@ __global__ void __launch_bounds__(256) cvt_f16_kernel(const float4 * __restrict_
 
 bool gemm_supported(int type_w, int64_t M, int64_t K) {
     type_w &= ~PKV_TYPE_PACKED;
-    if (type_w != PKV_TYPE_F16 && type_w != PKV_TYPE_Q8_0 && type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q6_K) return false;
-    return M > 0 && K > 0 && K % BK == 0 && (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K ? K % 256 == 0 : true);
+    if (type_w != PKV_TYPE_F16 && type_w != PKV_TYPE_Q8_0 && type_w != PKV_TYPE_Q4_K && type_w != PKV_TYPE_Q5_K && type_w != PKV_TYPE_Q6_K) return false;
+    return M > 0 && K > 0 && K % BK == 0 && (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q5_K || type_w == PKV_TYPE_Q6_K ? K % 256 == 0 : true);
 }
 
 // ---- per-stream scratch of the f16 activations (grown on demand; hipFree of the old buffer synchronises) ----
@@ -757,6 +788,7 @@ int launch_gemm2(GemmArgs & a, int type_w, int64_t n_cols, hipStream_t st, bool 
         case PKV_TYPE_F16:  PKV_GEMM2(PKV_TYPE_F16); break;
         case PKV_TYPE_Q8_0: PKV_GEMM2(PKV_TYPE_Q8_0); break;
         case PKV_TYPE_Q4_K: PKV_GEMM2(PKV_TYPE_Q4_K); break;
+        case PKV_TYPE_Q5_K: PKV_GEMM2(PKV_TYPE_Q5_K); break;
         case PKV_TYPE_Q6_K: PKV_GEMM2(PKV_TYPE_Q6_K); break;
         case PKV_TYPE_Q4_K | PKV_TYPE_PACKED: PKV_GEMM2((PKV_TYPE_Q4_K | PKV_TYPE_PACKED)); break;
         case PKV_TYPE_Q6_K | PKV_TYPE_PACKED: PKV_GEMM2((PKV_TYPE_Q6_K | PKV_TYPE_PACKED)); break;
@@ -772,7 +804,7 @@ int launch_gemm2(GemmArgs & a, int type_w, int64_t n_cols, hipStream_t st, bool 
 int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x, float * const * y, const int64_t * M, int64_t K, int64_t n_cols, hipStream_t st) {
     if (n_cols == 0) return PKV_OK;
     PKV_REQUIRE(n >= 1 && n <= GEMM_MAX, "pkv_mul_mat (batched): 1 to %d matrices per launch", GEMM_MAX);
-    if (!gemm_supported(type_w, 1, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
+    if (!gemm_supported(type_w, 1, K)) { set_error("pkv_mul_mat_batched: weight type %d / K %lld not supported (f16, q8_0, q4_K, q5_K, q6_K; K %% 64 == 0)", type_w, (long long) K); return PKV_ERR_UNSUPPORTED; }
     PKV_REQUIRE(((uintptr_t) x % 16) == 0, "pkv_mul_mat (batched): x must be 16-byte aligned");
     GemmArgs a = {};
     a.x = x; a.N = n_cols; a.K = K; a.row_bytes = (int64_t) row_size(type_w & ~PKV_TYPE_PACKED, K);
@@ -818,6 +850,7 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
         case PKV_TYPE_F16:  PKV_GEMM(PKV_TYPE_F16); break;
         case PKV_TYPE_Q8_0: PKV_GEMM(PKV_TYPE_Q8_0); break;
         case PKV_TYPE_Q4_K: PKV_GEMM(PKV_TYPE_Q4_K); break;
+        case PKV_TYPE_Q5_K: PKV_GEMM(PKV_TYPE_Q5_K); break;
         case PKV_TYPE_Q6_K: PKV_GEMM(PKV_TYPE_Q6_K); break;
         case PKV_TYPE_Q4_K | PKV_TYPE_PACKED: PKV_GEMM((PKV_TYPE_Q4_K | PKV_TYPE_PACKED)); break;
         case PKV_TYPE_Q6_K | PKV_TYPE_PACKED: PKV_GEMM((PKV_TYPE_Q6_K | PKV_TYPE_PACKED)); break;

@@ -586,6 +586,20 @@ __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int
             const float d1 = d * (float) sc, m1 = dmin * (float) mn;         // f32 products, as the reference forms them
             o[k] = d1 * (float) q - m1;
         }
+    } else if constexpr (T == PKV_TYPE_Q5_K) {      // dequantize_row_q5_K (:1482-1507)
+        for (int64_t k = threadIdx.x; k < K; k += 256) {
+            const unsigned char * b = row + (size_t) (k >> 8) * 176;
+            const int e = (int) (k & 255), j = e >> 5, l = e & 31;
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(b)), dmin = h2f(*reinterpret_cast<const uint16_t *>(b + 2));
+            auto s = [&](int i) -> int { return (int) b[4 + i]; };
+            int sc, mn;
+            if (j < 4) { sc = s(j) & 63; mn = s(j + 4) & 63; }
+            else       { sc = (s(j + 4) & 0xF) | ((s(j - 4) >> 6) << 4); mn = (s(j + 4) >> 4) | ((s(j) >> 6) << 4); }
+            const unsigned char qb = b[48 + 32 * (j >> 1) + l];
+            const int q = ((j & 1) ? (qb >> 4) : (qb & 0xF)) + (((b[16 + l] >> j) & 1) ? 16 : 0);
+            const float d1 = d * (float) sc, m1 = dmin * (float) mn;
+            o[k] = d1 * (float) q - m1;
+        }
     } else {                                         // q6_K: dequantize_row_q6_K (:1690-1719)
         for (int64_t k = threadIdx.x; k < K; k += 256) {
             const size_t b = (size_t) (k >> 8) * 210;
@@ -703,6 +717,7 @@ int launch_get_rows(const void * w, int type_w, const int32_t * ids, float * out
         case PKV_TYPE_F16:  hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_F16>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;
         case PKV_TYPE_Q8_0: hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_Q8_0>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;
         case PKV_TYPE_Q4_K: hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_Q4_K>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;
+        case PKV_TYPE_Q5_K: hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_Q5_K>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;
         case PKV_TYPE_Q6_K: hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_Q6_K>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;
         default: set_error("pkv_get_rows: type %d not supported", type_w); return PKV_ERR_UNSUPPORTED;
     }

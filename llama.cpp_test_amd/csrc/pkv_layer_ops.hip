@@ -586,7 +586,7 @@ int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64
         return launch_gemv(g, st);
     }
     const int bt = type_w & ~PKV_TYPE_PACKED;                        // plane-layout rows (pkv_wlayout.h) keep the base type's row size
-    if ((n_cols >= GEMM_MIN_COLS || bt == PKV_TYPE_Q6_K) && gemm_supported(type_w, M, K)) return launch_gemm(w, type_w, x, y, M, K, n_cols, st);
+    if ((n_cols >= GEMM_MIN_COLS || bt == PKV_TYPE_Q6_K || bt == PKV_TYPE_Q5_K) && gemm_supported(type_w, M, K)) return launch_gemm(w, type_w, x, y, M, K, n_cols, st);
     const int rows_wg = bt == PKV_TYPE_Q4_K ? 4 * Q4K_ROWS : 4;
     const dim3 grid((unsigned) ((M + rows_wg - 1) / rows_wg));
     const size_t rb = row_size(bt, K);

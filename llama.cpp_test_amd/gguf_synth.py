@@ -23,8 +23,8 @@ T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I6
 _SCALAR = {T_U8: "<B", T_I8: "<b", T_U16: "<H", T_I16: "<h", T_U32: "<I", T_I32: "<i", T_F32: "<f", T_BOOL: "<?", T_U64: "<Q",
            T_I64: "<q", T_F64: "<d"}
 # ggml_type ids used here (/root/reference/ggml/include/ggml.h:351-392)
-GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0, GGML_Q4_K, GGML_Q6_K = 0, 1, 2, 8, 12, 14
-_BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144), GGML_Q6_K: (256, 210)}   # (elements, bytes) per block
+GGML_F32, GGML_F16, GGML_Q4_0, GGML_Q8_0, GGML_Q4_K, GGML_Q5_K, GGML_Q6_K = 0, 1, 2, 8, 12, 13, 14
+_BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_Q4_0: (32, 18), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144), GGML_Q5_K: (256, 176), GGML_Q6_K: (256, 210)}   # (elements, bytes) per block
 
 
 def row_bytes(t: int, ne0: int) -> int:
@@ -74,6 +74,37 @@ def random_q4_K(rng, n_rows: int, ne0: int) -> bytes:
     out[:, 4:16] = rng.integers(0, 256, (nb, 12), dtype=np.uint8)
     out[:, 16:] = rng.integers(0, 256, (nb, 128), dtype=np.uint8)
     return out.tobytes()
+
+
+def random_q5_K(rng, n_rows: int, ne0: int) -> bytes:
+    """random but well-formed block_q5_K rows (/root/reference/ggml/src/ggml-common.h:291-308: d, dmin, scales[12], qh[32], qs[128]): dequantized values
+    d * sc * q - dmin * m with q in 0..31 (dequantize_row_q5_K) look like N(0, 1/ne0) weights"""
+    nb = n_rows * (ne0 // 256)
+    out = np.empty((nb, 176), np.uint8)
+    d = (rng.uniform(0.7, 1.3, nb) / (np.sqrt(ne0) * 290.0)).astype(np.float16)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    out[:, 2:4] = (d.astype(np.float32) * 15.5).astype(np.float16).view(np.uint8).reshape(nb, 2)   # dmin * E[m] cancels d * E[sc] * E[q]
+    out[:, 4:] = rng.integers(0, 256, (nb, 172), dtype=np.uint8)
+    return out.tobytes()
+
+
+def dequantize_q5_K(raw, ne0: int) -> np.ndarray:
+    """dequantize_row_q5_K (/root/reference/ggml/src/ggml-quants.c:1482-1507) in numpy: rows of ne0 f32"""
+    b = np.frombuffer(raw, np.uint8).reshape(-1, 176)
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)[:, 0]
+    dmin = b[:, 2:4].copy().view(np.float16).astype(np.float32)[:, 0]
+    sc, qh, qs = b[:, 4:16].astype(np.int32), b[:, 16:48].astype(np.int32), b[:, 48:]
+    out = np.empty((b.shape[0], 256), np.float32)
+    for j in range(8):                                            # get_scale_min_k4
+        if j < 4:
+            s_, m_ = sc[:, j] & 63, sc[:, j + 4] & 63
+        else:
+            s_, m_ = (sc[:, j + 4] & 0xF) | ((sc[:, j - 4] >> 6) << 4), (sc[:, j + 4] >> 4) | ((sc[:, j] >> 6) << 4)
+        q = qs[:, 32 * (j // 2):32 * (j // 2) + 32].astype(np.int32)
+        q = ((q & 0xF) if j % 2 == 0 else (q >> 4)) + (((qh >> j) & 1) << 4)
+        d1, m1 = d * s_.astype(np.float32), dmin * m_.astype(np.float32)                       # f32 products, as the reference
+        out[:, 32 * j:32 * j + 32] = d1[:, None] * q.astype(np.float32) - m1[:, None]
+    return out.reshape(-1, ne0)
 
 
 def random_q6_K(rng, n_rows: int, ne0: int) -> bytes:
@@ -226,15 +257,15 @@ def synth_llama(path: str, *, n_layer: int, n_embd: int, n_head: int, n_head_kv:
         return il < n_layer // 8 or il >= 7 * n_layer // 8 or (il - n_layer // 8) % 3 == 2
 
     def mat(nm, ne0, ne1, q6=False):            # ggml [ne0 = in, ne1 = out]; numpy array [ne1][ne0]
-        if wtype == GGML_Q4_K and ne0 % 256 == 0:
-            t = GGML_Q6_K if (k_mix and q6) else GGML_Q4_K
+        if wtype in (GGML_Q4_K, GGML_Q5_K) and ne0 % 256 == 0:     # (wtype q5_K + k_mix: the tensor mix of a Q5_K_M file, same rule with q5_K as the base type)
+            t = GGML_Q6_K if (k_mix and q6) else wtype
             if quantize is not None:
                 w = (rng.standard_normal((ne1, ne0)) / np.sqrt(ne0)).astype(np.float32)
                 tensors.append((nm, (ne0, ne1), t, bytes(quantize(t, w))))
             else:
-                tensors.append((nm, (ne0, ne1), t, (random_q6_K if t == GGML_Q6_K else random_q4_K)(rng, ne1, ne0)))
+                tensors.append((nm, (ne0, ne1), t, {GGML_Q6_K: random_q6_K, GGML_Q5_K: random_q5_K, GGML_Q4_K: random_q4_K}[t](rng, ne1, ne0)))
             return
-        t = GGML_F16 if wtype == GGML_Q4_K else wtype          # rows that are not a multiple of 256 stay f16
+        t = GGML_F16 if wtype in (GGML_Q4_K, GGML_Q5_K) else wtype          # rows that are not a multiple of 256 stay f16
         w = (rng.standard_normal((ne1, ne0)) / np.sqrt(ne0)).astype(np.float32)
         tensors.append((nm, (ne0, ne1), t, encode(w, t)))
 

@@ -4,6 +4,7 @@ compiled (this container) — elsewhere tests use the fixtures tests/golden/make
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -40,10 +41,19 @@ def gguf_write_demo(path: str) -> None:
         raise RuntimeError("gguf_write_to_file failed")
 
 
+_loaded_backends = set()
+
+
 def load_backend(so_path: str) -> None:
-    """register a ggml-backend plugin with the reference's registry (ggml_backend_load = what GGML_BACKEND_PATH triggers)"""
+    """register a ggml-backend plugin with the reference's registry (ggml_backend_load = what GGML_BACKEND_PATH triggers).  Once per process and path: every
+    ggml_backend_load registers the plugin's device AGAIN, and llama_context hands all registered devices to ggml_backend_sched_new, which asserts at
+    GGML_SCHED_MAX_BACKENDS = 16 (/root/reference/ggml/src/ggml-backend.cpp) — the sixteenth test of a file that loads the plugin per test aborted there."""
+    key = os.path.realpath(so_path)
+    if key in _loaded_backends:
+        return
     if _lib().refmodel_load_backend(so_path.encode()) != 0:
         raise RuntimeError(f"ggml_backend_load({so_path}) failed")
+    _loaded_backends.add(key)
 
 
 def set_defrag_thold(t: float) -> None:

@@ -59,6 +59,17 @@ def test_q4_K_blocks_dequantize_like_the_reference(G, O):
     assert np.array_equal(mine, ref) and 0.5 / 32 < mine.std() < 2.0 / 32
 
 
+def test_q5_K_blocks_dequantize_like_the_reference(G, O):
+    """block_q5_K (Q5_K_M files; r03): dequantize_row_q5_K bit for bit"""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built")
+    O.ref_rope(np.zeros((1, 1, 64), np.float32), np.zeros(1, np.int32), n_dims=64)
+    raw = G.random_q5_K(np.random.default_rng(5), 5, 1024)
+    mine = G.dequantize_q5_K(raw, 1024)
+    ref = O.ref_to_float(13, np.frombuffer(raw, np.uint8).reshape(5, -1), 1024)
+    assert np.array_equal(mine, ref) and 0.5 / 32 < mine.std() < 2.0 / 32
+
+
 def test_q6_K_blocks_dequantize_like_the_reference(G, O):
     """the same for block_q6_K (what a Q4_K_M file keeps attn_v / ffn_down / output in): dequantize_row_q6_K bit for bit"""
     if not O.ref_available():

@@ -176,18 +176,18 @@ def test_strided_cpy_and_mul_mat(pkv):
     assert np.abs(kqv.cpu().numpy() - ref2).max() <= 1e-5
 
 
-@pytest.mark.parametrize("tname", ["f16", "q8_0", "q4_K", "q6_K"])
+@pytest.mark.parametrize("tname", ["f16", "q8_0", "q4_K", "q5_K", "q6_K"])
 def test_mul_mat_batched_mfma(pkv, O, tname):
     """pkv_mul_mat with many activation columns (prompt processing) = the MFMA product of csrc/pkv_gemm.hip: weight tiles dequantized to f16 once per 128
     columns, activations rounded to f16, f32 accumulation.  Against f64 arithmetic on the same stored weights: NMSE far inside the harness bar (5e-4),
     every element within the f16 rounding of the activations; ragged M / N (tiles past the end), and the single-column / few-column paths agree with it."""
     from llama_cpp_test_amd import gguf_synth as G
-    t = {"f16": 1, "q8_0": 8, "q4_K": 12, "q6_K": 14}[tname]
+    t = {"f16": 1, "q8_0": 8, "q4_K": 12, "q5_K": 13, "q6_K": 14}[tname]
     rng = np.random.default_rng(100 + t)
     for M, K, N in [(256, 512, 16), (384, 4096, 200), (130, 1024, 129), (1024, 2048, 512)]:
-        if t in (12, 14):
-            raw = (G.random_q4_K if t == 12 else G.random_q6_K)(rng, M, K)
-            wb, wd = np.frombuffer(raw, np.uint8).copy(), (G.dequantize_q4_K if t == 12 else G.dequantize_q6_K)(raw, K).astype(np.float64).reshape(M, K)
+        if t in (12, 13, 14):
+            raw = {12: G.random_q4_K, 13: G.random_q5_K, 14: G.random_q6_K}[t](rng, M, K)
+            wb, wd = np.frombuffer(raw, np.uint8).copy(), {12: G.dequantize_q4_K, 13: G.dequantize_q5_K, 14: G.dequantize_q6_K}[t](raw, K).astype(np.float64).reshape(M, K)
         else:
             w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
             wb = O.from_float(t, w, variant="ref") if t == 8 else O.from_float(t, w)
@@ -202,3 +202,20 @@ def test_mul_mat_batched_mfma(pkv, O, tname):
         if M % 2 == 0:
             y1 = pkv.mul_mat(dev(np.ascontiguousarray(wb).reshape(-1)), t, M, K, dev(x[:1].copy())).cpu().numpy()
             assert float(((y1 - ref[:1]) ** 2).sum() / (ref[:1] ** 2).sum()) <= 5e-4
+
+
+def test_q5_K_get_rows_and_single_column(pkv):
+    """block_q5_K weights (r03): pkv_get_rows = dequantize_row_q5_K exactly; one activation column goes through the MFMA product as well (no decode-step kernel for
+    this type yet): within the f16 rounding of the column of f64 arithmetic on the same stored weights"""
+    from llama_cpp_test_amd import gguf_synth as G
+    rng = np.random.default_rng(13)
+    n_rows, K = 300, 1024
+    raw = G.random_q5_K(rng, n_rows, K)
+    w = dev(np.frombuffer(raw, np.uint8).copy())
+    ids = np.array([5, 0, 299, 5, 17, 123], np.int32)
+    got = pkv.get_rows(w, 13, dev(ids), K, n_rows).cpu().numpy()
+    assert np.array_equal(got, G.dequantize_q5_K(raw, K)[ids])
+    x = rng.standard_normal((1, K)).astype(np.float32)
+    y = pkv.mul_mat(w, 13, n_rows, K, dev(x)).cpu().numpy()
+    ref = x.astype(np.float64) @ G.dequantize_q5_K(raw, K).astype(np.float64).T
+    assert float(((y - ref) ** 2).sum() / (ref ** 2).sum()) <= 2e-6

@@ -29,12 +29,15 @@ MODELS = {
     # K and V in a side buffer, gate / up in one launch) at prefill widths and at decode
     "llama3_q4k": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=79,
                        rope_freqs=True, wtype=12),
+    # ... and with the tensor mix of a Q5_K_M file (q5_K + q6_K; r03): every q5_K product, one column or many, through the MFMA product
+    "llama3_q5km": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=80,
+                        rope_freqs=True, wtype=13, k_mix=True),
 }
 
 
 @pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
 @pytest.mark.parametrize("tk", [1, 8])
-@pytest.mark.parametrize("model", ["tiny", "llama3", "llama3_q4k"])
+@pytest.mark.parametrize("model", ["tiny", "llama3", "llama3_q4k", "llama3_q5km"])
 def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
     from llama_cpp_test_amd import gguf_synth as G
     MODEL = MODELS[model]
@@ -90,11 +93,11 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
             # amplify that rounding difference — measured 2e-4 (layer 0) .. 3.4e-3 (layer 1) with f16 KV, up to 1.6e-2 with q8_0 KV, with
             # or without the merged launches (bit-identical, checked above).  For this model the comparison with the CPU run is a sanity
             # bound; the product itself is held to 1e-4 / exact int8 arithmetic in tests/test_gpu_layer_ops.py and to the harness bar.
-            assert nmse(b, a) <= (5e-2 if MODEL.get("wtype") == 12 else 5e-4), (ci, il)
+            assert nmse(b, a) <= (5e-2 if MODEL.get("wtype") in (12, 13) else 5e-4), (ci, il)
         # Q8_0 weights: the CPU backend rounds the activations to q8_0 before every product (0.4 % of the block maximum per
         # element, 14 products deep), the device keeps them in f32: the runs differ by the CPU path's own quantization noise
         # (Q4_K weights: q8_K activations of 256 on the CPU, int8 per 32 on the device — same kind of difference)
-        bar = 2e-2 if MODEL.get("wtype") == 12 else (2e-3 if MODEL.get("wtype") == 8 else (1e-4 if tk == 1 else 5e-4))
+        bar = 2e-2 if MODEL.get("wtype") in (12, 13) else (2e-3 if MODEL.get("wtype") == 8 else (1e-4 if tk == 1 else 5e-4))
         if os.environ.get("PKV_PRINT_NMSE"):
             print("call", ci, "logits nmse %.3e" % nmse(logit_g, logit_c), flush=True)
             continue
