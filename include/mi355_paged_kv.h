@@ -437,7 +437,7 @@ int pkv_gemv_q(const pkv_gemv * g, void * stream);
 #define PKV_TYPE_PACKED 0x100
 int pkv_weights_pack(const void * src, void * dst, int type, int64_t n_rows, int64_t K, int inverse, void * stream);
 /* ggml_get_rows (/ref/src/llama-model.cpp:4047: inp_embd = get_rows(tok_embd, tokens)): out[i][:] = dequantize(row ids[i] of w);
- * w = n_rows_w rows of K elements in f32 / f16 / q8_0 / q4_K / q6_K; ids device i32 [n_ids]; out device f32 [n_ids][K] */
+ * w = n_rows_w rows of K elements in f32 / f16 / q8_0 / q4_K / q5_K / q6_K; ids device i32 [n_ids]; out device f32 [n_ids][K] */
 int pkv_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, void * stream);
 
 /* Session state of the KV cache in the reference's byte format: llama_kv_cache_unified::state_write / state_read
