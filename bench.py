@@ -526,8 +526,7 @@ def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps, p
         n = len(seq_ids)
         plan = r.plan(seq_ids, poss)
         qq, oo = (qp, outp) if prompt else (q, out)
-        for il in range(L):
-            r.layer(il, plan, qq[il][:n], k[il][:n], v[il][:n], oo[il][:n])
+        r.layers(plan, [x[:n] for x in qq], [x[:n] for x in k], [x[:n] for x in v], [x[:n] for x in oo])   # all layers in one trip through the binding (pkv_attn_step_layers)
     spp, stg = [], []
     for rep in range(reps + 1):
         r.clear()
@@ -551,7 +550,7 @@ def batched_bench_record(pkv, torch, *, npl, npp, ntg, n_batch, kv_type, reps, p
     torch.cuda.empty_cache()
     sd = lambda a: round(float(np.std(a, ddof=1)), 1) if len(a) > 1 else 0.0   # noqa: E731
     return {"S_PP": round(float(np.mean(spp)), 1), "S_PP_stdev": sd(spp), "S_TG": round(float(np.mean(stg)), 1), "S_TG_stdev": sd(stg), "unit": "tok/s", "repetitions": reps,
-            "workload": f"batched-bench semantics, B={npl} PP={npp} TG={ntg} n_batch={n_batch}, {kv_type} KV, attention path of all {L} layers, host block manager in the loop, eager launches"
+            "workload": f"batched-bench semantics, B={npl} PP={npp} TG={ntg} n_batch={n_batch}, {kv_type} KV, attention path of all {L} layers, host block manager in the loop, eager launches (one call into the library per ubatch: pkv_attn_step_layers)"
                         + (", prompt ubatches with f16 Q in / f16 O out" if pp_f16 else "")}
 
 

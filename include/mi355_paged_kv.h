@@ -242,6 +242,14 @@ int pkv_attn_decode_step(const pkv_attn_args * args, const pkv_step_args * step,
  * (2/3 of that call's traffic).  step->rope_cache (pkv_rope_cache rows of the ubatch's tokens, computed once per ubatch and shared by all layers)
  * is REQUIRED with rope; step->pos is still read by the K rotation.  PKV_ERR_UNSUPPORTED for NEOX pairs (use the two calls). */
 int pkv_attn_prefill_step(const pkv_attn_args * args, const pkv_step_args * step, const int32_t * slot_block, const int32_t * slot_off, void * stream);
+/* One ubatch through ALL layers in one call (r03): the per-layer loop of llm_build_llama's attention block (/ref/src/llama-model.cpp:4066-4110) as the host
+ * side runs it — pkv_attn_decode_step (slot_block == NULL: one token per sequence) or pkv_attn_prefill_step (slot_block / slot_off given) for layer
+ * l = 0 .. n_layer - 1 with args / step as given except the per-layer pointers: q[l] / k_cur[l] / v_cur[l] / out[l] (device tensors of that layer) and
+ * k_pool[l] / v_pool[l].  Same launches, same results; one trip through the binding instead of n_layer (a Python caller spends ~18 us per call: at 32
+ * layers that is the whole 0.6 ms of a 32-sequence decode step).  Stops at the first error. */
+int pkv_attn_step_layers(const pkv_attn_args * args, const pkv_step_args * step, int n_layer, const void * const * q, const void * const * k_cur,
+                         const void * const * v_cur, void * const * out, const void * const * k_pool, const void * const * v_pool,
+                         const int32_t * slot_block, const int32_t * slot_off, void * stream);
 /* DIAGNOSTIC build of the decode-step kernel with in-kernel phase stamps (f16 KV, head_dim 128, gqa 4 / 8; the two-launch step):
  * same arguments as pkv_attn_decode_step; `stamps` = device u64 [n_workgroups][8 waves][PKV_DECODE_NSTAMP], workgroup index
  * (seq * n_head_kv + kv_head) * n_splits + split.  Slots: 0 = s_memrealtime (100 MHz) at entry, 1..10 = s_memtime (shader clock) at

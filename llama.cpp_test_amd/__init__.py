@@ -338,6 +338,29 @@ class KernelTimer:
         self.ev = []
 
 
+def attn_step_layers(q, k_cur, v_cur, out, k_pools, v_pools, pos, rope, block_table, seq_lens, *, rope_cache, n_head_kv, type_k, type_v, block_size, scale,
+                     max_seq_len, workspace, q_start=None, max_q_per_seq=1, slot_block=None, slot_off=None, stream=None, flags=0):
+    """pkv_attn_step_layers: one ubatch through all layers in ONE call — attn_decode_step per layer (slot_block None) or attn_prefill_step per layer.
+    q / k_cur / v_cur / out: lists of per-layer device tensors (same shapes and strides in every layer); k_pools / v_pools: lists of per-layer pools."""
+    import torch
+    L = len(q)
+    n_tok, n_head, D = q[0].shape
+    n_seq, max_blocks = block_table.shape
+    if q[0].dtype == torch.float16:
+        flags |= ATTN_Q_F16
+    if out[0].dtype == torch.float16:
+        flags |= ATTN_OUT_F16
+    a = AttnArgs(_ptr(q[0]), q[0].stride(0), q[0].stride(1), _ptr(out[0]), _ptr(k_pools[0]), _ptr(v_pools[0]), _ptr(block_table),
+                 _ptr(seq_lens), _ptr(q_start), None, None, _ptr(workspace), workspace.numel(),
+                 n_seq, n_tok, max_q_per_seq, n_head, n_head_kv, D, block_size, max_blocks, type_k, type_v,
+                 scale, 0.0, max_seq_len, flags, None, 0, 0.0, None, None, None)
+    st = StepArgs(_ptr(k_cur[0]), _ptr(v_cur[0]), _ptr(pos), C.pointer(rope) if rope is not None else None, _ptr(rope_cache))
+    arr = lambda ts: (C.c_void_p * L)(*[_ptr(t) for t in ts])   # noqa: E731
+    check(lib().pkv_attn_step_layers(C.byref(a), C.byref(st), L, arr(q), arr(k_cur), arr(v_cur), arr(out), arr(k_pools), arr(v_pools),
+                                     C.c_void_p(_ptr(slot_block)), C.c_void_p(_ptr(slot_off)), C.c_void_p(_stream(stream))))
+    return out
+
+
 def attn_prefill(q, k_pool, v_pool, block_table, seq_lens, q_start, **kw):
     """Paged causal prefill (many query tokens per sequence); q f32 [n_tok][n_head][D]."""
     return _attn(lib().pkv_attn_prefill, q, k_pool, v_pool, block_table, seq_lens, q_start=q_start, **kw)

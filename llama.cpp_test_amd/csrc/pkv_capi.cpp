@@ -229,6 +229,23 @@ int pkv_attn_decode_step(const pkv_attn_args * args, const pkv_step_args * step,
     return launch_attn_decode(*args, (hipStream_t) stream, step);
 }
 
+int pkv_attn_step_layers(const pkv_attn_args * args, const pkv_step_args * step, int n_layer, const void * const * q, const void * const * k_cur,
+                         const void * const * v_cur, void * const * out, const void * const * k_pool, const void * const * v_pool,
+                         const int32_t * slot_block, const int32_t * slot_off, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args && step && n_layer >= 0 && q && k_cur && v_cur && out && k_pool && v_pool, "pkv_attn_step_layers: null argument");
+    PKV_REQUIRE((slot_block == nullptr) == (slot_off == nullptr), "pkv_attn_step_layers: slot_block and slot_off come together");
+    for (int l = 0; l < n_layer; ++l) {
+        pkv_attn_args a = *args;
+        pkv_step_args s = *step;
+        a.q = (const float *) q[l]; a.out = (float *) out[l]; a.k_pool = k_pool[l]; a.v_pool = v_pool[l];
+        s.k_cur = (const float *) k_cur[l]; s.v_cur = (const float *) v_cur[l];
+        const int rc = slot_block ? pkv_attn_prefill_step(&a, &s, slot_block, slot_off, stream) : pkv_attn_decode_step(&a, &s, stream);
+        if (rc != PKV_OK) return rc;
+    }
+    return PKV_OK;
+}
+
 int pkv_attn_decode_stamps(const pkv_attn_args * args, const pkv_step_args * step, uint64_t * stamps, int mode, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(args != nullptr && step != nullptr && stamps != nullptr, "pkv_attn_decode_stamps: null args");

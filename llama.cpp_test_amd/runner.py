@@ -18,7 +18,7 @@ from typing import List, Sequence
 import numpy as np
 
 from . import (ATTN_NONCAUSAL, PagedKVCache, PkvError, RopeParams, attn_decode, attn_decode_step, attn_prefill,  # noqa: F401
-               attn_prefill_step, attn_prefill_workspace_bytes, attn_workspace, qkv_prepare, rope_cache, rope_params)
+               attn_prefill_step, attn_prefill_workspace_bytes, attn_step_layers, attn_workspace, qkv_prepare, rope_cache, rope_params)
 
 
 class AttnPathRunner:
@@ -99,10 +99,17 @@ class AttnPathRunner:
         for a in parts:
             offs.append(tot)
             tot += -(-a.size // 4) * 4                               # 16-byte aligned pieces
-        host = np.zeros(tot, np.int32)
+        # ... from PINNED host memory, asynchronously: a pageable source makes the copy a synchronisation point of the stream — the host then builds the next ubatch's
+        # tables and starts its launches only after the previous ubatch has drained.  With all layers of a ubatch behind ONE call into the library (layers()) the
+        # host is a fraction of a decode step ahead of the device instead.  A small ring of pinned buffers, each guarded by the event of the copy that last read it.
+        slot = self._pin_slot(tot)
+        host = slot["np"]
+        host[:tot] = 0
         for a, o in zip(parts, offs):
             host[o:o + a.size] = a
-        dall = torch.from_numpy(host).cuda()
+        dall = torch.empty(tot, dtype=torch.int32, device="cuda")
+        dall.copy_(slot["t"][:tot], non_blocking=True)
+        slot["ev"].record()
         d_blk, d_off, dpos, d_sl, d_qs, d_bt = (dall[o:o + a.size] for a, o in zip(parts, offs))
         return dict(n_tok=n_tok, n_seq=len(seqs), max_q=int(n_q.max()), all_decode=all_decode,
                     max_seq_len=int(sl.max()), slot_block=d_blk, slot_off=d_off, pos=dpos, block_table=d_bt.view(bt.shape[0], bt.shape[1]),
@@ -110,6 +117,23 @@ class AttnPathRunner:
                     # ggml_rope_cache_init once per ubatch, shared by every layer's fused decode step
                     # ggml_rope_cache_init once per ubatch, shared by every layer's fused step (decode: attn_decode_step; prefill, NORM pairs: attn_prefill_step)
                     rope_cache=rope_cache(dpos, self.rope, self.D) if (with_rope_cache and (all_decode or self.fused_prefill)) else None)
+
+    def _pin_slot(self, n: int):
+        torch = self.torch
+        ring = getattr(self, "_pins", None)
+        if ring is None:
+            ring = self._pins = {"i": 0, "slots": []}
+        if len(ring["slots"]) < 8:
+            t = torch.empty(max(4096, 2 * n), dtype=torch.int32).pin_memory()
+            ring["slots"].append({"t": t, "np": t.numpy(), "ev": torch.cuda.Event()})
+            return ring["slots"][-1]
+        ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+        sl = ring["slots"][ring["i"]]
+        sl["ev"].synchronize()                                   # the copy that read this buffer eight plans ago
+        if sl["t"].numel() < n:
+            t = torch.empty(2 * n, dtype=torch.int32).pin_memory()
+            sl["t"], sl["np"] = t, t.numpy()
+        return sl
 
     def layer(self, il: int, plan, q, k_cur, v_cur, out=None):
         """device half, one layer: q f32 [n_tok][n_head][D], k_cur/v_cur f32 [n_tok][n_head_kv][D], all un-rotated.
@@ -132,6 +156,21 @@ class AttnPathRunner:
                     slot_off=plan["slot_off"], block_size=self.BS, pos=plan["pos"], rope=self.rope)
         return attn_prefill(q, c.k_pool(il), c.v_pool(il), plan["block_table"], plan["seq_lens"], plan["q_start"],
                             max_q_per_seq=plan["max_q"], **kw)
+
+    def layers(self, plan, q: List, k_cur: List, v_cur: List, out: List):
+        """device half, ALL layers of a planned ubatch in one trip through the binding (pkv_attn_step_layers: the fused decode step, or the fused prefill step, per
+        layer — what layer() launches, without n_layer Python calls of ~18 us each).  Falls back to layer() where the fused steps do not apply."""
+        fused = plan["rope_cache"] is not None and (plan["all_decode"] or self.fused_prefill)
+        if not fused:
+            return [self.layer(il, plan, q[il], k_cur[il], v_cur[il], out[il]) for il in range(self.L)]
+        c = self.cache
+        if getattr(self, "_pools", None) is None:
+            self._pools = ([c.k_pool(il) for il in range(self.L)], [c.v_pool(il) for il in range(self.L)])
+        pre = not plan["all_decode"]
+        return attn_step_layers(q, k_cur, v_cur, out, self._pools[0], self._pools[1], plan["pos"], self.rope, plan["block_table"], plan["seq_lens"],
+                                rope_cache=plan["rope_cache"], n_head_kv=self.HK, type_k=self.tk, type_v=self.tv, block_size=self.BS, scale=self.scale,
+                                max_seq_len=plan["max_seq_len"], workspace=self.ws, q_start=plan["q_start"] if pre else None, max_q_per_seq=plan["max_q"] if pre else 1,
+                                slot_block=plan["slot_block"] if pre else None, slot_off=plan["slot_off"] if pre else None)
 
     def decode(self, seq_id, pos, q: List, k_cur: List, v_cur: List, out: List | None = None):
         """one ubatch through all layers; q/k_cur/v_cur: per-layer device tensors"""

@@ -11,7 +11,8 @@ from llama_cpp_test_amd.runner import AttnPathRunner
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--npl", type=int, default=32); ap.add_argument("--npp", type=int, default=512); ap.add_argument("--ntg", type=int, default=128)
-ap.add_argument("--n-batch", type=int, default=2048); ap.add_argument("--kv-type", default="f16"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--pp-f16", action="store_true", help="prompt ubatches hand Q over / take O back as f16 (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16)")
+ap.add_argument("--n-batch", type=int, default=2048); ap.add_argument("--kv-type", default="f16"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--per-layer", action="store_true", help="one call into the library per layer (r02) instead of pkv_attn_step_layers per ubatch")
+ap.add_argument("--pp-f16", action="store_true", help="prompt ubatches hand Q over / take O back as f16 (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16)")
 ap.add_argument("--graph", action="store_true", help="AttnPathRunner.decode_captured: one cached hipGraph per ubatch shape instead of per-layer launches (measured: no faster, the GPU is the bound)")
 a = ap.parse_args()
 L, H, HK, D, BS = 32, 32, 8, 128, 128
@@ -35,8 +36,11 @@ def run(seq_ids, poss, prompt=False):
         r.decode_captured(seq_ids, poss, [x[:n] for x in qq], [x[:n] for x in k], [x[:n] for x in v], [x[:n] for x in oo])
         return
     plan = r.plan(seq_ids, poss)
-    for il in range(L):
-        r.layer(il, plan, qq[il][:n], k[il][:n], v[il][:n], oo[il][:n])
+    if a.per_layer:
+        for il in range(L):
+            r.layer(il, plan, qq[il][:n], k[il][:n], v[il][:n], oo[il][:n])
+    else:
+        r.layers(plan, [x[:n] for x in qq], [x[:n] for x in k], [x[:n] for x in v], [x[:n] for x in oo])
 
 res = []
 for rep in range(a.reps + 1):
@@ -54,4 +58,4 @@ for rep in range(a.reps + 1):
         res.append((t1 - t0, t2 - t1))
 tpp, ttg = np.median([x[0] for x in res]), np.median([x[1] for x in res])
 print(f"{a.kv_type}{' (prompt Q / O f16)' if a.pp_f16 else ''} B={a.npl} PP={a.npp} TG={a.ntg} n_batch={a.n_batch}: T_PP {tpp*1e3:.1f} ms  S_PP {a.npl*a.npp/tpp:.0f} t/s | "
-      f"T_TG {ttg*1e3:.1f} ms  S_TG {a.npl*a.ntg/ttg:.0f} t/s  ({ttg/a.ntg*1e3:.3f} ms/step, {'one cached hipGraph per ubatch shape' if a.graph else 'eager launches'}, host block manager in the loop)")
+      f"T_TG {ttg*1e3:.1f} ms  S_TG {a.npl*a.ntg/ttg:.0f} t/s  ({ttg/a.ntg*1e3:.3f} ms/step, {'one cached hipGraph per ubatch shape' if a.graph else ('eager launches, one library call per layer' if a.per_layer else 'eager launches, one library call per ubatch')}, host block manager in the loop)")

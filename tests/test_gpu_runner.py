@@ -154,3 +154,38 @@ def test_captured_ubatches_equal_eager_ubatches(pkv, tk):
         step([0, 2, 3], [lens[0] + 12 + i, lens[2] + 12 + i, 100 + i])
     assert len(rb._graphs) >= 3                                      # (equal outputs of the later steps = equal cache contents)
     ra.close(); rb.close()
+
+
+def test_all_layers_in_one_call_equals_layer_by_layer(pkv, O):
+    """pkv_attn_step_layers (AttnPathRunner.layers): a prompt ubatch and decode ubatches through all layers in one call — the same launches as layer() per layer:
+    identical outputs (prompt and the decode steps that read its stores), f32 and f16 boundary"""
+    from llama_cpp_test_amd.runner import AttnPathRunner
+    rng = np.random.default_rng(41)
+    L, H, HK, D = 3, 8, 2, 128
+    outs = {}
+    for mode in ("per_layer", "one_call"):
+        r = AttnPathRunner(n_layer=L, n_head=H, n_head_kv=HK, head_dim=D, type_k=1, type_v=8, n_blocks=16, n_seq_max=3, max_batch_tokens=512,
+                           rope=pkv.rope_params(n_dims=D, mode=0, freq_base=10000.0))
+        g = np.random.default_rng(7)
+        res = []
+        ubatches = [([0] * 200 + [1] * 130 + [2] * 64, list(range(200)) + list(range(130)) + list(range(64)))] + [([0, 1, 2], [200 + i, 130 + i, 64 + i]) for i in range(3)]
+        for ui, (sid, pos) in enumerate(ubatches):
+            n = len(sid)
+            dt = torch.float16 if ui == 0 else torch.float32                 # the prompt ubatch with the f16 boundary
+            q = [dev(g.uniform(-1, 1, (n, H, D)).astype(np.float32)).to(dt) for _ in range(L)]
+            k = [dev(g.uniform(-1, 1, (n, HK, D)).astype(np.float32)) for _ in range(L)]
+            v = [dev(g.uniform(-1, 1, (n, HK, D)).astype(np.float32)) for _ in range(L)]
+            out = [torch.empty((n, H, D), device="cuda", dtype=dt) for _ in range(L)]
+            plan = r.plan(sid, pos)
+            if mode == "one_call":
+                r.layers(plan, q, k, v, out)
+            else:
+                for il in range(L):
+                    r.layer(il, plan, q[il], k[il], v[il], out[il])
+            torch.cuda.synchronize()
+            res.append([o.float().cpu().numpy() for o in out])
+        outs[mode] = res                   # (the decode ubatches read what the prompt ubatch stored: equal outputs there = equal pools)
+        r.close()
+    for a, b in zip(outs["per_layer"], outs["one_call"]):
+        for x, y in zip(a, b):
+            assert np.isfinite(x).all() and np.array_equal(x, y)
