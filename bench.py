@@ -497,6 +497,8 @@ def configs_record(pkv, torch, *, reps, kernel_reps):
         h = batched_bench_record(pkv, torch, npl=32, npp=512, ntg=128, n_batch=2048, kv_type="f16", reps=reps, pp_f16=True)
         out["8b_batched_bench_32x_pp512_tg128_f16"].update({"S_PP_f16_io": h["S_PP"], "S_PP_f16_io_stdev": h["S_PP_stdev"],
                                                             "S_PP_f16_io_note": "same run with the prompt ubatches' Q handed over / O taken back as f16 (PKV_ATTN_Q_F16 | PKV_ATTN_OUT_F16)"})
+        k8 = batched_bench_record(pkv, torch, npl=32, npp=512, ntg=128, n_batch=2048, kv_type="q8_0", reps=reps)
+        out["8b_batched_bench_32x_pp512_tg128_f16"].update({"q8_0_kv": {k: k8[k] for k in ("S_PP", "S_PP_stdev", "S_TG", "S_TG_stdev")}})
     except Exception as e:
         out["8b_batched_bench_32x_pp512_tg128_f16"] = {"error": f"{type(e).__name__}: {e}"}
     return out
