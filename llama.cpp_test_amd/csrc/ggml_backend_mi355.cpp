@@ -316,7 +316,7 @@ bool supports_flash_attn(const ggml_tensor * op) {
     if (q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return false;
     if (k->ne[2] <= 0 || q->ne[2] % k->ne[2] != 0 || v->ne[2] != k->ne[2] || v->ne[1] != k->ne[1]) return false;
     const int64_t g = q->ne[2] / k->ne[2];
-    if (g != 1 && g != 2 && g != 4 && g != 8) return false;
+    if (g != 1 && g != 2 && g != 4 && g != 8 && g != 16 && g != 32) return false;
     if (q->nb[0] != sizeof(float) || q->nb[1] % 16 || q->nb[2] % 16) return false;
     if (k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type)) return false;
     if (!ggml_is_contiguous(op)) return false;

@@ -84,6 +84,8 @@ struct DecodeArgs {
     unsigned *      counters; // [n_seq][n_head_kv] arrival tickets (fused merge), zero between launches
     int             part_o_bytes, part_ml_bytes;   // extents of the partial slabs (buffer descriptors of the fused merge)
     int   n_head, n_head_kv, block_size, max_blocks, n_splits, bs_shift;  // block_size = WG_TOK << bs_shift
+    int   kv_div, n_head_kv_pool;  // gqa ratios 16 / 32 run as ratio 8 over kv_div = 2 / 4 times as many "virtual" kv heads (n_head_kv above): virtual head hk reads
+                                   // the tiles of real kv head hk / kv_div of the pool's n_head_kv_pool, its query heads hk * 8 + g are the real ones
     int   n_tile;             // MULTI: consecutive 128-token tiles one workgroup walks (n_splits = partials per (sequence, head) = ceil(tiles / n_tile))
     int   final_out;          // MULTI with n_splits == 1: the workgroup's result IS the head's output -> normalised straight into `out`, no partials, no merge launch
     float scale, softcap;
@@ -482,8 +484,9 @@ __global__ void __launch_bounds__((64 * Geo<KT, VT, D, TPWQ>::NW), PKV_OCC) attn
     const size_t tb_k = tile_bytes(KT, a.block_size, D), tb_v = tile_bytes(VT, a.block_size, D);
     const size_t tq_k = tile_quant_bytes(KT, a.block_size, D), tq_v = tile_quant_bytes(VT, a.block_size, D);
     // buffer descriptors of a tile's 128-token range: records end at the last valid token / token group (n_valid 0: every load returns 0)
-    auto tile_k  = [&](int phys) { return a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k; };
-    auto tile_v  = [&](int phys) { return a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v; };
+    const int hk_pool = a.kv_div > 1 ? hk / a.kv_div : hk;
+    auto tile_k  = [&](int phys) { return a.k_pool + ((size_t) phys * a.n_head_kv_pool + hk_pool) * tb_k; };
+    auto tile_v  = [&](int phys) { return a.v_pool + ((size_t) phys * a.n_head_kv_pool + hk_pool) * tb_v; };
     auto mk_rs_k = [&](int phys, int boff, int nv) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(tile_k(phys)) + (size_t) boff * K_ROWB, 0, nv * K_ROWB, 0x00020000); };
     auto mk_rs_ks = [&](int phys, int boff, int nv) {
@@ -1318,6 +1321,14 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
     da.block_table = a.block_table; da.seq_lens = a.seq_lens; da.slot_pos = a.slot_pos; da.q_pos = a.q_pos;
     da.mask = (const _Float16 *) a.mask; da.mask_stride = a.mask_stride;
     da.n_head = a.n_head; da.n_head_kv = a.n_head_kv; da.block_size = a.block_size; da.max_blocks = a.max_blocks;
+    da.kv_div = 1; da.n_head_kv_pool = a.n_head_kv;
+    {   // gqa ratios 16 and 32 (the reference's harness tests nr = 16): ratio 8 over kv_div times as many virtual kv heads — the K / V tiles are read kv_div times
+        const int G0 = a.n_head / a.n_head_kv;
+        if (G0 == 16 || G0 == 32) {
+            if (step) { set_error("pkv_attn_decode_step: gqa ratio %d takes pkv_qkv_prepare + pkv_attn_decode", G0); return PKV_ERR_UNSUPPORTED; }
+            da.kv_div = G0 / 8; da.n_head_kv = a.n_head_kv * da.kv_div;
+        }
+    }
     da.n_splits = (a.max_seq_len + WG_TOK - 1) / WG_TOK;
     da.bs_shift = 0;
     while ((WG_TOK << da.bs_shift) < a.block_size) ++da.bs_shift;
@@ -1369,7 +1380,7 @@ int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_a
             }
         }
     }
-    const int G = a.n_head / a.n_head_kv;
+    const int G = a.n_head / da.n_head_kv;
     switch (a.type_k) {
         case PKV_TYPE_F16:  return launch_v<PKV_TYPE_F16>(da, a.type_v, a.head_dim, G, a.n_seq, st);
         case PKV_TYPE_Q8_0: return launch_v<PKV_TYPE_Q8_0>(da, a.type_v, a.head_dim, G, a.n_seq, st);

@@ -61,6 +61,7 @@ struct PrefillArgs {
     const int32_t * seq_lens;
     const int32_t * q_start;
     int   n_head, n_head_kv, block_size, max_blocks;
+    int   kv_div, n_head_kv_pool; // gqa ratios 16 / 32 as ratio 8 over kv_div times as many virtual kv heads (see pkv_attn_decode.hip)
     int   bs_shift;               // log2(block_size), or -1 when it is not a power of two
     int   mask_align8;            // mask rows start on 8-byte boundaries (base and row stride)
     const float * rope_cache;     // pkv_attn_prefill_step: (cos, sin) rows of the ubatch's tokens [n_tok][D/2][2] (pkv_rope_cache), NORM pairs: Q arrives
@@ -513,14 +514,14 @@ __global__ void __launch_bounds__(64 * G, QB == 2 ? 1 : 2) attn_prefill_kernel(c
     if constexpr (KDMA) kst.init(tid);
     auto prefetch_k = [&](int kv0, int phys, char * img) {
         const int row0 = kv0 - blk_of(kv0) * a.block_size, nval = min(KVT, seq_len - kv0);
-        const char * kt = a.k_pool + ((size_t) phys * a.n_head_kv + hk) * tb_k;
+        const char * kt = a.k_pool + ((size_t) phys * a.n_head_kv_pool + (a.kv_div > 1 ? hk / a.kv_div : hk)) * tb_k;
         const rsrc_t rs = mk_rsrc(kt + (size_t) row0 * KSt::ROWB, nval * KSt::ROWB);
         if constexpr (KDMA) kst.dma(rs, img, g);
         else kst.load(rs, mk_rsrc(kt + tile_quant_bytes(KT, a.block_size, D) + (size_t) row0 * (D / PKV_QK) * 2, nval * (D / PKV_QK) * 2), k_go, k_so);
     };
     auto prefetch_v = [&](int kv0, int phys) {
         const int row0 = kv0 - blk_of(kv0) * a.block_size, nval = min(KVT, seq_len - kv0);
-        const char * vt = a.v_pool + ((size_t) phys * a.n_head_kv + hk) * tb_v;
+        const char * vt = a.v_pool + ((size_t) phys * a.n_head_kv_pool + (a.kv_div > 1 ? hk / a.kv_div : hk)) * tb_v;
         constexpr int VTL = VSt::TL;
         const int ngrp = (nval + VTL - 1) / VTL;
         vst.load(mk_rsrc(vt + (size_t) (row0 / VTL) * D * 4, ngrp * D * 4),
@@ -972,6 +973,8 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * r
     pa.k_pool = (const char *) a.k_pool; pa.v_pool = (const char *) a.v_pool;
     pa.block_table = a.block_table; pa.seq_lens = a.seq_lens; pa.q_start = a.q_start;
     pa.n_head = a.n_head; pa.n_head_kv = a.n_head_kv; pa.block_size = a.block_size; pa.max_blocks = a.max_blocks;
+    pa.kv_div = 1; pa.n_head_kv_pool = a.n_head_kv;
+    if (a.n_head / a.n_head_kv == 16 || a.n_head / a.n_head_kv == 32) { pa.kv_div = a.n_head / a.n_head_kv / 8; pa.n_head_kv = a.n_head_kv * pa.kv_div; }
     pa.bs_shift = -1;
     for (int sh = 0; sh < 31; ++sh) if ((1 << sh) == a.block_size) pa.bs_shift = sh;
     pa.softcap = a.logit_softcap;
@@ -984,7 +987,7 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * r
     pa.q_f16 = (a.flags & PKV_ATTN_Q_F16) ? 1 : 0; pa.out_f16 = (a.flags & PKV_ATTN_OUT_F16) ? 1 : 0;
     PKV_REQUIRE(a.max_bias == 0.0f || a.mask, "pkv_attn_prefill: max_bias (ALiBi) needs a mask");
     pa.scale   = a.logit_softcap != 0.0f ? a.scale / a.logit_softcap : a.scale;
-    const int G = a.n_head / a.n_head_kv;
+    const int G = a.n_head / pa.n_head_kv;
     // 64 queries per wave (QB = 2: one workgroup per CU, one wave per SIMD) is built, bit-compatible and SLOWER than two 32-query waves per
     // SIMD (617 vs 644 TFLOP/s at pp4096, 295 vs 334 at 32 x pp512): a single in-order wave per SIMD does not overlap its
     // softmax arithmetic with its own MFMAs.  Kept as an opt-in experiment for the headline instantiation (PKV_PREFILL_QB=2).
@@ -994,7 +997,7 @@ int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * r
     const int n_tiles = (a.max_q_per_seq + QT * qb - 1) / (QT * qb);
     // split-KV when the launch would leave most of the 256 CUs (2 workgroups each) idle and the past is long enough to share
     pa.n_split = 1; pa.n_tok_total = a.n_tok; pa.part_o = nullptr; pa.part_ml = nullptr;
-    const long long n_wg = (long long) n_tiles * a.n_head_kv * a.n_seq;
+    const long long n_wg = (long long) n_tiles * pa.n_head_kv * a.n_seq;
     const int nkt_max = (a.max_seq_len + KVT - 1) / KVT;
     if (n_wg < 384 && a.n_tok <= PREFILL_SPLIT_MAX_TOK && !pa.stamps) {
         int ns = (int) std::min<long long>(PREFILL_MAX_SPLIT, (512 + n_wg - 1) / n_wg);

@@ -24,7 +24,7 @@ def run_decode(pkv, q, kp, vp, bt, sl, *, n_head_kv, tk, tv, bs=128, softcap=0.0
 
 
 @pytest.mark.parametrize("tk,tv", [("f16", "f16"), ("q8_0", "q8_0"), ("q4_0", "q4_0"), ("q8_0", "f16"), ("f16", "q8_0"), ("q4_0", "q8_0")])
-@pytest.mark.parametrize("D,n_head,n_head_kv", [(128, 32, 8), (128, 8, 1), (128, 4, 4), (64, 32, 4), (128, 4, 2)])
+@pytest.mark.parametrize("D,n_head,n_head_kv", [(128, 32, 8), (128, 8, 1), (128, 4, 4), (64, 32, 4), (128, 4, 2), (128, 32, 2), (64, 32, 1)])   # (.., 32, 2) / (.., 32, 1): gqa 16 / 32
 def test_decode_matches_oracle(pkv, O, tk, tv, D, n_head, n_head_kv):
     tk, tv = TYPES[tk], TYPES[tv]
     rng = np.random.default_rng(D + n_head * 3 + tk + tv * 5)

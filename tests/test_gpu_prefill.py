@@ -37,7 +37,7 @@ def run_prefill(pkv, O, rng, *, lens, n_qs, D, nh, nkv, tk, tv, softcap=0.0, bs=
     return got, np.concatenate(refs), np.concatenate(exacts)
 
 
-@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (128, 8, 1), (128, 4, 4), (64, 32, 4), (128, 4, 2)])
+@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (128, 8, 1), (128, 4, 4), (64, 32, 4), (128, 4, 2), (128, 32, 2), (64, 32, 1)])   # (.., 32, 2) / (.., 32, 1): gqa 16 / 32
 def test_prefill_f16_matches_oracle(pkv, O, D, nh, nkv):
     rng = np.random.default_rng(D + nh + nkv)
     lens = [1, 31, 32, 33, 100, 128, 129, 300, 512]          # whole prompt in one ubatch: n_q == seq_len
