@@ -686,6 +686,7 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
     // (8 waves with exactly 7 row pairs each instead of 16 with 3 or 4 — gate + up at Llama-3-8B sizes — is SLOWER, 16.4 vs 14.3 us: the waves hide
     // each other's load latency; profiles/r03_gemv_shapes.txt)
+    if (tot >= 256 * 128) nwv = 8;   // ... a very long stream (lm_head: 250 row pairs per CU) runs 5 % faster with 8: 73.3 vs 76.9 us (sweep of PKV_GEMV_NWV, same file)
     if (const char * e = getenv("PKV_GEMV_NWV")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) nwv = v; }   // experiments
     int grid = tot >= 256 * nwv ? 256 : (tot + nwv - 1) / nwv;
     // long rows, few of them (ffn_down): two waves per row pair, 16 waves per CU
