@@ -466,7 +466,7 @@ def timed_config(pkv, torch, *, model, ctx, n_seq, kv_type, steps, warmup, reps,
            "bytes_launch": bytes_launch, "achieved": achieved,
            "kernel_us": {"mean": round(k_used * 1e6, 3), "event_bound_mean": round(k_mean * 1e6, 3), "event_bound_median": round(k_med * 1e6, 3), "event_bound_min": round(k_min * 1e6, 3)},
            "k_graph": k_graph is not None}
-    tiles = 1 if fused_merge else pkv.attn_decode_tiles(ctx, g["n_head_kv"], n_seq)
+    tiles = 1 if fused_merge else pkv.attn_decode_tiles(ctx, g["n_head"], g["n_head_kv"], n_seq)
     rec["tiles_per_workgroup"] = tiles
     rec["merge"] = ("in-kernel (last-arriving workgroup)" if fused_merge else
                     "none: one workgroup per (sequence, kv head) walks the whole sequence and writes the output" if (tiles > 1 and tiles >= -(-ctx // 128)) else "second launch")

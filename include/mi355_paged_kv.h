@@ -205,14 +205,14 @@ size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq
 size_t pkv_attn_prefill_workspace_bytes(int n_tok, int n_head, int head_dim);
 /* zero a fresh workspace (asynchronously, on `stream`); required once before PKV_ATTN_FUSED_COMBINE is used with it */
 int    pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream);
-/* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks.  Launches with more
- * workgroups than CUs take the multi-tile form: one workgroup walks several consecutive 128-token tiles of its (sequence,
+/* single-token decode (one query token per sequence, q_start == NULL): split-KV over 128-token blocks.  Launches of at least four
+ * rounds of resident workgroups take the multi-tile form: one workgroup walks several consecutive 128-token tiles of its (sequence,
  * kv head) with an online softmax and writes ONE partial; when a workgroup covers the whole sequence it writes `out`
  * itself (no partials, no merge launch — also under PKV_ATTN_NO_COMBINE, which then has nothing to leave behind). */
 int pkv_attn_decode(const pkv_attn_args * args, void * stream);
 /* the 128-token tiles one workgroup of pkv_attn_decode / pkv_attn_decode_step walks for a launch of this shape (1 = one
  * tile per workgroup + merge launch; >= ceil(max_seq_len / 128) = the form without partials).  Informational (bench.py). */
-int pkv_attn_decode_tiles(int max_seq_len, int n_head_kv, int n_seq);
+int pkv_attn_decode_tiles(int max_seq_len, int n_head, int n_head_kv, int n_seq);
 /* One decode step of a layer in ONE launch (+ the merge): pkv_qkv_prepare + pkv_attn_decode fused, i.e. the whole
  * ggml_rope_ext(Qcur) / ggml_rope_ext(Kcur) / ggml_cpy(Kcur, Vcur -> cache) / ggml_flash_attn_ext run of
  * llm_build_llama + build_attn (/ref/src/llama-model.cpp:4091-4105, /ref/src/llama-graph.cpp:1367-1432) for a

@@ -213,9 +213,9 @@ def attn_workspace_bytes(n_tok: int, n_head: int, head_dim: int, max_seq_len: in
     return lib().pkv_attn_workspace_bytes(n_tok, n_head, head_dim, max_seq_len, block_size)
 
 
-def attn_decode_tiles(max_seq_len: int, n_head_kv: int, n_seq: int) -> int:
+def attn_decode_tiles(max_seq_len: int, n_head: int, n_head_kv: int, n_seq: int) -> int:
     """128-token tiles one workgroup of the plain decode launch walks for this launch shape (pkv_attn_decode_tiles)"""
-    return int(lib().pkv_attn_decode_tiles(int(max_seq_len), int(n_head_kv), int(n_seq)))
+    return int(lib().pkv_attn_decode_tiles(int(max_seq_len), int(n_head), int(n_head_kv), int(n_seq)))
 
 
 def attn_prefill_workspace_bytes(n_tok: int, n_head: int, head_dim: int) -> int:

@@ -1195,7 +1195,7 @@ int launch_one(const DecodeArgs & da0, int n_seq, hipStream_t st) {
     // multi-tile form: the plain variants with their own merge launch
     da.n_tile = 1; da.final_out = 0;
     if (!cap && !sp && !da.counters && !da.stamps) {
-        da.n_tile    = decode_tiles_per_wg(da.n_splits, da.n_head_kv, n_seq);
+        da.n_tile    = decode_tiles_per_wg(da.n_splits, da.n_head_kv, n_seq, G);
         da.n_splits  = (da.n_splits + da.n_tile - 1) / da.n_tile;
         da.final_out = da.n_tile > 1 && da.n_splits == 1 && da.out_direct != nullptr && da.out_image == nullptr;   // (the image is made by the merge launch)
         if (da.final_out) da.out = da.out_direct;     // (also under PKV_ATTN_NO_COMBINE: this form has no partials to leave behind)

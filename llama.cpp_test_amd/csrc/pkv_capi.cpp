@@ -199,7 +199,7 @@ size_t pkv_attn_workspace_bytes(int n_tok, int n_head, int head_dim, int max_seq
 }
 
 size_t pkv_attn_prefill_workspace_bytes(int n_tok, int n_head, int head_dim) { return prefill_workspace_bytes(n_tok, n_head, head_dim); }
-int pkv_attn_decode_tiles(int max_seq_len, int n_head_kv, int n_seq) { return decode_tiles_for(max_seq_len, n_head_kv, n_seq); }
+int pkv_attn_decode_tiles(int max_seq_len, int n_head, int n_head_kv, int n_seq) { return decode_tiles_for(max_seq_len, n_head, n_head_kv, n_seq); }
 
 int pkv_attn_workspace_init(void * workspace, size_t bytes, void * stream) {
     if (int rc = ensure_device()) return rc;

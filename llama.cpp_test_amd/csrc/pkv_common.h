@@ -103,24 +103,31 @@ __device__ __forceinline__ float rms_scale(const double * block_sums, int n_bloc
 
 // ---- how a decode launch is cut into workgroups (host logic) ------------------------------------------
 // Tiles per workgroup of the multi-tile form (1 = the single-tile form).  A launch of one 128-token tile per workgroup pays its fixed work — scalars, the Q
-// operand, the cross-wave merge, a partial, a share of the merge launch — once per 128 tokens; once the launch has more workgroups than CUs they only queue
-// behind each other.  Measured (profiles/r03_decode_tiles.txt, ms per step of all layers): 70B geometry ctx 16384 (1024 tiles) 1.99 at 1 tile per workgroup,
-// 1.86 at 2, 1.60 at 4 (= 256 workgroups), 2.24 at 8; 32 sequences x ctx 640: 0.657 -> 0.539 with one workgroup per (sequence, kv head) (no partials, no
-// merge launch); 32 x ctx 4096: 2.93 -> 2.82 (8 tiles) / 2.74 (32); q8_0 / q4_0 KV 32 x ctx 4096: 1.98 -> 1.86 / 1.84 -> 1.57 at 8 tiles (1024 4-wave workgroups).
-// Rule: about one 8-wave workgroup per CU, at most DECODE_MAX_TILES tiles each (the bound keeps one long sequence among short ones from serialising the launch).
+// operand, the cross-wave merge, a partial, a share of the merge launch — once per 128 tokens; but it also keeps two workgroups per CU resident (gqa <= 4: 118
+// VGPRs; gqa 8: 167, one workgroup), and a launch of a few hundred multi-tile workgroups has LESS in flight per CU than the same launch cut into single tiles.
+// Measured (profiles/r03_decode_tiles.txt, r03_decode_rule_sweep.txt; ms per step of all layers): 70B geometry ctx 16384 (gqa 8, 1024 tiles) 1.99 at 1 tile per
+// workgroup, 1.77 at 2, 1.46 at 4 (= 256 workgroups), 2.00 at 8; 8B geometry ctx 4096: 32 sequences 3.09 -> 2.85 (8 tiles), 16 sequences 1.58 -> 1.54, but 3 / 6
+// sequences 0.44 -> 0.56 / 0.72 -> 0.88 with 3 / 6 tiles (264 uneven workgroups); 32 sequences x ctx 640: 0.66 -> 0.52 with one workgroup per (sequence, kv
+// head) (no partials, no merge launch), 24 sequences with 4 + 1 tiles 0.55 -> 0.67.  Rule: (1) enough streams to fill the chip and few tiles: one workgroup per
+// stream; (2) otherwise several tiles only from four rounds of resident workgroups on, a power of two that leaves at least one round and divides the
+// sequence's tiles evenly (or nearly so), at most DECODE_MAX_TILES (the bound keeps one long sequence among short ones from serialising the launch).
 constexpr int DECODE_CUS = 256, DECODE_MAX_TILES = 8, DECODE_TILE_TOKENS = 128;
-inline int decode_tiles_per_wg(int n_splits, int n_head_kv, int n_seq) {
+inline int decode_tiles_per_wg(int n_splits, int n_head_kv, int n_seq, int gqa) {
     if (const char * e = getenv("PKV_DECODE_NTILE")) { const int v = atoi(e); if (v >= 1) return v < n_splits ? v : n_splits; }   // experiments
-    const long wg1 = (long) n_head_kv * n_seq * n_splits;
-    if (wg1 < 2 * DECODE_CUS) return 1;
-    long nt = (wg1 + DECODE_CUS / 2) / DECODE_CUS;
-    if (nt > DECODE_MAX_TILES) nt = DECODE_MAX_TILES;
-    if (nt > n_splits) nt = n_splits;
-    return (int) (nt < 1 ? 1 : nt);
+    const long streams = (long) n_head_kv * n_seq, wg1 = streams * n_splits;
+    if (n_splits <= 1) return 1;
+    if (streams >= DECODE_CUS && n_splits <= DECODE_MAX_TILES) return n_splits;
+    const long slots = (long) DECODE_CUS * (gqa <= 4 ? 2 : 1);           // workgroups resident at a time
+    if (wg1 < 4 * slots) return 1;
+    const long lim = wg1 / slots;
+    for (int nt = DECODE_MAX_TILES; nt >= 2; nt >>= 1)
+        if (nt <= lim && (n_splits % nt == 0 || n_splits >= 8 * nt)) return nt;
+    return 1;
 }
-
-inline int decode_tiles_for(int max_seq_len, int n_head_kv, int n_seq) {   // pkv_attn_decode_tiles
-    return decode_tiles_per_wg((max_seq_len + DECODE_TILE_TOKENS - 1) / DECODE_TILE_TOKENS, n_head_kv, n_seq);
+inline int decode_tiles_for(int max_seq_len, int n_head, int n_head_kv, int n_seq) {   // pkv_attn_decode_tiles
+    int g = n_head_kv > 0 ? n_head / n_head_kv : 1;
+    if (g == 16 || g == 32) { n_head_kv *= g / 8; g = 8; }                // (run as gqa 8 over virtual kv heads)
+    return decode_tiles_per_wg((max_seq_len + DECODE_TILE_TOKENS - 1) / DECODE_TILE_TOKENS, n_head_kv, n_seq, g);
 }
 
 // ---- kernel launchers (pkv_kernels_*.hip) ---------------------------------------------------------

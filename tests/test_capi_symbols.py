@@ -50,15 +50,18 @@ def test_decode_launch_shapes(pkv, monkeypatch):
     workgroup while the launch has fewer than two workgroups per CU, otherwise about one 8-wave workgroup per CU with at most 8 tiles each; a
     workgroup that covers its whole sequence means no partials and no merge launch (bench.py reports the choice)."""
     monkeypatch.delenv("PKV_DECODE_NTILE", raising=False)
-    t = pkv.attn_decode_tiles
-    assert t(4096, 8, 1) == 1            # config 2: 32 x 8 = 256 workgroups, one per CU
-    assert t(16384, 8, 1) == 4           # config 5 (70B geometry): 1024 tiles -> 256 workgroups of 4
-    assert t(640, 8, 32) == 5            # config 3's decode step: one workgroup per (sequence, kv head) walks all 5 tiles
-    assert t(4096, 8, 32) == 8           # 8192 tiles: capped (a long sequence among short ones must not serialise the launch)
-    assert t(1, 8, 1) == 1 and t(128, 1, 1) == 1 and t(129, 8, 31) == 1      # (496 workgroups: below two per CU)
-    assert t(256, 8, 32) == 2
-    for msl, nkv, ns in ((100, 2, 3), (5000, 8, 7), (131072, 8, 1), (640, 8, 256)):
-        n = t(msl, nkv, ns)
+    t = pkv.attn_decode_tiles               # (max_seq_len, n_head, n_head_kv, n_seq)
+    assert t(4096, 32, 8, 1) == 1           # config 2: 32 x 8 = 256 workgroups, one per CU
+    assert t(16384, 64, 8, 1) == 4          # config 5 (70B geometry, gqa 8: one resident workgroup per CU): 1024 tiles -> 256 workgroups of 4
+    assert t(640, 32, 8, 32) == 5           # config 3's decode step: one workgroup per (sequence, kv head) walks all 5 tiles, no merge launch
+    assert t(4096, 32, 8, 32) == 8          # 8192 tiles: capped (a long sequence among short ones must not serialise the launch)
+    assert t(4096, 32, 8, 16) == 8 and t(4096, 32, 8, 8) == 4
+    assert t(4096, 32, 8, 3) == 1 and t(4096, 32, 8, 6) == 1      # measured: 3 / 6 tiles per workgroup lose 20 % here (fewer, uneven workgroups)
+    assert t(640, 32, 8, 24) == 1 and t(640, 32, 8, 16) == 1
+    assert t(1, 32, 8, 1) == 1 and t(128, 4, 1, 1) == 1
+    assert t(4096, 32, 2, 4) == t(4096, 32, 8, 4)                 # gqa 16 runs as gqa 8 over twice the kv heads
+    for msl, nh, nkv, ns in ((100, 8, 2, 3), (5000, 32, 8, 7), (131072, 64, 8, 1), (640, 32, 8, 256)):
+        n = t(msl, nh, nkv, ns)
         assert 1 <= n <= min(8, -(-msl // 128))
     monkeypatch.setenv("PKV_DECODE_NTILE", "3")                              # the experiments' override, clamped to the sequence's tiles
-    assert t(4096, 8, 1) == 3 and t(200, 8, 1) == 2
+    assert t(4096, 32, 8, 1) == 3 and t(200, 32, 8, 1) == 2
