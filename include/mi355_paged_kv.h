@@ -50,7 +50,8 @@ extern "C" {
 enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8,
                 PKV_TYPE_Q4_K = 12, /* weights of pkv_mul_mat / pkv_gemv_q only (block_q4_K, /ref/ggml/src/ggml-common.h:279-290); not a KV type */
                 PKV_TYPE_Q5_K = 13, /* weights of pkv_mul_mat / pkv_get_rows (block_q5_K, :291-308; Q5_K_M files): every column count through the MFMA product */
-                PKV_TYPE_Q6_K = 14  /* weights of pkv_gemv_q / pkv_get_rows only (block_q6_K, :309-319): what a Q4_K_M file mixes in          */ };
+                PKV_TYPE_Q6_K = 14, /* weights of pkv_gemv_q / pkv_get_rows only (block_q6_K, :309-319): what a Q4_K_M file mixes in          */
+                PKV_TYPE_BF16 = 30  /* K / V rows of pkv_flash_attn_ext_flat only (ggml_bf16_t, /ref/ggml/include/ggml.h:339-342): not a pool type */ };
 
 enum pkv_status {
     PKV_OK              =  0,
@@ -267,6 +268,28 @@ int    pkv_event_synchronize(void * ev);
 int    pkv_event_elapsed_ms(void * ev_start, void * ev_stop, float * ms);
 /* batched prefill (many query tokens per sequence, causal): MFMA QK^T / PV */
 int pkv_attn_prefill(const pkv_attn_args * args, void * stream);
+
+/* GGML_OP_FLASH_ATTN_EXT on the reference's OWN tensor layout, for what the paged kernels above do not take (r03): head sizes other than 64 / 128 (even,
+ * <= 256; a multiple of 32 with quantized rows), bf16 K / V, any gqa ratio, K / V as strided views of flat tensors — the rest of the domain of
+ * ggml_compute_forward_flash_attn_ext_f16 (/ref/ggml/src/ggml-cpu/ggml-cpu.c:12219-12432) that /ref/tests/test-backend-ops.cpp:4367-4390 tests (head sizes
+ * 64 / 80 / 128 / 256 x f16 / bf16 / q8_0 / q4_0) and `-ctk / -ctv bf16` runs (/ref/common/arg.cpp:172-182).  No pool: K / V rows are read where they lie, in
+ * the reference's bytes (block_q8_0 / block_q4_0, 16-bit elements), Q rounded through the K type's vec_dot_type as the reference does (f16 / bf16 /
+ * q8_0 with the AVX2 rounding).  One workgroup per (query row, head): a coverage kernel, not a roofline one — callers ask the paged kernels first (the
+ * ggml-backend plugin does).
+ *   q    : device f32, row (t, h) at q + t*q_stride_tok + h*q_stride_head (floats)       [ggml q: ne = {D, n_q, n_head}]
+ *   k, v : device bytes, row (cell c, kv head g) at k + c*k_stride_tok + g*k_stride_head (BYTES = ggml nb[1], nb[2]), types PKV_TYPE_F16 / _BF16 / _Q8_0 / _Q4_0
+ *   mask : device f16 [n_q][mask_stride] or NULL (no causal structure is implied: what is not masked is seen); max_bias > 0 = ALiBi slopes on the mask
+ *   out  : device f32 [n_q][n_head][head_dim]                                             [ggml dst: ne = {D, n_head, n_q}]                                  */
+typedef struct pkv_flat_attn_args {
+    const float * q;    int64_t q_stride_tok, q_stride_head;
+    const void *  k;    int64_t k_stride_tok, k_stride_head;
+    const void *  v;    int64_t v_stride_tok, v_stride_head;
+    const void *  mask; int64_t mask_stride;
+    float *       out;
+    int32_t n_q, n_kv, n_head, n_head_kv, head_dim, type_k, type_v;
+    float   scale, max_bias, logit_softcap;           /* op_params[0..2] */
+} pkv_flat_attn_args;
+int pkv_flash_attn_ext_flat(const pkv_flat_attn_args * args, void * stream);
 
 /* In-place K-shift: replaces build_kv_self_shift / build_rope_shift (/ref/src/llama-context.cpp:447-571).
  * For each listed cell rotate the cached K row of every kv head by `delta` positions (f16 in place; quantized:

@@ -26,8 +26,8 @@ LIB_PATH = os.environ.get("PKV_LIB_PATH") or os.path.join(_HERE, "libmi355_paged
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355_paged_kv.h")
 
 # enum pkv_type (= enum ggml_type values)
-F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 0, 1, 2, 8, 12, 13, 14
-TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K}
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, BF16 = 0, 1, 2, 8, 12, 13, 14, 30
+TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K, "bf16": BF16}
 # enum pkv_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SPACE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 PACKED = 0x100          # PKV_TYPE_PACKED: K-quant rows in the plane layout (csrc/pkv_wlayout.h), produced by weights_pack()
@@ -79,6 +79,15 @@ class AttnArgs(C.Structure):
                 ("max_seq_len", C.c_int32), ("flags", C.c_int32),
                 ("mask", C.c_void_p), ("mask_stride", C.c_int64), ("max_bias", C.c_float),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("out_image", C.c_void_p)]
+
+
+class FlatAttnArgs(C.Structure):   # pkv_flat_attn_args
+    _fields_ = [("q", C.c_void_p), ("q_stride_tok", C.c_int64), ("q_stride_head", C.c_int64),
+                ("k", C.c_void_p), ("k_stride_tok", C.c_int64), ("k_stride_head", C.c_int64),
+                ("v", C.c_void_p), ("v_stride_tok", C.c_int64), ("v_stride_head", C.c_int64),
+                ("mask", C.c_void_p), ("mask_stride", C.c_int64), ("out", C.c_void_p),
+                ("n_q", C.c_int32), ("n_kv", C.c_int32), ("n_head", C.c_int32), ("n_head_kv", C.c_int32), ("head_dim", C.c_int32),
+                ("type_k", C.c_int32), ("type_v", C.c_int32), ("scale", C.c_float), ("max_bias", C.c_float), ("logit_softcap", C.c_float)]
 
 
 class Gemv(C.Structure):
@@ -364,6 +373,26 @@ def attn_step_layers(q, k_cur, v_cur, out, k_pools, v_pools, pos, rope, block_ta
 def attn_prefill(q, k_pool, v_pool, block_table, seq_lens, q_start, **kw):
     """Paged causal prefill (many query tokens per sequence); q f32 [n_tok][n_head][D]."""
     return _attn(lib().pkv_attn_prefill, q, k_pool, v_pool, block_table, seq_lens, q_start=q_start, **kw)
+
+
+def flash_attn_ext_flat(q, k, v, mask=None, *, type_k: int, type_v: int, scale: float, max_bias: float = 0.0, softcap: float = 0.0, out=None, stream=None):
+    """ggml_flash_attn_ext on the reference's own tensor layout (pkv_flash_attn_ext_flat): what the paged kernels do not take — head sizes up to 256, bf16
+    rows, any gqa ratio, strided views.  q f32 [n_head][n_q][D] (any strides with a unit last one); k / v uint8 [n_head_kv][n_kv][row bytes] in the
+    reference's bytes (views allowed: strides are taken from the tensors); mask f16 [>= n_q][n_kv] or None.  Returns out f32 [n_q][n_head][D]."""
+    import torch
+    n_head, n_q, D = q.shape
+    n_head_kv, n_kv = k.shape[0], k.shape[1]
+    assert q.dtype == torch.float32 and q.stride(2) == 1 and k.dtype == torch.uint8 and v.dtype == torch.uint8 and k.stride(2) == 1 and v.stride(2) == 1
+    if out is None:
+        out = torch.empty((n_q, n_head, D), dtype=torch.float32, device=q.device)
+    if mask is not None:
+        assert mask.dtype == torch.float16 and mask.stride(1) == 1 and mask.shape[0] >= n_q and mask.shape[1] == n_kv
+    a = FlatAttnArgs(q=_ptr(q), q_stride_tok=q.stride(1), q_stride_head=q.stride(0), k=_ptr(k), k_stride_tok=k.stride(1), k_stride_head=k.stride(0),
+                     v=_ptr(v), v_stride_tok=v.stride(1), v_stride_head=v.stride(0), mask=_ptr(mask), mask_stride=mask.stride(0) if mask is not None else 0,
+                     out=_ptr(out), n_q=n_q, n_kv=n_kv, n_head=n_head, n_head_kv=n_head_kv, head_dim=D, type_k=type_k, type_v=type_v, scale=scale,
+                     max_bias=max_bias, logit_softcap=softcap)
+    check(lib().pkv_flash_attn_ext_flat(C.byref(a), C.c_void_p(_stream(stream))))
+    return out
 
 
 def attn_prefill_step(q, k_cur, v_cur, pos, rope, k_pool, v_pool, block_table, seq_lens, q_start, slot_block, slot_off, *, rope_cache=None, **kw):

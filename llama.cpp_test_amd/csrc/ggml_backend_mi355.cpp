@@ -10,7 +10,8 @@
 // of the reference is copied.  Tensors in our buffers hold the reference's own bytes (plain f32 / f16 / block_q8_0 /
 // block_q4_0), exactly what ggml_backend_tensor_set/get move; ops convert to the private paged pool layout on the fly:
 //   GGML_OP_FLASH_ATTN_EXT  K/V views -> pkv_pool_scatter_rows_strided (identity block table) -> pkv_attn_decode
-//                           (1 query, no mask) or pkv_attn_prefill (general mask / ALiBi / softcap, non-causal)
+//                           (1 query, no mask) or pkv_attn_prefill (general mask / ALiBi / softcap, non-causal); head sizes other than
+//                           64 / 128, bf16 rows, odd gqa ratios -> pkv_flash_attn_ext_flat on the tensors as they lie
 //   GGML_OP_ROPE(_BACK)     pkv_rope_f32_strided / pkv_rope_f16_strided (NORM / NEOX)
 //   GGML_OP_CPY             pkv_convert_f32           (f32 -> f16 / q8_0 / q4_0, contiguous)
 //   view ops                no-ops
@@ -307,17 +308,15 @@ ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t buft, size_t size) {
 size_t buft_align(ggml_backend_buffer_type_t) { return 256; }
 
 // ---- ops -------------------------------------------------------------------------------------------------------------------
-bool supports_flash_attn(const ggml_tensor * op) {
+// what every FLASH_ATTN_EXT of this device needs
+bool fa_common_ok(const ggml_tensor * op) {
     const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * m = op->src[3];
     if (!q || !k || !v || q->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
-    if (!kv_type(k->type) || !kv_type(v->type)) return false;
     const int64_t D = q->ne[0];
-    if ((D != 64 && D != 128) || k->ne[0] != D || v->ne[0] != D) return false;
+    if (k->ne[0] != D || v->ne[0] != D) return false;
     if (q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return false;
     if (k->ne[2] <= 0 || q->ne[2] % k->ne[2] != 0 || v->ne[2] != k->ne[2] || v->ne[1] != k->ne[1]) return false;
-    const int64_t g = q->ne[2] / k->ne[2];
-    if (g != 1 && g != 2 && g != 4 && g != 8 && g != 16 && g != 32) return false;
-    if (q->nb[0] != sizeof(float) || q->nb[1] % 16 || q->nb[2] % 16) return false;
+    if (q->nb[0] != sizeof(float)) return false;
     if (k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type)) return false;
     if (!ggml_is_contiguous(op)) return false;
     if (m && (m->type != GGML_TYPE_F16 || !ggml_is_contiguous(m) || m->ne[0] != k->ne[1] || m->ne[1] < q->ne[1])) return false;
@@ -326,6 +325,29 @@ bool supports_flash_attn(const ggml_tensor * op) {
     if (max_bias > 0.0f && !m) return false;
     return true;
 }
+// the paged kernels (tiles of a block pool): the north-star geometries
+bool fa_paged_ok(const ggml_tensor * op) {
+    const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2];
+    if (!kv_type(k->type) || !kv_type(v->type)) return false;
+    const int64_t D = q->ne[0];
+    if (D != 64 && D != 128) return false;
+    const int64_t g = q->ne[2] / k->ne[2];
+    if (g != 1 && g != 2 && g != 4 && g != 8 && g != 16 && g != 32) return false;
+    if (q->nb[1] % 16 || q->nb[2] % 16) return false;
+    return true;
+}
+// pkv_flash_attn_ext_flat: the rest of the operator's domain, on the tensors as they lie (head sizes up to 256, bf16 rows, any gqa ratio)
+bool fa_flat_type(ggml_type t) { return t == GGML_TYPE_F16 || t == GGML_TYPE_BF16 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0; }
+bool fa_flat_ok(const ggml_tensor * op) {
+    const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2];
+    if (!fa_flat_type(k->type) || !fa_flat_type(v->type)) return false;
+    const int64_t D = q->ne[0];
+    if (D > 256 || D % 2) return false;
+    if ((ggml_is_quantized(k->type) || ggml_is_quantized(v->type)) && D % 32) return false;
+    if (q->nb[1] % 4 || q->nb[2] % 4 || k->nb[1] % 2 || k->nb[2] % 2 || v->nb[1] % 2 || v->nb[2] % 2) return false;
+    return true;
+}
+bool supports_flash_attn(const ggml_tensor * op) { return fa_common_ok(op) && (fa_paged_ok(op) || fa_flat_ok(op)); }
 
 // Returns the mirror pool of the flat tensor `t` views, brought up to date for cells [0, n_kv), or NULL when `t` is not such a
 // view (test-backend-ops hands over free-standing K/V tensors: those take the scratch path).
@@ -395,6 +417,18 @@ ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
     memcpy(&max_bias, (const float *) op->op_params + 1, sizeof(float));
     memcpy(&softcap, (const float *) op->op_params + 2, sizeof(float));
     const int D = (int) q->ne[0], n_q = (int) q->ne[1], n_head = (int) q->ne[2], n_kv = (int) k->ne[1], n_head_kv = (int) k->ne[2];
+    if (!fa_paged_ok(op)) {   // outside the paged kernels' geometries: the flat kernel reads the tensors where they lie
+        pkv_flat_attn_args f = {};
+        f.q = (const float *) q->data; f.q_stride_tok = (int64_t) (q->nb[1] / sizeof(float)); f.q_stride_head = (int64_t) (q->nb[2] / sizeof(float));
+        f.k = k->data; f.k_stride_tok = (int64_t) k->nb[1]; f.k_stride_head = (int64_t) k->nb[2];
+        f.v = v->data; f.v_stride_tok = (int64_t) v->nb[1]; f.v_stride_head = (int64_t) v->nb[2];
+        f.mask = m ? m->data : nullptr; f.mask_stride = m ? (int64_t) m->ne[0] : 0;
+        f.out = (float *) op->data;
+        f.n_q = n_q; f.n_kv = n_kv; f.n_head = n_head; f.n_head_kv = n_head_kv; f.head_dim = D; f.type_k = k->type; f.type_v = v->type;
+        f.scale = scale; f.max_bias = max_bias; f.logit_softcap = softcap;
+        if (pkv_flash_attn_ext_flat(&f, bc->stream)) { MI355_LOG("flash_attn_ext (flat) failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+        return GGML_STATUS_SUCCESS;
+    }
     const int n_blocks = (n_kv + BLOCK - 1) / BLOCK;
     // K/V of a llama graph are views of the flat cache tensors (cell-major rows of n_head_kv * D elements, first cell 0):
     // serve them from the persistent mirrors
@@ -501,10 +535,11 @@ ggml_status run_rope(backend_ctx * bc, ggml_tensor * op, bool back) {
 }
 
 bool plain_type(ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
+bool cpy_type(ggml_type t) { return plain_type(t) || t == GGML_TYPE_BF16; }   // (bf16: the rows of a `-ctk / -ctv bf16` cache, read by pkv_flash_attn_ext_flat)
 // ggml_cpy / ggml_cont between strided f32 / f16 tensors (the V store into the transposed v cache of a -fa 0 graph, /ref/src/llama-graph.cpp:1387-1394;
 // kqv_merged -> cont, :1232-1234): the generic element-by-element copy
 bool supports_cpy_strided(const ggml_tensor * s, const ggml_tensor * d) {
-    return s && d && plain_type(s->type) && plain_type(d->type) && ggml_nelements(s) == ggml_nelements(d);
+    return s && d && cpy_type(s->type) && cpy_type(d->type) && ggml_nelements(s) == ggml_nelements(d);
 }
 bool supports_cpy(const ggml_tensor * op) {
     const ggml_tensor * s = op->src[0], * d = op->src[1];

@@ -274,6 +274,12 @@ int pkv_attn_prefill(const pkv_attn_args * args, void * stream) {
     return launch_attn_prefill(*args, (hipStream_t) stream);
 }
 
+int pkv_flash_attn_ext_flat(const pkv_flat_attn_args * args, void * stream) {
+    if (int rc = ensure_device()) return rc;
+    PKV_REQUIRE(args != nullptr, "pkv_flash_attn_ext_flat: null args");
+    return launch_attn_flat(*args, (hipStream_t) stream);
+}
+
 int pkv_attn_prefill_step(const pkv_attn_args * args, const pkv_step_args * step, const int32_t * slot_block, const int32_t * slot_off, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(args != nullptr && step != nullptr && slot_block && slot_off, "pkv_attn_prefill_step: null args");

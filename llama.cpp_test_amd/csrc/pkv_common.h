@@ -148,6 +148,7 @@ int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * 
                     const RopeDev * rope, int n_tok, int n_head_kv, int D, int block_size, hipStream_t st, const float * rope_cache = nullptr);
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_args * step = nullptr);
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * rope_cache = nullptr);   // rope_cache: RoPE(Q) fused in (NORM pairs)
+int launch_attn_flat(const pkv_flat_attn_args & a, hipStream_t st);   // pkv_attn_flat.hip
 int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);

@@ -184,6 +184,16 @@ __device__ __forceinline__ int64_t offset_of(int64_t i, const Strided4 & t) {
     const int64_t i2 = i % t.ne[2], i3 = i / t.ne[2];
     return i0 * t.nb[0] + i1 * t.nb[1] + i2 * t.nb[2] + i3 * t.nb[3];
 }
+// ggml_bf16_t with the reference's conversions (ggml_compute_fp32_to_bf16 / _bf16_to_fp32, /ref/ggml/src/ggml-impl.h:519-551: nearest even, NaNs forced quiet)
+struct bf16_t {
+    unsigned short bits;
+    bf16_t() = default;
+    __device__ explicit bf16_t(float f) {
+        const unsigned u = __float_as_uint(f);
+        bits = (u & 0x7fffffffu) > 0x7f800000u ? (unsigned short) ((u >> 16) | 64u) : (unsigned short) ((u + (0x7fffu + ((u >> 16) & 1u))) >> 16);
+    }
+    __device__ explicit operator float() const { return __uint_as_float((unsigned) bits << 16); }
+};
 template <typename ST, typename DT>
 __global__ void __launch_bounds__(256) cpy_strided_kernel(const char * src, char * dst, int64_t n, const Strided4 s, const Strided4 d) {
     for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256)
@@ -532,11 +542,18 @@ int launch_cpy_strided(const void * src, int src_type, const int64_t * ne_s, con
     PKV_REQUIRE(n == nd, "pkv_cpy_strided: element counts differ");
     if (n == 0) return PKV_OK;
     const unsigned grid = (unsigned) std::min<int64_t>((n + 255) / 256, 65535);
-    if (src_type == PKV_TYPE_F32 && dst_type == PKV_TYPE_F32)      hipLaunchKernelGGL((cpy_strided_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
-    else if (src_type == PKV_TYPE_F32 && dst_type == PKV_TYPE_F16) hipLaunchKernelGGL((cpy_strided_kernel<float, _Float16>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
-    else if (src_type == PKV_TYPE_F16 && dst_type == PKV_TYPE_F16) hipLaunchKernelGGL((cpy_strided_kernel<_Float16, _Float16>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
-    else if (src_type == PKV_TYPE_F16 && dst_type == PKV_TYPE_F32) hipLaunchKernelGGL((cpy_strided_kernel<_Float16, float>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d);
-    else { set_error("pkv_cpy_strided: types %d -> %d not supported (f32 / f16)", src_type, dst_type); return PKV_ERR_UNSUPPORTED; }
+#define PKV_CPY(ST, DT) hipLaunchKernelGGL((cpy_strided_kernel<ST, DT>), dim3(grid), dim3(256), 0, st, (const char *) src, (char *) dst, n, s, d)
+    if (src_type == PKV_TYPE_F32 && dst_type == PKV_TYPE_F32)        PKV_CPY(float, float);
+    else if (src_type == PKV_TYPE_F32 && dst_type == PKV_TYPE_F16)   PKV_CPY(float, _Float16);
+    else if (src_type == PKV_TYPE_F16 && dst_type == PKV_TYPE_F16)   PKV_CPY(_Float16, _Float16);
+    else if (src_type == PKV_TYPE_F16 && dst_type == PKV_TYPE_F32)   PKV_CPY(_Float16, float);
+    else if (src_type == PKV_TYPE_F32 && dst_type == PKV_TYPE_BF16)  PKV_CPY(float, bf16_t);     // the KV store of a bf16 cache (-ctk / -ctv bf16)
+    else if (src_type == PKV_TYPE_F16 && dst_type == PKV_TYPE_BF16)  PKV_CPY(_Float16, bf16_t);
+    else if (src_type == PKV_TYPE_BF16 && dst_type == PKV_TYPE_BF16) PKV_CPY(bf16_t, bf16_t);
+    else if (src_type == PKV_TYPE_BF16 && dst_type == PKV_TYPE_F32)  PKV_CPY(bf16_t, float);
+    else if (src_type == PKV_TYPE_BF16 && dst_type == PKV_TYPE_F16)  PKV_CPY(bf16_t, _Float16);
+#undef PKV_CPY
+    else { set_error("pkv_cpy_strided: types %d -> %d not supported (f32 / f16 / bf16)", src_type, dst_type); return PKV_ERR_UNSUPPORTED; }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }

@@ -23,6 +23,7 @@ size_t pkv_o_row_size(int type, int64_t ne) {
     switch (type) {
         case PKV_O_F32:  return (size_t) ne * 4;
         case PKV_O_F16:  return (size_t) ne * 2;
+        case PKV_O_BF16: return (size_t) ne * 2;
         case PKV_O_Q8_0: return (size_t) (ne / QK) * 34;  // block_q8_0 {half d; int8 qs[32]} ggml-common.h:203-208
         case PKV_O_Q4_0: return (size_t) (ne / QK) * 18;  // block_q4_0 {half d; uint8 qs[16]} ggml-common.h:161-166
         default: return 0;
@@ -31,6 +32,17 @@ size_t pkv_o_row_size(int type, int64_t ne) {
 
 void pkv_o_f32_to_f16(const float * x, uint16_t * y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = f2h(x[i]); }
 void pkv_o_f16_to_f32(const uint16_t * x, float * y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = h2f(x[i]); }
+
+// ggml_compute_fp32_to_bf16 / ggml_compute_bf16_to_fp32 (ggml/src/ggml-impl.h:519-551): round to nearest even, NaNs forced quiet
+static inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((u >> 16) | 64);
+    return (uint16_t) ((u + (0x7fffu + ((u >> 16) & 1))) >> 16);
+}
+static inline float bf2f(uint16_t h) { const uint32_t u = (uint32_t) h << 16; float f; memcpy(&f, &u, 4); return f; }
+void pkv_o_f32_to_bf16(const float * x, uint16_t * y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = f2bf(x[i]); }
+void pkv_o_bf16_to_f32(const uint16_t * x, float * y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = bf2f(x[i]); }
 
 // ggml/src/ggml-quants.c:194-215
 void pkv_o_quantize_q8_0_ref(const float * x, void * vy, int64_t k) {
@@ -88,6 +100,7 @@ void pkv_o_to_float(int type, const void * vx, float * y, int64_t k) {
     const uint8_t * x = (const uint8_t *) vx;
     if (type == PKV_O_F32) { memcpy(y, vx, (size_t) k * 4); return; }
     if (type == PKV_O_F16) { pkv_o_f16_to_f32((const uint16_t *) vx, y, k); return; }
+    if (type == PKV_O_BF16) { pkv_o_bf16_to_f32((const uint16_t *) vx, y, k); return; }
     for (int64_t i = 0; i < k / QK; ++i) {
         uint16_t dh;
         if (type == PKV_O_Q8_0) {
@@ -111,6 +124,7 @@ void pkv_o_from_float(int type, const float * x, void * y, int64_t k) {
     switch (type) {
         case PKV_O_F32:  memcpy(y, x, (size_t) k * 4); break;
         case PKV_O_F16:  pkv_o_f32_to_f16(x, (uint16_t *) y, k); break;
+        case PKV_O_BF16: pkv_o_f32_to_bf16(x, (uint16_t *) y, k); break;
         case PKV_O_Q8_0: pkv_o_quantize_q8_0_cpu(x, y, k); break;
         case PKV_O_Q4_0: pkv_o_quantize_q4_0(x, y, k); break;
     }
@@ -200,6 +214,35 @@ static float vec_dot_f16(int n, const uint16_t * x, const uint16_t * y) {
     return (float) sumf;
 }
 
+// ggml_vec_dot_bf16, AVX2 branch (ggml-cpu.c:1537-1562): four 8-lane accumulators over steps of 32 (product then add; BF16_FMA: what the
+// compiler made of it in oracle/_ref), c1 + c3 and c2 + c4, the halves, movehl, movehdup; leftovers in double
+#ifndef BF16_FMA
+#define BF16_FMA 1
+#endif
+static float vec_dot_bf16(int n, const uint16_t * x, const uint16_t * y) {
+    float c[4][8];
+    memset(c, 0, sizeof(c));
+    const int np = n & ~31;
+    for (int i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; ++j)
+            for (int l = 0; l < 8; ++l) {
+                const float a = bf2f(x[i + j * 8 + l]), b = bf2f(y[i + j * 8 + l]);
+#if BF16_FMA
+                c[j][l] = fmaf(a, b, c[j][l]);
+#else
+                volatile float pr = a * b;
+                c[j][l] = pr + c[j][l];
+#endif
+            }
+    float t[8], g[4];
+    for (int l = 0; l < 8; ++l) t[l] = (c[0][l] + c[2][l]) + (c[1][l] + c[3][l]);
+    for (int l = 0; l < 4; ++l) g[l] = t[l + 4] + t[l];
+    g[0] += g[2]; g[1] += g[3];
+    double sumf = (double) (g[0] + g[1]);
+    for (int i = np; i < n; ++i) sumf += (double) (bf2f(x[i]) * bf2f(y[i]));
+    return (float) sumf;
+}
+
 static inline float hsum8(const float * a) {  // hsum_float_8, ggml-cpu-quants.c:49-55
     float r[4];
     for (int l = 0; l < 4; ++l) r[l] = a[l + 4] + a[l];
@@ -255,17 +298,19 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
                          int D, int n_q, int n_head, int n_kv, int n_head_kv, int mask_stride,
                          int type_k, int type_v, float scale, float max_bias, float logit_softcap,
                          int n_threads) {
-    if (type_k != PKV_O_F16 && type_k != PKV_O_Q8_0 && type_k != PKV_O_Q4_0) return -1;
-    if (type_v != PKV_O_F16 && type_v != PKV_O_Q8_0 && type_v != PKV_O_Q4_0) return -1;
+    if (type_k != PKV_O_F16 && type_k != PKV_O_BF16 && type_k != PKV_O_Q8_0 && type_k != PKV_O_Q4_0) return -1;
+    if (type_v != PKV_O_F16 && type_v != PKV_O_BF16 && type_v != PKV_O_Q8_0 && type_v != PKV_O_Q4_0) return -1;
+    if (D > 512 || ((type_k == PKV_O_Q8_0 || type_k == PKV_O_Q4_0 || type_v == PKV_O_Q8_0 || type_v == PKV_O_Q4_0) && D % QK != 0)) return -1;
     if (logit_softcap != 0) scale /= logit_softcap;                                   // :12290-12292
     const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2(n_head));               // :12295
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2);
     const float m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
     const size_t rk = pkv_o_row_size(type_k, D), rv = pkv_o_row_size(type_v, D);
     const int gq = n_head / n_head_kv;                                               // rk2 :12264
-    // k's vec_dot_type: f16 for f16, q8_0 for q8_0/q4_0 (type_traits_cpu, ggml-cpu.c:240-300)
-    const int q_type = type_k == PKV_O_F16 ? PKV_O_F16 : PKV_O_Q8_0;
+    // k's vec_dot_type: f16 for f16, bf16 for bf16, q8_0 for q8_0/q4_0 (type_traits_cpu, ggml-cpu.c:240-300,403-405)
+    const int q_type = type_k == PKV_O_F16 ? PKV_O_F16 : type_k == PKV_O_BF16 ? PKV_O_BF16 : PKV_O_Q8_0;
     const int nr = n_head * n_q;
+    const int D32 = D & ~31;                                                         // GGML_F32_STEP == GGML_F16_STEP == 32 (AVX2)
     if (n_threads < 1) n_threads = 1;
 
 #pragma omp parallel for num_threads(n_threads) schedule(static)
@@ -283,6 +328,7 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
         const int hk = h / gq;
         const float * pq = q + ((size_t) h * n_q + iq) * D;
         if (q_type == PKV_O_F16) pkv_o_f32_to_f16(pq, (uint16_t *) Qq, D);
+        else if (q_type == PKV_O_BF16) pkv_o_f32_to_bf16(pq, (uint16_t *) Qq, D);
         else                     pkv_o_quantize_q8_0_cpu(pq, Qq, D);                 // :12343
         float * lg = logits ? logits + ((size_t) h * n_q + iq) * n_kv : NULL;
 
@@ -292,6 +338,7 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
             const uint8_t * kd = (const uint8_t *) k + ((size_t) hk * n_kv + ic) * rk;
             float s;
             if (type_k == PKV_O_F16)       s = vec_dot_f16(D, (const uint16_t *) kd, (const uint16_t *) Qq);
+            else if (type_k == PKV_O_BF16) s = vec_dot_bf16(D, (const uint16_t *) kd, (const uint16_t *) Qq);
             else if (type_k == PKV_O_Q8_0) s = vec_dot_q8_0_q8_0(D, kd, Qq);
             else                           s = vec_dot_q4_0_q8_0(D, kd, Qq);
             s = s * scale;
@@ -309,7 +356,8 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
                     vs = expf(s - M);
                 }
                 const uint16_t * vh = (const uint16_t *) vd;
-                for (int d = 0; d < D; ++d) VKQ16[d] = f2h(fmaf(h2f(vh[d]), vs, h2f(VKQ16[d])));  // ggml_vec_mad_f16 (FMA)
+                for (int d = 0; d < D32; ++d) VKQ16[d] = f2h(fmaf(h2f(vh[d]), vs, h2f(VKQ16[d])));  // ggml_vec_mad_f16 (FMA)
+                for (int d = D32; d < D; ++d) VKQ16[d] = f2h(h2f(VKQ16[d]) + h2f(vh[d]) * vs);     // leftovers of a 32-element step: product, then sum (ggml-cpu.c:1693-1723)
             } else {                                                                 // :12389-12406
                 if (s > M) {
                     M = s; ms = expf(Mold - M);
@@ -318,7 +366,8 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
                     vs = expf(s - M);
                 }
                 pkv_o_to_float(type_v, vd, V32, D);
-                for (int d = 0; d < D; ++d) VKQ32[d] = fmaf(V32[d], vs, VKQ32[d]);   // ggml_vec_mad_f32 (FMA)
+                for (int d = 0; d < D32; ++d) VKQ32[d] = fmaf(V32[d], vs, VKQ32[d]);   // ggml_vec_mad_f32 (FMA)
+                for (int d = D32; d < D; ++d) VKQ32[d] = VKQ32[d] + V32[d] * vs;      // leftovers (head size 80): not fused (:1662-1691; -std=c11 contracts nothing)
             }
             S = S * ms + vs;                                                         // :12408
         }

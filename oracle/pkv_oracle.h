@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 // numeric values follow enum ggml_type (ggml/include/ggml.h:350-360)
-enum { PKV_O_F32 = 0, PKV_O_F16 = 1, PKV_O_Q4_0 = 2, PKV_O_Q8_0 = 8 };
+enum { PKV_O_F32 = 0, PKV_O_F16 = 1, PKV_O_Q4_0 = 2, PKV_O_Q8_0 = 8, PKV_O_BF16 = 30 };
 
 // ggml_row_size (ggml/src/ggml.c) for the four KV-relevant types
 size_t pkv_o_row_size(int type, int64_t ne);
@@ -26,6 +26,10 @@ size_t pkv_o_row_size(int type, int64_t ne);
 // f32 <-> f16, round-to-nearest-even (GGML_FP32_TO_FP16 on x86 = F16C, ggml/src/ggml-impl.h)
 void pkv_o_f32_to_f16(const float * x, uint16_t * y, int64_t n);
 void pkv_o_f16_to_f32(const uint16_t * x, float * y, int64_t n);
+
+// f32 <-> bf16 (ggml_compute_fp32_to_bf16, ggml/src/ggml-impl.h:538-551: nearest even, quiet NaNs)
+void pkv_o_f32_to_bf16(const float * x, uint16_t * y, int64_t n);
+void pkv_o_bf16_to_f32(const uint16_t * x, float * y, int64_t n);
 
 // quantize_row_q8_0_ref (ggml/src/ggml-quants.c:194-215): id = 1/d, roundf (ties away)
 void pkv_o_quantize_q8_0_ref(const float * x, void * y, int64_t k);

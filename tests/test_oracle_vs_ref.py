@@ -8,8 +8,8 @@ from oracle import cpu_oracle as O
 pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
 
 
-@pytest.mark.parametrize("tk,tv", [(O.F16, O.F16), (O.Q8_0, O.Q8_0), (O.Q4_0, O.Q4_0), (O.Q8_0, O.F16), (O.F16, O.Q4_0)])
-@pytest.mark.parametrize("D,nh,nkv,n_kv,n_q", [(128, 8, 2, 512, 1), (128, 4, 4, 257, 7), (64, 8, 1, 300, 2)])
+@pytest.mark.parametrize("tk,tv", [(O.F16, O.F16), (O.Q8_0, O.Q8_0), (O.Q4_0, O.Q4_0), (O.Q8_0, O.F16), (O.F16, O.Q4_0), (O.BF16, O.BF16), (O.BF16, O.Q8_0)])
+@pytest.mark.parametrize("D,nh,nkv,n_kv,n_q", [(128, 8, 2, 512, 1), (128, 4, 4, 257, 7), (64, 8, 1, 300, 2), (256, 4, 2, 200, 3), (96, 4, 4, 130, 2)])
 def test_flash_attn_bit_exact(tk, tv, D, nh, nkv, n_kv, n_q):
     rng = np.random.default_rng(n_kv * 31 + tk * 7 + tv)
     q = rng.uniform(-1, 1, (nh, n_q, D)).astype(np.float32)
@@ -25,14 +25,33 @@ def test_flash_attn_bit_exact(tk, tv, D, nh, nkv, n_kv, n_q):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("tk", [O.F16, O.BF16])
+def test_flash_attn_head_size_80_bit_exact(tk):
+    """head size 80 (tests/test-backend-ops.cpp:4367): not a multiple of the 32-element steps of the vector dots, the leftovers run in double"""
+    rng = np.random.default_rng(80 + tk)
+    D, nh, nkv, n_kv, n_q = 80, 4, 4, 300, 3
+    q = rng.uniform(-1, 1, (nh, n_q, D)).astype(np.float32)
+    k = O.from_float(tk, rng.uniform(-1, 1, (nkv, n_kv, D)).astype(np.float32))
+    v = O.from_float(tk, rng.uniform(-1, 1, (nkv, n_kv, D)).astype(np.float32))
+    mask = np.zeros((n_q, n_kv), np.float16)
+    mask[:, 280:] = -np.inf
+    for mb in (0.0, 8.0):
+        a = O.flash_attn_ext(q, k, v, mask, type_k=tk, type_v=tk, scale=D ** -0.5, max_bias=mb, n_threads=3)
+        b = O.ref_flash_attn_ext(q, k, v, mask, type_k=tk, type_v=tk, scale=D ** -0.5, max_bias=mb, n_threads=2)
+        assert np.array_equal(a, b)
+
+
 def test_codecs_bit_exact():
     rng = np.random.default_rng(7)
     x = (rng.standard_normal((257, 128)) * rng.choice([1e-3, 1.0, 50.0], (257, 1))).astype(np.float32)
     x[::17] = np.round(x[::17] * 4) / 4
-    for t in (O.F16, O.Q8_0, O.Q4_0):
+    x[3, :4] = [np.nan, np.inf, -np.inf, 0.0]
+    for t in (O.F16, O.Q8_0, O.Q4_0, O.BF16):
+        if t in (O.Q8_0, O.Q4_0):
+            x[3, :4] = 0.0
         assert np.array_equal(O.from_float(t, x), O.ref_cpy(t, x, n_threads=2))
         b = O.from_float(t, x)
-        assert np.array_equal(O.to_float(t, b, 128), O.ref_to_float(t, b, 128))
+        assert np.array_equal(O.to_float(t, b, 128).view(np.uint32), O.ref_to_float(t, b, 128).view(np.uint32))     # (bits: the row holds a NaN)
     assert np.array_equal(O.from_float(O.Q8_0, x, "ref"), O.ref_from_float_ref(O.Q8_0, x))
 
 
