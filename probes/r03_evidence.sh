@@ -48,7 +48,7 @@ step "the reference's harness"
 export GGML_BACKEND_PATH=$PWD/llama.cpp_test_amd/libggml-mi355.so
 for op in FLASH_ATTN_EXT ROPE ROPE_BACK CPY CONT RMS_NORM ADD MUL SILU MUL_MAT SOFT_MAX; do
   timeout -k 10 600 oracle/_ref/test-backend-ops test -o $op 2>&1 | sed 's/\x1b\[[0-9;]*m//g' > $O/tbo_$op.txt
-  echo "$op OK=$(grep -c ': OK' $O/tbo_$op.txt) FAIL=$(grep -c FAIL $O/tbo_$op.txt) not-supported=$(grep -c 'not supported' $O/tbo_$op.txt)"
+  echo "$op OK=$(grep -c '): OK' $O/tbo_$op.txt) FAIL=$(grep -c FAIL $O/tbo_$op.txt) not-supported=$(grep -c 'not supported' $O/tbo_$op.txt)"
 done
 unset GGML_BACKEND_PATH
 find $O -name "*_agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete

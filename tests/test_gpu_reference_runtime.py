@@ -29,6 +29,8 @@ MODELS = {
     # K and V in a side buffer, gate / up in one launch) at prefill widths and at decode
     "llama3_q4k": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=79,
                        rope_freqs=True, wtype=12),
+    # head size 256 (Gemma-like geometry in a llama graph), gqa 2, f16 weights: outside the paged kernels' geometries -> pkv_flash_attn_ext_flat
+    "hs256": dict(n_layer=2, n_embd=1024, n_head=4, n_head_kv=2, n_ff=1024, n_vocab=96, n_ctx=1024, rope_freq_base=10000.0, seed=81),
     # ... and with the tensor mix of a Q5_K_M file (q5_K + q6_K; r03): every q5_K product, one column or many, through the MFMA product
     "llama3_q5km": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=80,
                         rope_freqs=True, wtype=13, k_mix=True),
@@ -102,6 +104,38 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
             print("call", ci, "logits nmse %.3e" % nmse(logit_g, logit_c), flush=True)
             continue
         assert nmse(logit_g, logit_c) <= bar, (ci, bar)
+
+
+@pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
+@pytest.mark.parametrize("model,tk", [("tiny", 30), ("llama3", 30), ("hs256", 1), ("hs256", 8), ("hs256", 30)])
+def test_llama_decode_outside_the_paged_geometries(pkv, tmp_path, model, tk):
+    """r03: what the paged kernels do not take runs through pkv_flash_attn_ext_flat inside the unmodified reference runtime — a bf16 KV cache (`-ctk bf16
+    -ctv bf16`, /root/reference/common/arg.cpp:172-182: the KV store is the plugin's f32 -> bf16 strided CPY, the cache tensors stay flat bf16 rows) and head
+    size 256 (f16 / q8_0 / bf16 cache).  Expected values: the CPU-only run of the same library, per-layer kqv_out NMSE <= 5e-4, logits as in the test above."""
+    from llama_cpp_test_amd import gguf_synth as G
+    MODEL = MODELS[model]
+    path = str(tmp_path / "m.gguf")
+    G.synth_llama(path, **MODEL)
+    rng = np.random.default_rng(15 + tk)
+    calls = [([0] * 100, list(range(100))), ([0] * 70 + [1] * 33, list(range(100, 170)) + list(range(33)))] + [([0, 1], [170 + i, 33 + i]) for i in range(3)]
+    toks = [rng.integers(0, MODEL["n_vocab"], len(c[0])) for c in calls]
+
+    def run(gpu_layers):
+        R.set_gpu_layers(gpu_layers)
+        m = R.RefModel(path, n_ctx=512, n_batch=128, n_seq_max=2, flash_attn=True, type_k=tk, type_v=tk, n_threads=8)
+        outs = []
+        for (sid, pos), t in zip(calls, toks):
+            layers = m.decode(t, pos, sid)
+            outs.append(([layers[il]["out"].copy() for il in sorted(layers)], m.logits(MODEL["n_vocab"]).copy()))
+        return outs
+    cpu = run(0)
+    R.load_backend(PLUGIN)
+    gpu = run(99)
+    R.set_gpu_layers(0)
+    for ci, ((lc, logit_c), (lg, logit_g)) in enumerate(zip(cpu, gpu)):
+        for il, (a, b) in enumerate(zip(lc, lg)):
+            assert np.isfinite(b).all() and nmse(b, a) <= 5e-4, (ci, il, nmse(b, a))
+        assert nmse(logit_g, logit_c) <= (2e-3 if MODEL.get("wtype") == 8 else 5e-4), (ci, nmse(logit_g, logit_c))
 
 
 @pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
