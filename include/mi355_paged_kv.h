@@ -51,7 +51,9 @@ enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_
                 PKV_TYPE_Q4_K = 12, /* weights of pkv_mul_mat / pkv_gemv_q only (block_q4_K, /ref/ggml/src/ggml-common.h:279-290); not a KV type */
                 PKV_TYPE_Q5_K = 13, /* weights of pkv_mul_mat / pkv_get_rows (block_q5_K, :291-308; Q5_K_M files): every column count through the MFMA product */
                 PKV_TYPE_Q6_K = 14, /* weights of pkv_gemv_q / pkv_get_rows only (block_q6_K, :309-319): what a Q4_K_M file mixes in          */
-                PKV_TYPE_BF16 = 30  /* K / V rows of pkv_flash_attn_ext_flat only (ggml_bf16_t, /ref/ggml/include/ggml.h:339-342): not a pool type */ };
+                PKV_TYPE_BF16 = 30, /* K / V rows of pkv_flash_attn_ext_flat only (ggml_bf16_t, /ref/ggml/include/ggml.h:339-342): not a pool type */
+                /* the remaining cache types of /ref/common/arg.cpp:172-182 — flat rows only: pkv_convert_f32 (the KV store) and pkv_flash_attn_ext_flat */
+                PKV_TYPE_Q4_1 = 3, PKV_TYPE_Q5_0 = 6, PKV_TYPE_Q5_1 = 7, PKV_TYPE_IQ4_NL = 20 };
 
 enum pkv_status {
     PKV_OK              =  0,
@@ -98,7 +100,9 @@ int pkv_rope_f16_strided(const void * x, int64_t x_stride_tok, int64_t x_stride_
                          int n_tok, int n_head, int head_dim, const pkv_rope_params * rope, int inverse, void * stream);
 
 /* GGML_OP_CPY f32 -> f16/q8_0/q4_0 into a CONTIGUOUS typed tensor in the reference's own byte format
- * (ggml_compute_forward_dup_f32, /ref/ggml/src/ggml-cpu/ggml-cpu.c:3742): x f32 [n_rows][ne0], ne0 % 64 == 0. */
+ * (ggml_compute_forward_dup_f32, /ref/ggml/src/ggml-cpu/ggml-cpu.c:3742): x f32 [n_rows][ne0], ne0 % 64 == 0.
+ * Also q4_1 / q5_0 / q5_1 / iq4_nl (ne0 % 32 == 0; the *_ref quantizers the CPU backend's from_float forwards to,
+ * /ref/ggml/src/ggml-quants.c:68-190, :4573-4720): bit-exact, all-zero iq4_nl blocks excepted (the reference leaves their indices undefined). */
 int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, void * stream);
 /* the same store for n_cells KV rows ([n_cells][n_head_kv][head_dim] f32) that ALSO lands in a paged pool with identity placement
  * (cell c = block c / block_size, offset c % block_size; K or V layout by is_v): dst gets the reference's bytes for cells
@@ -277,7 +281,7 @@ int pkv_attn_prefill(const pkv_attn_args * args, void * stream);
  * q8_0 with the AVX2 rounding).  One workgroup per (query row, head): a coverage kernel, not a roofline one — callers ask the paged kernels first (the
  * ggml-backend plugin does).
  *   q    : device f32, row (t, h) at q + t*q_stride_tok + h*q_stride_head (floats)       [ggml q: ne = {D, n_q, n_head}]
- *   k, v : device bytes, row (cell c, kv head g) at k + c*k_stride_tok + g*k_stride_head (BYTES = ggml nb[1], nb[2]), types PKV_TYPE_F16 / _BF16 / _Q8_0 / _Q4_0
+ *   k, v : device bytes, row (cell c, kv head g) at k + c*k_stride_tok + g*k_stride_head (BYTES = ggml nb[1], nb[2]), types PKV_TYPE_F16 / _BF16 / _Q8_0 / _Q4_0 / _Q4_1 / _Q5_0 / _Q5_1 / _IQ4_NL
  *   mask : device f16 [n_q][mask_stride] or NULL (no causal structure is implied: what is not masked is seen); max_bias > 0 = ALiBi slopes on the mask
  *   out  : device f32 [n_q][n_head][head_dim]                                             [ggml dst: ne = {D, n_head, n_q}]                                  */
 typedef struct pkv_flat_attn_args {

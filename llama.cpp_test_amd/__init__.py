@@ -27,7 +27,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355_paged_kv.h"
 
 # enum pkv_type (= enum ggml_type values)
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, BF16 = 0, 1, 2, 8, 12, 13, 14, 30
-TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K, "bf16": BF16}
+Q4_1, Q5_0, Q5_1, IQ4_NL = 3, 6, 7, 20   # cache types that exist as flat rows only (convert_f32, flash_attn_ext_flat)
+TYPE_BY_NAME = {"f32": F32, "f16": F16, "q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K, "bf16": BF16, "q4_1": Q4_1, "q5_0": Q5_0, "q5_1": Q5_1,
+                "iq4_nl": IQ4_NL}
 # enum pkv_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SPACE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 PACKED = 0x100          # PKV_TYPE_PACKED: K-quant rows in the plane layout (csrc/pkv_wlayout.h), produced by weights_pack()

@@ -337,7 +337,8 @@ bool fa_paged_ok(const ggml_tensor * op) {
     return true;
 }
 // pkv_flash_attn_ext_flat: the rest of the operator's domain, on the tensors as they lie (head sizes up to 256, bf16 rows, any gqa ratio)
-bool fa_flat_type(ggml_type t) { return t == GGML_TYPE_F16 || t == GGML_TYPE_BF16 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0; }
+bool flat_only_kv(ggml_type t) { return t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL; }   // cache types that stay flat rows
+bool fa_flat_type(ggml_type t) { return t == GGML_TYPE_F16 || t == GGML_TYPE_BF16 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0 || flat_only_kv(t); }
 bool fa_flat_ok(const ggml_tensor * op) {
     const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2];
     if (!fa_flat_type(k->type) || !fa_flat_type(v->type)) return false;
@@ -547,9 +548,12 @@ bool supports_cpy(const ggml_tensor * op) {
     // (/ref/src/llama-graph.cpp:1375-1397): shapes differ, the element order does not; rows of 64/128 keep quant blocks whole
     if (s && d && s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) &&
         ggml_nelements(s) == ggml_nelements(d) && s->ne[0] % 64 == 0) return true;
+    // the KV store of a q4_1 / q5_0 / q5_1 / iq4_nl cache (flat rows, read by pkv_flash_attn_ext_flat): the reference's *_ref quantizers, block by block
+    if (s && d && s->type == GGML_TYPE_F32 && flat_only_kv(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) && ggml_nelements(s) == ggml_nelements(d) &&
+        s->ne[0] % 32 == 0) return true;
     // defrag moves of a quantized cache (build_kv_self_defrag, /ref/src/llama-context.cpp:668-711): same type, same shape, contiguous row ranges — cells of a
     // tensor that is its own pool (run_cpy_cells) or flat bytes (a staged byte copy); f16 moves also pass the plain-type rule below
-    if (s && d && s->type == d->type && kv_type(s->type) && ggml_are_same_shape(s, d) && ggml_is_contiguous(s) && ggml_is_contiguous(d)) return true;
+    if (s && d && s->type == d->type && (kv_type(s->type) || flat_only_kv(s->type)) && ggml_are_same_shape(s, d) && ggml_is_contiguous(s) && ggml_is_contiguous(d)) return true;
     return supports_cpy_strided(s, d);
 }
 bool supports_cont(const ggml_tensor * op) { return supports_cpy_strided(op->src[0], op) && op->src[0]->type == op->type; }
@@ -633,6 +637,12 @@ ggml_status run_cpy_strided(backend_ctx * bc, const ggml_tensor * s, ggml_tensor
 ggml_status run_cpy(backend_ctx * bc, ggml_tensor * op) {
     const ggml_tensor * s = op->src[0];
     ggml_tensor * d = op->src[1];
+    if (s->type == GGML_TYPE_F32 && flat_only_kv(d->type)) {
+        const int rc = pkv_convert_f32((const float *) bc->src_data(s), d->data, d->type, ggml_nrows(s), s->ne[0], bc->stream);
+        if (rc) { MI355_LOG("cpy failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
+        note_write_all(d);
+        return GGML_STATUS_SUCCESS;
+    }
     if (!(s->type == GGML_TYPE_F32 && kv_type(d->type) && ggml_is_contiguous(s) && ggml_is_contiguous(d) && s->ne[0] % 64 == 0)) return run_cpy_strided(bc, s, d);
     // the KV store of a step into a cache tensor that already has its paged mirror: flat bytes and mirror rows in ONE launch (same
     // quantized bits), nothing left to re-scatter at the next attention call

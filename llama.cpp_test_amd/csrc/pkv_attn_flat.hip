@@ -3,7 +3,8 @@
 // The paged decode / prefill kernels (pkv_attn_decode.hip, pkv_attn_prefill.hip) are cut for the north-star geometries: head size 64 / 128, f16 / q8_0 / q4_0
 // tiles of a block pool.  The operator they stand in for — ggml_compute_forward_flash_attn_ext_f16 (/ref/ggml/src/ggml-cpu/ggml-cpu.c:12219-12432) — is
 // wider: any head size, bf16 K / V (CLI-whitelisted cache type, /ref/common/arg.cpp:172-182), any gqa ratio, K / V as strided views of flat tensors
-// (/ref/tests/test-backend-ops.cpp:4367-4390 tests head sizes 64 / 80 / 128 / 256 x f16 / bf16 / q8_0 / q4_0).  This file is that width: one kernel that reads
+// (/ref/tests/test-backend-ops.cpp:4367-4390 tests head sizes 64 / 80 / 128 / 256 x f16 / bf16 / q8_0 / q4_0), and the cache types q4_1 / q5_0 / q5_1 / iq4_nl
+// the CLI also accepts (their KV store — GGML_OP_CPY f32 -> type — is quantize_blocks_kernel below).  This file is that width: one kernel that reads
 // the reference's rows where they lie (block_q8_0 34 B, block_q4_0 18 B, 2-byte aligned; 16-bit rows by 16-byte loads when aligned) — no pool, no
 // conversion pass, bf16 stays bf16.
 //
@@ -12,7 +13,7 @@
 // dots of the quantized types are exact in f32 (|sum| <= 32 * 127 * 127); scale, softcap (tanhf), mask * ALiBi slope as :12349-12365; V rows are
 // accumulated in f32 (the reference: f32 for every V type but f16, where its f16 accumulator drifts from exact arithmetic by itself).
 //
-// Shape: one workgroup of 4 waves per (query row, head); wave w walks the 64-token chunks w, w + 4, ..: lane = token for QK^T (the Q operand sits in LDS,
+// Shape: one workgroup of 4 waves (16 for rows of >= 1024 cells) per (query row, head); wave w walks the 64-token chunks w, w + 4, ..: lane = token for QK^T (the Q operand sits in LDS,
 // every lane reads the same address: a broadcast), online softmax per wave, then lane = column for PV (consecutive lanes read consecutive elements of one V
 // row); one cross-wave merge through LDS.  A coverage kernel, not a roofline one: the hot geometries never come here (pkv_flash_attn_ext_flat's callers
 // ask the paged kernels first).
@@ -21,7 +22,7 @@
 namespace pkv {
 namespace {
 
-constexpr int FLAT_NW = 4, FLAT_DMAX = 256;
+constexpr int FLAT_NW = 4, FLAT_NW_LONG = 16, FLAT_DMAX = 256;   // waves per workgroup: 4, or 16 once a row has >= 16 chunks of 64 cells to walk
 
 struct FlatArgs {
     const float * q; int64_t q_s_tok, q_s_head;
@@ -43,6 +44,31 @@ __device__ __forceinline__ float bf_round(float f) {
     return __uint_as_float(((u + (0x7fffu + ((u >> 16) & 1u))) >> 16) << 16);
 }
 template <int T> __device__ __forceinline__ float e16(unsigned short h) { return T == PKV_TYPE_BF16 ? bf2f(h) : h2f(h); }
+
+// the other CLI-whitelisted cache types (/ref/common/arg.cpp:172-182), blocks of 32 as the reference stores them (/ref/ggml/src/ggml-common.h:168-203, :421-426):
+//   q4_1 {half d, m; u8 qs[16]} 20 B   q5_0 {half d; u8 qh[4]; u8 qs[16]} 22 B   q5_1 {half d, m; u8 qh[4]; u8 qs[16]} 24 B   iq4_nl {half d; u8 qs[16]} 18 B
+// element e: low nibbles are elements 0..15, high nibbles 16..31; q5: bit e of qh is the fifth bit; iq4_nl: the nibble indexes kvalues_iq4nl
+template <int T> struct Blk;
+template <> struct Blk<PKV_TYPE_Q4_1>   { static constexpr int B = 20, QS = 4, QH = -1, M = 2;  };
+template <> struct Blk<PKV_TYPE_Q5_0>   { static constexpr int B = 22, QS = 6, QH = 2,  M = -1; };
+template <> struct Blk<PKV_TYPE_Q5_1>   { static constexpr int B = 24, QS = 8, QH = 4,  M = 2;  };
+template <> struct Blk<PKV_TYPE_IQ4_NL> { static constexpr int B = 18, QS = 2, QH = -1, M = -1; };
+template <int T> constexpr bool is_new_blk = T == PKV_TYPE_Q4_1 || T == PKV_TYPE_Q5_0 || T == PKV_TYPE_Q5_1 || T == PKV_TYPE_IQ4_NL;
+template <int T> constexpr bool is_q81 = T == PKV_TYPE_Q4_1 || T == PKV_TYPE_Q5_1;        // K types whose vec_dot_type is q8_1 (type_traits_cpu)
+__device__ __forceinline__ int iq4nl_value(int nib) {                                   // kvalues_iq4nl (/ref/ggml/src/ggml-quants.c:2434), two 64-bit tables
+    const unsigned long long lo = 0xF6EADDCFBFAD9881ull, hi = 0x715945352619'0D01ull;
+    return (int) (signed char) ((nib < 8 ? lo >> (8 * nib) : hi >> (8 * (nib - 8))) & 0xff);
+}
+__device__ __forceinline__ unsigned ld_u32_2(const char * p) {                          // 4 bytes at a 2-byte aligned address
+    return (unsigned) *reinterpret_cast<const unsigned short *>(p) | ((unsigned) *reinterpret_cast<const unsigned short *>(p + 2) << 16);
+}
+// the integer value of element e of a block (q5_0: minus 16; iq4_nl: the table value) given its nibble and fifth bit
+template <int T> __device__ __forceinline__ int blk_value(int nib, unsigned qh, int e) {
+    if constexpr (T == PKV_TYPE_Q4_1)      return nib;
+    else if constexpr (T == PKV_TYPE_IQ4_NL) return iq4nl_value(nib);
+    else if constexpr (T == PKV_TYPE_Q5_0) return (nib | (int) (((qh >> e) & 1u) << 4)) - 16;
+    else                                   return nib | (int) (((qh >> e) & 1u) << 4);
+}
 
 __device__ __forceinline__ float wave_max(float x) {
 #pragma unroll
@@ -87,6 +113,27 @@ __device__ __forceinline__ float k_dot(const char * row, const float * sQ, const
             }
             acc = fmaf(dk * sQd[b], s, acc);                         // (ggml_vec_dot_q8_0_q8_0: d_x * d_y * sum of integer products)
         }
+    } else if constexpr (is_new_blk<KT>) {                           // q4_1 / q5_1 against q8_1 (+ m_k * s_q per block), q5_0 / iq4_nl against q8_0
+        using BK = Blk<KT>;
+        float summs = 0.0f;
+        for (int b = 0; b < D / PKV_QK; ++b) {
+            const char * blk = row + BK::B * b;
+            const float dk = h2f(*reinterpret_cast<const unsigned short *>(blk));
+            unsigned qh = 0;
+            if constexpr (BK::QH >= 0) qh = ld_u32_2(blk + BK::QH);
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned w = *reinterpret_cast<const unsigned short *>(blk + BK::QS + 2 * j);
+                s = fmaf((float) blk_value<KT>((int) (w & 0xf), qh, 2 * j), sQ[32 * b + 2 * j], s);
+                s = fmaf((float) blk_value<KT>((int) ((w >> 4) & 0xf), qh, 2 * j + 16), sQ[32 * b + 2 * j + 16], s);
+                s = fmaf((float) blk_value<KT>((int) ((w >> 8) & 0xf), qh, 2 * j + 1), sQ[32 * b + 2 * j + 1], s);
+                s = fmaf((float) blk_value<KT>((int) (w >> 12), qh, 2 * j + 17), sQ[32 * b + 2 * j + 17], s);
+            }
+            acc = fmaf(dk * sQd[b], s, acc);
+            if constexpr (BK::M >= 0) summs = __fadd_rn(summs, __fmul_rn(h2f(*reinterpret_cast<const unsigned short *>(blk + BK::M)), sQd[FLAT_DMAX / PKV_QK + b]));
+        }
+        acc += summs;
     } else {                                                         // block_q4_0 {half d; uint8 qs[16]}: byte j = elem j | elem j + 16 << 4, minus 8 (:161-166)
         for (int b = 0; b < D / PKV_QK; ++b) {
             const char * blk = row + 18 * b;
@@ -114,6 +161,16 @@ __device__ __forceinline__ float v_elem(const char * row, int d) {
     } else if constexpr (VT == PKV_TYPE_Q8_0) {
         const char * blk = row + 34 * (d >> 5);
         return (float) *reinterpret_cast<const signed char *>(blk + 2 + (d & 31)) * h2f(*reinterpret_cast<const unsigned short *>(blk));
+    } else if constexpr (is_new_blk<VT>) {                           // dequantize_row_q4_1 / _q5_0 / _q5_1 / _iq4_nl: q * d (+ m), product and sum rounded separately
+        using BV = Blk<VT>;
+        const char * blk = row + BV::B * (d >> 5);
+        const int e = d & 31;
+        const unsigned byte = *reinterpret_cast<const unsigned char *>(blk + BV::QS + (e & 15));
+        unsigned qh = 0;
+        if constexpr (BV::QH >= 0) qh = ld_u32_2(blk + BV::QH);
+        const float x = __fmul_rn((float) blk_value<VT>((e & 16) ? (int) (byte >> 4) : (int) (byte & 0xf), qh, e), h2f(*reinterpret_cast<const unsigned short *>(blk)));
+        if constexpr (BV::M >= 0) return __fadd_rn(x, h2f(*reinterpret_cast<const unsigned short *>(blk + BV::M)));
+        else return x;
     } else {
         const char * blk = row + 18 * (d >> 5);
         const unsigned byte = *reinterpret_cast<const unsigned char *>(blk + 2 + (d & 15));
@@ -122,25 +179,33 @@ __device__ __forceinline__ float v_elem(const char * row, int d) {
     }
 }
 
-// grid (n_q, n_head) x 256 threads
+// grid (n_q, n_head) x 256 (1024) threads
 template <int KT, int VT>
-__global__ void __launch_bounds__(64 * FLAT_NW) attn_flat_kernel(const FlatArgs a) {
+__global__ void __launch_bounds__(64 * FLAT_NW_LONG) attn_flat_kernel(const FlatArgs a) {
     const int iq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int D = a.D, hk = h / (a.n_head / a.n_head_kv);
-    __shared__ float sQ[FLAT_DMAX], sQd[FLAT_DMAX / PKV_QK], sAcc[FLAT_NW][FLAT_DMAX], sM[FLAT_NW], sL[FLAT_NW];
+    const int D = a.D, hk = h / (a.n_head / a.n_head_kv), nw = (int) (blockDim.x >> 6);
+    __shared__ float sQ[FLAT_DMAX], sQd[2 * FLAT_DMAX / PKV_QK], sAcc[FLAT_NW_LONG][FLAT_DMAX], sM[FLAT_NW_LONG], sL[FLAT_NW_LONG];
 
     // ---- the Q operand, rounded as the K type's vec_dot_type rounds it (:12343)
     {
         const float x = tid < D ? a.q[(size_t) iq * a.q_s_tok + (size_t) h * a.q_s_head + tid] : 0.0f;
-        if constexpr (KT == PKV_TYPE_F16)       sQ[tid] = (float) (_Float16) x;
+        if (tid >= FLAT_DMAX) {}                                     // (the long form has more threads than columns)
+        else if constexpr (KT == PKV_TYPE_F16)  sQ[tid] = (float) (_Float16) x;
         else if constexpr (KT == PKV_TYPE_BF16) sQ[tid] = bf_round(x);
         else {                                                       // quantize_row_q8_0, AVX2 branch (/ref/ggml/src/ggml-cpu/ggml-cpu-quants.c:808-862)
             float am = fabsf(x);
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));   // the 32 lanes of one block
             const float id = am != 0.0f ? 127.0f / am : 0.0f;
-            sQ[tid] = rintf(x * id);
+            const float qi = rintf(x * id);
+            sQ[tid] = qi;
             if ((tid & 31) == 0) sQd[tid >> 5] = (float) (_Float16) (am / 127.0f);
+            if constexpr (is_q81<KT>) {                              // quantize_row_q8_1 (:1138-1180): s = f16(d * sum of the block's quants), d NOT yet rounded to f16
+                float sm = qi;
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) sm += __shfl_xor(sm, o);
+                if ((tid & 31) == 0) sQd[FLAT_DMAX / PKV_QK + (tid >> 5)] = (float) (_Float16) __fmul_rn(am / 127.0f, sm);
+            }
         }
     }
     __syncthreads();
@@ -151,7 +216,7 @@ __global__ void __launch_bounds__(64 * FLAT_NW) attn_flat_kernel(const FlatArgs 
     const bool ksafe = a.k_al16 != 0;
     float m = -INFINITY, l = 0.0f, acc[FLAT_DMAX / 64] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    for (int c0 = wave * 64; c0 < a.n_kv; c0 += FLAT_NW * 64) {
+    for (int c0 = wave * 64; c0 < a.n_kv; c0 += nw * 64) {
         const int t = c0 + lane;
         float s = -INFINITY;
         if (t < a.n_kv) {
@@ -190,12 +255,10 @@ __global__ void __launch_bounds__(64 * FLAT_NW) attn_flat_kernel(const FlatArgs 
     __syncthreads();
     if (tid < D) {
         float M = sM[0];
-#pragma unroll
-        for (int w = 1; w < FLAT_NW; ++w) M = fmaxf(M, sM[w]);
+        for (int w = 1; w < nw; ++w) M = fmaxf(M, sM[w]);
         float L = 0.0f, o = 0.0f;
         if (M != -INFINITY) {
-#pragma unroll
-            for (int w = 0; w < FLAT_NW; ++w) {
+            for (int w = 0; w < nw; ++w) {
                 const float f = expf(sM[w] - M);
                 L = fmaf(sL[w], f, L);
                 o = fmaf(sAcc[w][tid], f, o);
@@ -207,20 +270,117 @@ __global__ void __launch_bounds__(64 * FLAT_NW) attn_flat_kernel(const FlatArgs 
 
 template <int KT>
 int launch_v(const FlatArgs & fa, int type_v, hipStream_t st) {
-    const dim3 grid(fa.n_q, fa.n_head), block(64 * FLAT_NW);
+    const dim3 grid(fa.n_q, fa.n_head), block(64 * (fa.n_kv >= 64 * FLAT_NW_LONG ? FLAT_NW_LONG : FLAT_NW));
     switch (type_v) {
-        case PKV_TYPE_F16:  hipLaunchKernelGGL((attn_flat_kernel<KT, PKV_TYPE_F16>), grid, block, 0, st, fa); break;
-        case PKV_TYPE_BF16: hipLaunchKernelGGL((attn_flat_kernel<KT, PKV_TYPE_BF16>), grid, block, 0, st, fa); break;
-        case PKV_TYPE_Q8_0: hipLaunchKernelGGL((attn_flat_kernel<KT, PKV_TYPE_Q8_0>), grid, block, 0, st, fa); break;
-        case PKV_TYPE_Q4_0: hipLaunchKernelGGL((attn_flat_kernel<KT, PKV_TYPE_Q4_0>), grid, block, 0, st, fa); break;
+#define PKV_FLAT_V(VT) case VT: hipLaunchKernelGGL((attn_flat_kernel<KT, VT>), grid, block, 0, st, fa); break
+        PKV_FLAT_V(PKV_TYPE_F16); PKV_FLAT_V(PKV_TYPE_BF16); PKV_FLAT_V(PKV_TYPE_Q8_0); PKV_FLAT_V(PKV_TYPE_Q4_0);
+        PKV_FLAT_V(PKV_TYPE_Q4_1); PKV_FLAT_V(PKV_TYPE_Q5_0); PKV_FLAT_V(PKV_TYPE_Q5_1); PKV_FLAT_V(PKV_TYPE_IQ4_NL);
+#undef PKV_FLAT_V
         default: return PKV_ERR_UNSUPPORTED;
     }
     PKV_HIP(hipGetLastError());
     return PKV_OK;
 }
 
-bool flat_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_BF16 || t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0; }
-size_t flat_row_bytes(int t, int D) { return t == PKV_TYPE_Q8_0 ? (size_t) D / PKV_QK * 34 : t == PKV_TYPE_Q4_0 ? (size_t) D / PKV_QK * 18 : (size_t) D * 2; }
+bool flat_blocked(int t) { return t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0 || t == PKV_TYPE_Q4_1 || t == PKV_TYPE_Q5_0 || t == PKV_TYPE_Q5_1 || t == PKV_TYPE_IQ4_NL; }
+bool flat_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_BF16 || flat_blocked(t); }
+size_t flat_row_bytes(int t, int D) {
+    const size_t nb = (size_t) D / PKV_QK;
+    switch (t) {
+        case PKV_TYPE_Q8_0: return nb * 34;
+        case PKV_TYPE_Q4_0: case PKV_TYPE_IQ4_NL: return nb * 18;
+        case PKV_TYPE_Q4_1: return nb * 20;
+        case PKV_TYPE_Q5_0: return nb * 22;
+        case PKV_TYPE_Q5_1: return nb * 24;
+    }
+    return (size_t) D * 2;
+}
+
+// ---- GGML_OP_CPY f32 -> q4_1 / q5_0 / q5_1 / iq4_nl (the KV store of a cache of those types): the CPU backend's from_float of each is the *_ref quantizer
+//      (/ref/ggml/src/ggml-quants.c:68-190, :4573-4720).  One thread per block of 32, the reference's scalar loops with every product and sum rounded
+//      separately (the reference is compiled without contraction): the same bytes.
+template <int T>
+__global__ void __launch_bounds__(256) quantize_blocks_kernel(const float * x, char * dst, int64_t n_blocks) {
+    const int64_t ib = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (ib >= n_blocks) return;
+    const float * xb = x + ib * PKV_QK;
+    char * y = dst + ib * Blk<T>::B;
+    float v[PKV_QK];
+#pragma unroll
+    for (int j = 0; j < PKV_QK; j += 4) { const float4 t = *reinterpret_cast<const float4 *>(xb + j); v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
+    // (the value passes through an opaque register first: hipcc otherwise folds a scale's last multiplication into the conversion as v_fma_mixlo_f16(x, c, +0),
+    //  and (-0) + (+0) = +0 where the reference stores the -0 that max / -16 of an all-zero block is)
+    auto put_h = [&](int off, float f) { asm volatile("" : "+v"(f)); *reinterpret_cast<_Float16 *>(y + off) = (_Float16) f; };
+    unsigned char qs[16];
+    unsigned qh = 0;
+    if constexpr (T == PKV_TYPE_Q4_1 || T == PKV_TYPE_Q5_1) {
+        constexpr int LV = T == PKV_TYPE_Q4_1 ? 15 : 31;
+        float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+#pragma unroll
+        for (int j = 0; j < PKV_QK; ++j) { if (v[j] < mn) mn = v[j]; if (v[j] > mx) mx = v[j]; }
+        const float d = __fdiv_rn(__fsub_rn(mx, mn), (float) LV), id = d ? __fdiv_rn(1.0f, d) : 0.0f;
+        put_h(0, d); put_h(2, mn);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = __fmul_rn(__fsub_rn(v[j], mn), id), x1 = __fmul_rn(__fsub_rn(v[j + 16], mn), id);
+            unsigned xi0, xi1;
+            if constexpr (T == PKV_TYPE_Q4_1) { const int a0 = (int) (signed char) (int) __fadd_rn(x0, 0.5f), a1 = (int) (signed char) (int) __fadd_rn(x1, 0.5f); xi0 = (unsigned) min(15, a0); xi1 = (unsigned) min(15, a1); }
+            else                              { xi0 = (unsigned) (unsigned char) (int) __fadd_rn(x0, 0.5f); xi1 = (unsigned) (unsigned char) (int) __fadd_rn(x1, 0.5f); }
+            qs[j] = (unsigned char) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+            qh |= ((xi0 & 0x10u) >> 4) << j;
+            qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+    } else if constexpr (T == PKV_TYPE_Q5_0) {
+        float amax = 0.0f, mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PKV_QK; ++j) if (amax < fabsf(v[j])) { amax = fabsf(v[j]); mx = v[j]; }
+        const float d = __fdiv_rn(mx, -16.0f), id = d ? __fdiv_rn(1.0f, d) : 0.0f;
+        put_h(0, d);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int a0 = (int) (signed char) (int) __fadd_rn(__fmul_rn(v[j], id), 16.5f), a1 = (int) (signed char) (int) __fadd_rn(__fmul_rn(v[j + 16], id), 16.5f);
+            const unsigned xi0 = (unsigned) (unsigned char) min(31, a0), xi1 = (unsigned) (unsigned char) min(31, a1);
+            qs[j] = (unsigned char) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+            qh |= ((xi0 & 0x10u) >> 4) << j;
+            qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+    } else {                                                          // iq4_nl, ntry = -1: first-pass indices, the scale re-fitted with weights x^2
+        float amax = 0.0f, mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PKV_QK; ++j) { const float ax = fabsf(v[j]); if (ax > amax) { amax = ax; mx = v[j]; } }
+        float dfit = 0.0f;
+        unsigned char L[PKV_QK];
+#pragma unroll
+        for (int j = 0; j < PKV_QK; ++j) L[j] = 0;
+        if (amax >= 1e-15f) {
+            const float id = __fdiv_rn(1.0f, __fdiv_rn(mx, -127.0f));
+            float sumqx = 0.0f, sumq2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PKV_QK; ++j) {
+                const float al = __fmul_rn(id, v[j]);
+                int l;                                                // best_index_int8 (:4562-4571)
+                if (al <= -127.0f) l = 0;
+                else if (al >= 113.0f) l = 15;
+                else {
+                    int ml = 0, mu = 15;
+                    while (mu - ml > 1) { const int mav = (ml + mu) / 2; if (al < (float) iq4nl_value(mav)) mu = mav; else ml = mav; }
+                    l = __fsub_rn(al, (float) iq4nl_value(mu - 1)) < __fsub_rn((float) iq4nl_value(mu), al) ? mu - 1 : mu;
+                }
+                L[j] = (unsigned char) l;
+                const float q = (float) iq4nl_value(l), w = __fmul_rn(v[j], v[j]);
+                sumqx = __fadd_rn(sumqx, __fmul_rn(__fmul_rn(w, q), v[j]));
+                sumq2 = __fadd_rn(sumq2, __fmul_rn(__fmul_rn(w, q), q));
+            }
+            dfit = __fdiv_rn(sumqx, sumq2);
+        }
+        put_h(0, dfit);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) qs[j] = (unsigned char) (L[j] | (L[16 + j] << 4));
+    }
+    if constexpr (Blk<T>::QH >= 0) { *reinterpret_cast<unsigned short *>(y + Blk<T>::QH) = (unsigned short) (qh & 0xffffu); *reinterpret_cast<unsigned short *>(y + Blk<T>::QH + 2) = (unsigned short) (qh >> 16); }
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) *reinterpret_cast<unsigned short *>(y + Blk<T>::QS + j) = (unsigned short) (qs[j] | (qs[j + 1] << 8));
+}
 
 }  // namespace
 
@@ -228,8 +388,8 @@ int launch_attn_flat(const pkv_flat_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.q && a.k && a.v && a.out, "pkv_flash_attn_ext_flat: null pointer");
     PKV_REQUIRE(a.n_q > 0 && a.n_kv > 0 && a.n_head > 0 && a.n_head_kv > 0 && a.n_head % a.n_head_kv == 0, "pkv_flash_attn_ext_flat: bad shape");
     PKV_REQUIRE(a.n_head <= 65535, "pkv_flash_attn_ext_flat: more than 65535 heads");
-    if (!flat_type_ok(a.type_k) || !flat_type_ok(a.type_v)) { set_error("pkv_flash_attn_ext_flat: KV types must be f16 / bf16 / q8_0 / q4_0"); return PKV_ERR_UNSUPPORTED; }
-    const bool quant = a.type_k == PKV_TYPE_Q8_0 || a.type_k == PKV_TYPE_Q4_0 || a.type_v == PKV_TYPE_Q8_0 || a.type_v == PKV_TYPE_Q4_0;
+    if (!flat_type_ok(a.type_k) || !flat_type_ok(a.type_v)) { set_error("pkv_flash_attn_ext_flat: KV types must be f16 / bf16 / q8_0 / q4_0 / q4_1 / q5_0 / q5_1 / iq4_nl"); return PKV_ERR_UNSUPPORTED; }
+    const bool quant = flat_blocked(a.type_k) || flat_blocked(a.type_v);
     if (a.head_dim <= 0 || a.head_dim > FLAT_DMAX || a.head_dim % 2 != 0 || (quant && a.head_dim % PKV_QK != 0)) {
         set_error("pkv_flash_attn_ext_flat: head_dim %d (even, <= %d; a multiple of 32 with quantized K / V)", a.head_dim, FLAT_DMAX);
         return PKV_ERR_UNSUPPORTED;
@@ -259,8 +419,30 @@ int launch_attn_flat(const pkv_flat_attn_args & a, hipStream_t st) {
         case PKV_TYPE_BF16: return launch_v<PKV_TYPE_BF16>(fa, a.type_v, st);
         case PKV_TYPE_Q8_0: return launch_v<PKV_TYPE_Q8_0>(fa, a.type_v, st);
         case PKV_TYPE_Q4_0: return launch_v<PKV_TYPE_Q4_0>(fa, a.type_v, st);
+        case PKV_TYPE_Q4_1: return launch_v<PKV_TYPE_Q4_1>(fa, a.type_v, st);
+        case PKV_TYPE_Q5_0: return launch_v<PKV_TYPE_Q5_0>(fa, a.type_v, st);
+        case PKV_TYPE_Q5_1: return launch_v<PKV_TYPE_Q5_1>(fa, a.type_v, st);
+        case PKV_TYPE_IQ4_NL: return launch_v<PKV_TYPE_IQ4_NL>(fa, a.type_v, st);
     }
     return PKV_ERR_UNSUPPORTED;
+}
+
+// pkv_convert_f32 for the cache types that exist only as flat rows
+int launch_quantize_blocks(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st) {
+    if (ne0 % PKV_QK != 0) { set_error("convert: row length %lld is not a multiple of 32", (long long) ne0); return PKV_ERR_UNSUPPORTED; }
+    PKV_REQUIRE(((uintptr_t) x % 16) == 0 && ((uintptr_t) dst % 2) == 0, "convert: x must be 16-byte aligned, dst 2-byte aligned");
+    const int64_t nb = n_rows * (ne0 / PKV_QK);
+    if (nb == 0) return PKV_OK;
+    const dim3 grid((unsigned) ((nb + 255) / 256)), block(256);
+    switch (type) {
+        case PKV_TYPE_Q4_1:   hipLaunchKernelGGL((quantize_blocks_kernel<PKV_TYPE_Q4_1>), grid, block, 0, st, x, (char *) dst, nb); break;
+        case PKV_TYPE_Q5_0:   hipLaunchKernelGGL((quantize_blocks_kernel<PKV_TYPE_Q5_0>), grid, block, 0, st, x, (char *) dst, nb); break;
+        case PKV_TYPE_Q5_1:   hipLaunchKernelGGL((quantize_blocks_kernel<PKV_TYPE_Q5_1>), grid, block, 0, st, x, (char *) dst, nb); break;
+        case PKV_TYPE_IQ4_NL: hipLaunchKernelGGL((quantize_blocks_kernel<PKV_TYPE_IQ4_NL>), grid, block, 0, st, x, (char *) dst, nb); break;
+        default: return PKV_ERR_UNSUPPORTED;
+    }
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
 }
 
 }  // namespace pkv

@@ -129,7 +129,8 @@ int pkv_rope_f16_strided(const void * x, int64_t xs_tok, int64_t xs_head, const 
 
 int pkv_convert_f32(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, void * stream) {
     if (int rc = ensure_device()) return rc;
-    PKV_REQUIRE(x && dst && n_rows >= 0 && ne0 > 0 && kv_type_ok(type), "pkv_convert_f32: bad arguments");
+    PKV_REQUIRE(x && dst && n_rows >= 0 && ne0 > 0 && (kv_type_ok(type) || flat_only_type(type)), "pkv_convert_f32: bad arguments");
+    if (flat_only_type(type)) return launch_quantize_blocks(x, dst, type, n_rows, ne0, (hipStream_t) stream);
     return launch_convert_rows(x, dst, type, n_rows, ne0, (hipStream_t) stream);
 }
 int pkv_convert_f32_paged(const float * x, void * dst, int type, void * pool, int is_v, int64_t cell0, int64_t n_cells, int n_head_kv, int head_dim,

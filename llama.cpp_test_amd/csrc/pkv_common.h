@@ -41,11 +41,17 @@ __host__ __device__ inline size_t row_size(int type, int64_t ne) {
          : type == PKV_TYPE_F16  ? (size_t) ne * 2
          : type == PKV_TYPE_Q8_0 ? (size_t) (ne / PKV_QK) * 34
          : type == PKV_TYPE_Q4_0 ? (size_t) (ne / PKV_QK) * 18
+         : type == PKV_TYPE_Q4_1 ? (size_t) (ne / PKV_QK) * 20
+         : type == PKV_TYPE_Q5_0 ? (size_t) (ne / PKV_QK) * 22
+         : type == PKV_TYPE_Q5_1 ? (size_t) (ne / PKV_QK) * 24
+         : type == PKV_TYPE_IQ4_NL ? (size_t) (ne / PKV_QK) * 18
+         : type == PKV_TYPE_BF16 ? (size_t) ne * 2
          : type == PKV_TYPE_Q4_K ? (size_t) (ne / 256) * 144
          : type == PKV_TYPE_Q5_K ? (size_t) (ne / 256) * 176
          : type == PKV_TYPE_Q6_K ? (size_t) (ne / 256) * 210 : 0;
 }
 inline bool kv_type_ok(int t) { return t == PKV_TYPE_F16 || t == PKV_TYPE_Q8_0 || t == PKV_TYPE_Q4_0; }
+inline bool flat_only_type(int t) { return t == PKV_TYPE_Q4_1 || t == PKV_TYPE_Q5_0 || t == PKV_TYPE_Q5_1 || t == PKV_TYPE_IQ4_NL; }   // cache types without a pool layout
 
 // ---- canonical sum of squares of an RMS norm -------------------------------------------------------
 // rms_norm_mul_kernel (pkv_layer_ops.hip) and the norm prologue of the products (pkv_gemv.hip) must produce the same bits whatever their
@@ -149,6 +155,7 @@ int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * 
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_args * step = nullptr);
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * rope_cache = nullptr);   // rope_cache: RoPE(Q) fused in (NORM pairs)
 int launch_attn_flat(const pkv_flat_attn_args & a, hipStream_t st);   // pkv_attn_flat.hip
+int launch_quantize_blocks(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);   // q4_1 / q5_0 / q5_1 / iq4_nl (pkv_attn_flat.hip)
 int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);
 size_t prefill_workspace_bytes(int n_tok, int n_head, int D);

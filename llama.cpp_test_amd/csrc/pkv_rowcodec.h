@@ -246,6 +246,7 @@ template <int T> __device__ __forceinline__ Q2 quantize(float2 x, int lane) {
             const int   oi = __shfl_xor(ix, m);
             if (oa > am || (oa == am && oi < ix)) { am = oa; mv = ov; ix = oi; }
         }
+        if (am == 0.0f) mv = 0.0f;              // an all-zero block: the reference's max stays its initial +0 also when the elements are -0 (d = +0 / -8 = -0)
         const float d  = mv / -8.0f;
         const float id = d != 0.0f ? 1.0f / d : 0.0f;
         r.d  = h_bits(d);

@@ -17,8 +17,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-F32, F16, Q4_0, Q8_0, BF16 = 0, 1, 2, 8, 30
-TYPE_NAMES = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", BF16: "bf16"}
+F32, F16, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, IQ4_NL, BF16 = 0, 1, 2, 3, 6, 7, 8, 20, 30
+TYPE_NAMES = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0", IQ4_NL: "iq4_nl", BF16: "bf16"}
 KQ_MASK_PAD = 64  # GGML_KQ_MASK_PAD, ggml/include/ggml.h:1792
 
 _port = None

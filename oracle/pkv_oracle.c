@@ -11,6 +11,7 @@
 
 #include <immintrin.h>
 #include <math.h>
+#include <float.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,6 +27,10 @@ size_t pkv_o_row_size(int type, int64_t ne) {
         case PKV_O_BF16: return (size_t) ne * 2;
         case PKV_O_Q8_0: return (size_t) (ne / QK) * 34;  // block_q8_0 {half d; int8 qs[32]} ggml-common.h:203-208
         case PKV_O_Q4_0: return (size_t) (ne / QK) * 18;  // block_q4_0 {half d; uint8 qs[16]} ggml-common.h:161-166
+        case PKV_O_Q4_1: return (size_t) (ne / QK) * 20;  // block_q4_1 {half d, m; uint8 qs[16]} ggml-common.h:168-180
+        case PKV_O_Q5_0: return (size_t) (ne / QK) * 22;  // block_q5_0 {half d; uint8 qh[4]; uint8 qs[16]} :182-188
+        case PKV_O_Q5_1: return (size_t) (ne / QK) * 24;  // block_q5_1 {half d, m; uint8 qh[4]; uint8 qs[16]} :190-203
+        case PKV_O_IQ4_NL: return (size_t) (ne / QK) * 18; // block_iq4_nl {half d; uint8 qs[16]} :421-426
         default: return 0;
     }
 }
@@ -95,12 +100,149 @@ void pkv_o_quantize_q4_0(const float * x, void * vy, int64_t k) {
     }
 }
 
+// ---- the remaining CLI-whitelisted cache types (common/arg.cpp:172-182): q4_1, q5_0, q5_1, iq4_nl.  The CPU backend's from_float of each forwards to
+//      the *_ref quantizer (ggml-cpu-quants.c:727-734, :11760-11763).  Compiled -std=c11 like oracle/_ref: nothing below is contracted into an FMA.
+static const int8_t kvalues_iq4nl[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};   // ggml-quants.c:2434
+static inline void put_h(uint8_t * p, float f) { const uint16_t h = f2h(f); memcpy(p, &h, 2); }
+static inline float get_h(const uint8_t * p) { uint16_t h; memcpy(&h, p, 2); return h2f(h); }
+// quantize_row_q4_1_ref, ggml-quants.c:68-103
+static void quantize_q4_1(const float * x, uint8_t * y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; ++i, y += 20) {
+        float min = FLT_MAX, max = -FLT_MAX;
+        for (int j = 0; j < QK; ++j) { const float v = x[i * QK + j]; if (v < min) min = v; if (v > max) max = v; }
+        const float d = (max - min) / 15, id = d ? 1.0f / d : 0.0f;
+        put_h(y, d); put_h(y + 2, min);
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = (x[i * QK + j] - min) * id, x1 = (x[i * QK + 16 + j] - min) * id;
+            const int a0 = (int8_t) (x0 + 0.5f), a1 = (int8_t) (x1 + 0.5f);
+            y[4 + j] = (uint8_t) ((uint8_t) (a0 < 15 ? a0 : 15) | ((uint8_t) (a1 < 15 ? a1 : 15) << 4));
+        }
+    }
+}
+// quantize_row_q5_0_ref, :105-147
+static void quantize_q5_0(const float * x, uint8_t * y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; ++i, y += 22) {
+        float amax = 0.0f, max = 0.0f;
+        for (int j = 0; j < QK; ++j) { const float v = x[i * QK + j]; if (amax < fabsf(v)) { amax = fabsf(v); max = v; } }
+        const float d = max / -16, id = d ? 1.0f / d : 0.0f;
+        put_h(y, d);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = x[i * QK + j] * id, x1 = x[i * QK + 16 + j] * id;
+            const int a0 = (int8_t) (x0 + 16.5f), a1 = (int8_t) (x1 + 16.5f);
+            const uint8_t xi0 = (uint8_t) (a0 < 31 ? a0 : 31), xi1 = (uint8_t) (a1 < 31 ? a1 : 31);
+            y[6 + j] = (uint8_t) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0);
+            qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(y + 2, &qh, 4);
+    }
+}
+// quantize_row_q5_1_ref, :149-190
+static void quantize_q5_1(const float * x, uint8_t * y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; ++i, y += 24) {
+        float min = FLT_MAX, max = -FLT_MAX;
+        for (int j = 0; j < QK; ++j) { const float v = x[i * QK + j]; if (v < min) min = v; if (v > max) max = v; }
+        const float d = (max - min) / 31, id = d ? 1.0f / d : 0.0f;
+        put_h(y, d); put_h(y + 2, min);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = (x[i * QK + j] - min) * id, x1 = (x[i * QK + 16 + j] - min) * id;
+            const uint8_t xi0 = (uint8_t) (x0 + 0.5f), xi1 = (uint8_t) (x1 + 0.5f);
+            y[8 + j] = (uint8_t) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0);
+            qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(y + 4, &qh, 4);
+    }
+}
+// best_index_int8, ggml-quants.c:4562-4571
+static inline int best_index_int8(int n, const int8_t * val, float x) {
+    if (x <= val[0]) return 0;
+    if (x >= val[n - 1]) return n - 1;
+    int ml = 0, mu = n - 1;
+    while (mu - ml > 1) { const int mav = (ml + mu) / 2; if (x < val[mav]) mu = mav; else ml = mav; }
+    return x - val[mu - 1] < val[mu] - x ? mu - 1 : mu;
+}
+// quantize_row_iq4_nl_ref = quantize_row_iq4_nl_impl(32, 32, ..., ntry = -1), :4573-4660, :4707-4720: one block of 32, weights x^2, the scale of the first pass
+// re-fitted as sum(w q x) / sum(w q q), no search, the indices of the FIRST pass kept.  (A block whose amax < 1e-15 keeps d = 0 and — in the reference — whatever
+// its index scratch held before: such blocks are not compared byte for byte.)
+static void quantize_iq4_nl(const float * x, uint8_t * y, int64_t k) {
+    uint8_t L[QK];
+    memset(L, 0, sizeof(L));
+    for (int64_t i = 0; i < k / QK; ++i, y += 18) {
+        const float * xb = x + i * QK;
+        memset(y + 2, 0, 16);
+        put_h(y, 0.0f);
+        float amax = 0, max = 0;
+        for (int j = 0; j < QK; ++j) { const float ax = fabsf(xb[j]); if (ax > amax) { amax = ax; max = xb[j]; } }
+        if (amax >= 1e-15f) {
+            float d = max / kvalues_iq4nl[0];
+            const float id = 1 / d;
+            float sumqx = 0, sumq2 = 0;
+            for (int j = 0; j < QK; ++j) {
+                const float al = id * xb[j];
+                const int l = best_index_int8(16, kvalues_iq4nl, al);
+                L[j] = (uint8_t) l;
+                const float q = kvalues_iq4nl[l], w = xb[j] * xb[j];
+                sumqx += w * q * xb[j];
+                sumq2 += w * q * q;
+            }
+            d = sumqx / sumq2;
+            put_h(y, d);
+        }
+        for (int j = 0; j < 16; ++j) y[2 + j] = (uint8_t) (L[j] | (L[16 + j] << 4));
+    }
+}
+// dequantize_row_q4_1 / _q5_0 / _q5_1 / _iq4_nl, ggml-quants.c:275-346, :2436-2452
+static void dequantize_new(int type, const uint8_t * x, float * y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; ++i, y += QK) {
+        if (type == PKV_O_Q4_1) {
+            const uint8_t * b = x + i * 20;
+            const float d = get_h(b), m = get_h(b + 2);
+            for (int j = 0; j < 16; ++j) { y[j] = (b[4 + j] & 0x0F) * d + m; y[j + 16] = (b[4 + j] >> 4) * d + m; }
+        } else if (type == PKV_O_Q5_0) {
+            const uint8_t * b = x + i * 22;
+            const float d = get_h(b);
+            uint32_t qh; memcpy(&qh, b + 2, 4);
+            for (int j = 0; j < 16; ++j) {
+                const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10, xh_1 = ((qh >> (j + 12))) & 0x10;
+                y[j] = (((b[6 + j] & 0x0F) | xh_0) - 16) * d; y[j + 16] = (((b[6 + j] >> 4) | xh_1) - 16) * d;
+            }
+        } else if (type == PKV_O_Q5_1) {
+            const uint8_t * b = x + i * 24;
+            const float d = get_h(b), m = get_h(b + 2);
+            uint32_t qh; memcpy(&qh, b + 4, 4);
+            for (int j = 0; j < 16; ++j) {
+                const uint8_t xh_0 = ((qh >> (j + 0)) << 4) & 0x10, xh_1 = ((qh >> (j + 12))) & 0x10;
+                y[j] = ((b[8 + j] & 0x0F) | xh_0) * d + m; y[j + 16] = ((b[8 + j] >> 4) | xh_1) * d + m;
+            }
+        } else {
+            const uint8_t * b = x + i * 18;
+            const float d = get_h(b);
+            for (int j = 0; j < 16; ++j) { y[j] = d * kvalues_iq4nl[b[2 + j] & 0xf]; y[j + 16] = d * kvalues_iq4nl[b[2 + j] >> 4]; }
+        }
+    }
+}
+// quantize_row_q8_1, AVX2 branch (ggml-cpu-quants.c:1138-1180): the q8_0 integers plus s = f16(d * sum of the quants); block {half d; half s; int8 qs[32]} 36 B
+static void quantize_q8_1_cpu(const float * x, uint8_t * y, int64_t k) {
+    for (int64_t i = 0; i < k / QK; ++i, y += 36) {
+        float amax = 0.0f;
+        for (int j = 0; j < QK; ++j) amax = fmaxf(amax, fabsf(x[i * QK + j]));
+        const float d = amax / 127.f, id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        int sum = 0;
+        for (int j = 0; j < QK; ++j) { const int q = (int) nearbyintf(x[i * QK + j] * id); ((int8_t *) (y + 4))[j] = (int8_t) q; sum += q; }
+        put_h(y, d); put_h(y + 2, d * sum);
+    }
+}
+
 // ggml/src/ggml-quants.c:349-362 (q8_0), :255-273 (q4_0)
 void pkv_o_to_float(int type, const void * vx, float * y, int64_t k) {
     const uint8_t * x = (const uint8_t *) vx;
     if (type == PKV_O_F32) { memcpy(y, vx, (size_t) k * 4); return; }
     if (type == PKV_O_F16) { pkv_o_f16_to_f32((const uint16_t *) vx, y, k); return; }
     if (type == PKV_O_BF16) { pkv_o_bf16_to_f32((const uint16_t *) vx, y, k); return; }
+    if (type == PKV_O_Q4_1 || type == PKV_O_Q5_0 || type == PKV_O_Q5_1 || type == PKV_O_IQ4_NL) { dequantize_new(type, x, y, k); return; }
     for (int64_t i = 0; i < k / QK; ++i) {
         uint16_t dh;
         if (type == PKV_O_Q8_0) {
@@ -127,6 +269,10 @@ void pkv_o_from_float(int type, const float * x, void * y, int64_t k) {
         case PKV_O_BF16: pkv_o_f32_to_bf16(x, (uint16_t *) y, k); break;
         case PKV_O_Q8_0: pkv_o_quantize_q8_0_cpu(x, y, k); break;
         case PKV_O_Q4_0: pkv_o_quantize_q4_0(x, y, k); break;
+        case PKV_O_Q4_1: quantize_q4_1(x, (uint8_t *) y, k); break;
+        case PKV_O_Q5_0: quantize_q5_0(x, (uint8_t *) y, k); break;
+        case PKV_O_Q5_1: quantize_q5_1(x, (uint8_t *) y, k); break;
+        case PKV_O_IQ4_NL: quantize_iq4_nl(x, (uint8_t *) y, k); break;
     }
 }
 
@@ -291,16 +437,60 @@ static float vec_dot_q4_0_q8_0(int n, const uint8_t * x, const uint8_t * y) {
     return hsum8(acc);
 }
 
+// the element e (0..31) of a block as the AVX2 dots see it: low nibbles -> 0..15, high -> 16..31; q5: the fifth bit from qh
+static inline int blk_q(int type, const uint8_t * b, int e) {
+    if (type == PKV_O_Q4_1) return e < 16 ? b[4 + e] & 0xF : b[4 + e - 16] >> 4;
+    if (type == PKV_O_IQ4_NL) return kvalues_iq4nl[e < 16 ? b[2 + e] & 0xF : b[2 + e - 16] >> 4];
+    const int o = type == PKV_O_Q5_0 ? 2 : 4;
+    uint32_t qh; memcpy(&qh, b + o, 4);
+    const int nib = e < 16 ? b[o + 4 + e] & 0xF : b[o + 4 + e - 16] >> 4;
+    const int q = nib | (int) (((qh >> e) & 1u) << 4);
+    return type == PKV_O_Q5_0 ? q - 16 : q;
+}
+// ggml_vec_dot_q4_1_q8_1 (ggml-cpu-quants.c:2751-2786), _q5_0_q8_0 (:3080-3103), _q5_1_q8_1 (:3445-3471), _iq4_nl_q8_0 (:11999-12027), AVX2 branches: per
+// block 8 lanes of 4 integer products, acc[l] = fma(d_x * d_y, lane sum, acc[l]); the *_1 types add m_x * s_y block by block into a scalar; iq4_nl keeps
+// two accumulators (even / odd blocks) and adds them before the horizontal sum
+static float vec_dot_new(int type, int n, const uint8_t * x, const uint8_t * y) {
+    const int xs = type == PKV_O_Q4_1 ? 20 : type == PKV_O_Q5_0 ? 22 : type == PKV_O_Q5_1 ? 24 : 18;
+    const int q81 = type == PKV_O_Q4_1 || type == PKV_O_Q5_1, ys = q81 ? 36 : 34, yq = q81 ? 4 : 2;
+    float acc[2][8];
+    memset(acc, 0, sizeof(acc));
+    float summs = 0.0f;
+    const int nbv = type == PKV_O_IQ4_NL ? (n / QK) & ~1 : n / QK;      // iq4_nl: blocks in pairs, an odd last one in the scalar tail (:12153-12161)
+    for (int ib = 0; ib < nbv; ++ib) {
+        const uint8_t * bx = x + ib * xs, * by = y + ib * ys;
+        const float d = get_h(bx) * get_h(by);
+        if (q81) summs += get_h(bx + 2) * get_h(by + 2);
+        float * a = acc[type == PKV_O_IQ4_NL ? (ib & 1) : 0];
+        for (int l = 0; l < 8; ++l) {
+            int sm = 0;
+            for (int j = 0; j < 4; ++j) sm += blk_q(type, bx, l * 4 + j) * (int) ((const int8_t *) (by + yq))[l * 4 + j];
+            a[l] = fmaf(d, (float) sm, a[l]);
+        }
+    }
+    for (int l = 0; l < 8; ++l) acc[0][l] += acc[1][l];
+    float sumf = q81 ? hsum8(acc[0]) + summs : hsum8(acc[0]);
+    for (int ib = nbv; ib < n / QK; ++ib) {
+        const uint8_t * bx = x + ib * xs, * by = y + ib * ys;
+        const float d = get_h(by) * get_h(bx);
+        int sumi = 0;
+        for (int e = 0; e < QK; ++e) sumi += blk_q(type, bx, e) * (int) ((const int8_t *) (by + yq))[e];
+        sumf += d * sumi;
+    }
+    return sumf;
+}
+
 // ---------------------------------------------------------------------------------------------------
+static int kv_blocked(int t) { return t == PKV_O_Q8_0 || t == PKV_O_Q4_0 || t == PKV_O_Q4_1 || t == PKV_O_Q5_0 || t == PKV_O_Q5_1 || t == PKV_O_IQ4_NL; }
+static int kv_ok(int t) { return t == PKV_O_F16 || t == PKV_O_BF16 || kv_blocked(t); }
 // ggml_compute_forward_flash_attn_ext_f16, ggml-cpu.c:12219-12432
 int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const uint16_t * mask,
                          float * out, float * logits,
                          int D, int n_q, int n_head, int n_kv, int n_head_kv, int mask_stride,
                          int type_k, int type_v, float scale, float max_bias, float logit_softcap,
                          int n_threads) {
-    if (type_k != PKV_O_F16 && type_k != PKV_O_BF16 && type_k != PKV_O_Q8_0 && type_k != PKV_O_Q4_0) return -1;
-    if (type_v != PKV_O_F16 && type_v != PKV_O_BF16 && type_v != PKV_O_Q8_0 && type_v != PKV_O_Q4_0) return -1;
-    if (D > 512 || ((type_k == PKV_O_Q8_0 || type_k == PKV_O_Q4_0 || type_v == PKV_O_Q8_0 || type_v == PKV_O_Q4_0) && D % QK != 0)) return -1;
+    if (!kv_ok(type_k) || !kv_ok(type_v)) return -1;
+    if (D > 512 || ((kv_blocked(type_k) || kv_blocked(type_v)) && D % QK != 0)) return -1;
     if (logit_softcap != 0) scale /= logit_softcap;                                   // :12290-12292
     const uint32_t n_head_log2 = 1u << (uint32_t) floor(log2(n_head));               // :12295
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2);
@@ -308,7 +498,8 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
     const size_t rk = pkv_o_row_size(type_k, D), rv = pkv_o_row_size(type_v, D);
     const int gq = n_head / n_head_kv;                                               // rk2 :12264
     // k's vec_dot_type: f16 for f16, bf16 for bf16, q8_0 for q8_0/q4_0 (type_traits_cpu, ggml-cpu.c:240-300,403-405)
-    const int q_type = type_k == PKV_O_F16 ? PKV_O_F16 : type_k == PKV_O_BF16 ? PKV_O_BF16 : PKV_O_Q8_0;
+    // (q4_1 / q5_1: q8_1; q5_0 / iq4_nl: q8_0)
+    const int q_type = type_k == PKV_O_F16 ? PKV_O_F16 : type_k == PKV_O_BF16 ? PKV_O_BF16 : (type_k == PKV_O_Q4_1 || type_k == PKV_O_Q5_1) ? PKV_O_Q8_1 : PKV_O_Q8_0;
     const int nr = n_head * n_q;
     const int D32 = D & ~31;                                                         // GGML_F32_STEP == GGML_F16_STEP == 32 (AVX2)
     if (n_threads < 1) n_threads = 1;
@@ -329,6 +520,7 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
         const float * pq = q + ((size_t) h * n_q + iq) * D;
         if (q_type == PKV_O_F16) pkv_o_f32_to_f16(pq, (uint16_t *) Qq, D);
         else if (q_type == PKV_O_BF16) pkv_o_f32_to_bf16(pq, (uint16_t *) Qq, D);
+        else if (q_type == PKV_O_Q8_1) quantize_q8_1_cpu(pq, Qq, D);
         else                     pkv_o_quantize_q8_0_cpu(pq, Qq, D);                 // :12343
         float * lg = logits ? logits + ((size_t) h * n_q + iq) * n_kv : NULL;
 
@@ -340,7 +532,8 @@ int pkv_o_flash_attn_ext(const float * q, const void * k, const void * v, const 
             if (type_k == PKV_O_F16)       s = vec_dot_f16(D, (const uint16_t *) kd, (const uint16_t *) Qq);
             else if (type_k == PKV_O_BF16) s = vec_dot_bf16(D, (const uint16_t *) kd, (const uint16_t *) Qq);
             else if (type_k == PKV_O_Q8_0) s = vec_dot_q8_0_q8_0(D, kd, Qq);
-            else                           s = vec_dot_q4_0_q8_0(D, kd, Qq);
+            else if (type_k == PKV_O_Q4_0) s = vec_dot_q4_0_q8_0(D, kd, Qq);
+            else                           s = vec_dot_new(type_k, D, kd, Qq);
             s = s * scale;
             if (logit_softcap != 0.0f) s = logit_softcap * tanhf(s);
             s += mv;

@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 // numeric values follow enum ggml_type (ggml/include/ggml.h:350-360)
-enum { PKV_O_F32 = 0, PKV_O_F16 = 1, PKV_O_Q4_0 = 2, PKV_O_Q8_0 = 8, PKV_O_BF16 = 30 };
+enum { PKV_O_F32 = 0, PKV_O_F16 = 1, PKV_O_Q4_0 = 2, PKV_O_Q4_1 = 3, PKV_O_Q5_0 = 6, PKV_O_Q5_1 = 7, PKV_O_Q8_0 = 8, PKV_O_Q8_1 = 9, PKV_O_IQ4_NL = 20, PKV_O_BF16 = 30 };
 
 // ggml_row_size (ggml/src/ggml.c) for the four KV-relevant types
 size_t pkv_o_row_size(int type, int64_t ne);

@@ -11,7 +11,7 @@ import torch
 from gpu_util import dev, nmse
 
 pytestmark = pytest.mark.gpu
-T = {"f16": 1, "bf16": 30, "q8_0": 8, "q4_0": 2}
+T = {"f16": 1, "bf16": 30, "q8_0": 8, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "iq4_nl": 20}
 
 
 def _case(O, rng, D, nh, nkv, n_kv, n_q, tk, tv, masked=True):
@@ -103,3 +103,43 @@ def test_row_without_visible_cell_and_bad_arguments(pkv, O):
         pkv.flash_attn_ext_flat(dev(q), dev(k), dev(v), None, type_k=30, type_v=30, scale=1.0, max_bias=8.0)     # ALiBi without a mask
     with pytest.raises(pkv.PkvError):
         pkv.flash_attn_ext_flat(dev(q), dev(k), dev(v), None, type_k=12, type_v=30, scale=1.0)                    # q4_K is no KV type
+
+
+@pytest.mark.parametrize("tk,tv", [("q4_1", "q4_1"), ("q5_0", "q5_0"), ("q5_1", "q5_1"), ("iq4_nl", "iq4_nl"), ("q5_1", "iq4_nl"), ("q4_1", "f16"), ("bf16", "q5_0")])
+@pytest.mark.parametrize("D,nh,nkv,n_kv,n_q", [(128, 8, 2, 515, 3), (64, 4, 4, 300, 1), (256, 4, 2, 257, 2), (96, 6, 2, 130, 33)])
+def test_remaining_cache_types(pkv, O, tk, tv, D, nh, nkv, n_kv, n_q):
+    """q4_1 / q5_0 / q5_1 / iq4_nl (the rest of /root/reference/common/arg.cpp:172-182): K rows meet Q as q8_1 (q4_1, q5_1: + m_K * s_Q per block) or q8_0, V rows are
+    dequantized as dequantize_row_* does; the oracle is bit-exact against the compiled reference for these types (tests/test_oracle_vs_ref.py)"""
+    tk, tv = T[tk], T[tv]
+    rng = np.random.default_rng(D + n_kv + 11 * tk + tv)
+    q, k, v, mask = _case(O, rng, D, nh, nkv, n_kv, n_q, tk, tv)
+    for kw in (dict(), dict(softcap=10.0), dict(max_bias=8.0)):
+        got = pkv.flash_attn_ext_flat(dev(q), dev(k), dev(v), dev(mask), type_k=tk, type_v=tv, scale=D ** -0.5, **kw)
+        torch.cuda.synchronize()
+        _check(O, got.cpu().numpy(), q, k, v, mask, tk, tv, D, **kw)
+
+
+@pytest.mark.parametrize("t", ["q4_1", "q5_0", "q5_1", "iq4_nl"])
+def test_kv_store_of_the_remaining_cache_types_is_bit_exact(pkv, O, t):
+    """pkv_convert_f32 = GGML_OP_CPY f32 -> type, the KV store of such a cache: the same bytes as the reference's quantizers (the oracle's are bit-exact against
+    oracle/_ref): values at three scales, exact ties, constant blocks; (all-zero iq4_nl blocks are left out: the reference leaves their indices undefined)"""
+    t = T[t]
+    rng = np.random.default_rng(40 + t)
+    x = (rng.standard_normal((513, 128)) * rng.choice([1e-3, 1.0, 50.0], (513, 1))).astype(np.float32)
+    x[::17] = np.round(x[::17] * 4) / 4
+    x[5] = 0.75
+    x[6, :32] = -2.0
+    x[7, 32:64] = np.arange(32, dtype=np.float32) - 16
+    x[8] = 0.0                                                       # all-zero blocks: q5_0 stores d = 0 / -16 = -0
+    x[9] = -0.0
+    want = O.from_float(t, x)
+    dst = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+    pkv.convert_f32(dev(x), dst, t)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy().reshape(want.shape)
+    if t == 20:                                                      # iq4_nl: all-zero blocks are not compared (see above); their scale must still be 0
+        nz = np.abs(x.reshape(-1, 32)).max(axis=1) > 0
+        w, g = want.reshape(-1, 18), got.reshape(-1, 18)
+        assert np.array_equal(g[nz], w[nz]) and not g[~nz][:, :2].any() and (~nz).sum() >= 8
+    else:
+        assert np.array_equal(got, want)

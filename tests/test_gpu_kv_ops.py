@@ -52,6 +52,8 @@ def test_kv_store_bit_exact(pkv, O, golden, tk, tv, D):
     if D == 128:
         k[:48, 0, :] = golden["cpy"]["x"]                    # the reference's corner cases (zeros, ties, scales)
         v[:48, 1, :] = golden["cpy"]["x"]
+    k[60, 1, :] = -0.0                                       # blocks of negative zeros: q4_0's scale is max / -8 with max = +0 (the initial value), i.e. -0
+    v[61, 2, :32] = -0.0
     # ragged slot mapping: interleaved blocks, one skipped token (slot_block < 0)
     cells = rng.permutation(nb * bs)[:n_tok]
     sb, so = (cells // bs).astype(np.int32), (cells % bs).astype(np.int32)

@@ -17,7 +17,7 @@ PLUGIN = os.path.join(ROOT, "llama.cpp_test_amd", "libggml-mi355.so")
 
 @pytest.mark.skipif(not (os.path.exists(TBO) and os.path.exists(PLUGIN)), reason="oracle/_ref/test-backend-ops or the plugin not built")
 @pytest.mark.parametrize("op,min_ok", [("FLASH_ATTN_EXT", 960),     # ALL of them (r03: what the paged kernels decline goes to pkv_flash_attn_ext_flat)
-                                       ("ROPE", 150), ("ROPE_BACK", 150), ("CPY", 24),
+                                       ("ROPE", 150), ("ROPE_BACK", 150), ("CPY", 28),
                                        # first slice of the rest of the layer: harness bars 1e-7 / 5e-4 (MUL_MAT)
                                        ("RMS_NORM", 3), ("ADD", 10), ("MUL", 10), ("SILU", 2), ("MUL_MAT", 30),
                                        # the softmax of the non-flash-attention path (a13): mask f32 / f16, scale, ALiBi; harness bar 1e-6

@@ -107,11 +107,12 @@ def test_llama_decode_with_attention_on_the_plugin(pkv, tmp_path, tk, model):
 
 
 @pytest.mark.skipif(not (R.available() and os.path.exists(PLUGIN)), reason="needs oracle/_ref/libref_kv.so and libggml-mi355.so")
-@pytest.mark.parametrize("model,tk", [("tiny", 30), ("llama3", 30), ("hs256", 1), ("hs256", 8), ("hs256", 30)])
+@pytest.mark.parametrize("model,tk", [("tiny", 30), ("llama3", 30), ("hs256", 1), ("hs256", 8), ("hs256", 30), ("tiny", 3), ("tiny", 6), ("tiny", 7), ("tiny", 20), ("hs256", 6)])   # (f16 weights: both runs quantize the same K / V values)
 def test_llama_decode_outside_the_paged_geometries(pkv, tmp_path, model, tk):
     """r03: what the paged kernels do not take runs through pkv_flash_attn_ext_flat inside the unmodified reference runtime — a bf16 KV cache (`-ctk bf16
     -ctv bf16`, /root/reference/common/arg.cpp:172-182: the KV store is the plugin's f32 -> bf16 strided CPY, the cache tensors stay flat bf16 rows) and head
-    size 256 (f16 / q8_0 / bf16 cache).  Expected values: the CPU-only run of the same library, per-layer kqv_out NMSE <= 5e-4, logits as in the test above."""
+    size 256 (f16 / q8_0 / bf16 cache); and the remaining cache types of that list — q4_1 (3), q5_0 (6), q5_1 (7), iq4_nl (20): the KV store is pkv_convert_f32's
+    block quantizers, bit-exact with the CPU backend's.  Expected values: the CPU-only run of the same library, per-layer kqv_out NMSE <= 5e-4, logits as in the test above."""
     from llama_cpp_test_amd import gguf_synth as G
     MODEL = MODELS[model]
     path = str(tmp_path / "m.gguf")

@@ -25,6 +25,24 @@ def test_flash_attn_bit_exact(tk, tv, D, nh, nkv, n_kv, n_q):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("tk,tv", [(O.Q4_1, O.Q4_1), (O.Q5_0, O.Q5_0), (O.Q5_1, O.Q5_1), (O.IQ4_NL, O.IQ4_NL), (O.Q5_1, O.IQ4_NL), (O.Q4_1, O.F16), (O.F16, O.Q5_0)])
+@pytest.mark.parametrize("D,nh,nkv,n_kv,n_q", [(128, 8, 2, 300, 2), (64, 4, 4, 257, 3), (256, 4, 2, 130, 1), (96, 4, 2, 70, 2)])
+def test_flash_attn_remaining_cache_types_bit_exact(tk, tv, D, nh, nkv, n_kv, n_q):
+    """the other CLI-whitelisted cache types (common/arg.cpp:172-182): q4_1 / q5_1 meet Q as q8_1, q5_0 / iq4_nl as q8_0 (type_traits_cpu); head size 96 = three
+    blocks: iq4_nl's two-blocks-at-a-time loop leaves one to its scalar tail"""
+    rng = np.random.default_rng(n_kv * 13 + tk * 5 + tv)
+    q = rng.uniform(-1, 1, (nh, n_q, D)).astype(np.float32)
+    k = O.from_float(tk, rng.uniform(-1, 1, (nkv, n_kv, D)).astype(np.float32))
+    v = O.from_float(tv, rng.uniform(-1, 1, (nkv, n_kv, D)).astype(np.float32))
+    mask = np.zeros((n_q, n_kv), np.float16)
+    for j in range(n_q):
+        mask[j, n_kv - n_q + j + 1:] = -np.inf
+    for kw in (dict(), dict(softcap=8.0), dict(max_bias=8.0)):
+        a = O.flash_attn_ext(q, k, v, mask, type_k=tk, type_v=tv, scale=D ** -0.5, n_threads=3, **kw)
+        b = O.ref_flash_attn_ext(q, k, v, mask, type_k=tk, type_v=tv, scale=D ** -0.5, n_threads=2, **kw)
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("tk", [O.F16, O.BF16])
 def test_flash_attn_head_size_80_bit_exact(tk):
     """head size 80 (tests/test-backend-ops.cpp:4367): not a multiple of the 32-element steps of the vector dots, the leftovers run in double"""
@@ -45,11 +63,15 @@ def test_codecs_bit_exact():
     rng = np.random.default_rng(7)
     x = (rng.standard_normal((257, 128)) * rng.choice([1e-3, 1.0, 50.0], (257, 1))).astype(np.float32)
     x[::17] = np.round(x[::17] * 4) / 4
+    x[9] = -0.0                                      # blocks of negative zeros (q4_0 / q5_0: d = +0 / -8 = -0, the quants of -0 * 0)
     x[3, :4] = [np.nan, np.inf, -np.inf, 0.0]
-    for t in (O.F16, O.Q8_0, O.Q4_0, O.BF16):
-        if t in (O.Q8_0, O.Q4_0):
+    for t in (O.F16, O.BF16, O.Q8_0, O.Q4_0, O.Q4_1, O.Q5_0, O.Q5_1, O.IQ4_NL):
+        if t not in (O.F16, O.BF16):
             x[3, :4] = 0.0
-        assert np.array_equal(O.from_float(t, x), O.ref_cpy(t, x, n_threads=2))
+        got, want = O.from_float(t, x), O.ref_cpy(t, x, n_threads=2)
+        if t == O.IQ4_NL:                                # (all-zero iq4_nl blocks: the reference's indices are whatever its scratch held)
+            got[9], want[9] = 0, 0
+        assert np.array_equal(got, want)
         b = O.from_float(t, x)
         assert np.array_equal(O.to_float(t, b, 128).view(np.uint32), O.ref_to_float(t, b, 128).view(np.uint32))     # (bits: the row holds a NaN)
     assert np.array_equal(O.from_float(O.Q8_0, x, "ref"), O.ref_from_float_ref(O.Q8_0, x))
