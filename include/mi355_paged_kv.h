@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PKV_ABI_VERSION 2   /* 2 (r03): PKV_ATTN_Q_F16 / PKV_ATTN_OUT_F16, pkv_attn_decode_tiles */
+#define PKV_ABI_VERSION 3   /* 2 (r03): PKV_ATTN_Q_F16 / PKV_ATTN_OUT_F16, pkv_attn_decode_tiles; 3 (r03): pkv_flash_attn_ext_flat, pkv_attn_step_layers, PKV_TYPE_BF16 / _Q4_1 / _Q5_0 / _Q5_1 / _IQ4_NL */
 
 /* values follow enum ggml_type (/ref/ggml/include/ggml.h:351-360) */
 enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8,

@@ -36,7 +36,7 @@ PACKED = 0x100          # PKV_TYPE_PACKED: K-quant rows in the plane layout (csr
 ATTN_NO_COMBINE = 1
 ATTN_FUSED_COMBINE = 2
 ATTN_NONCAUSAL = 4
-ABI_VERSION = 2      # == PKV_ABI_VERSION of include/mi355_paged_kv.h
+ABI_VERSION = 3      # == PKV_ABI_VERSION of include/mi355_paged_kv.h
 ATTN_Q_F16 = 8      # attn_prefill / attn_prefill_step: q is f16 (set from q.dtype)
 ATTN_OUT_F16 = 16   # ... out is f16 (out_dtype=torch.float16 or an f16 `out`)
 

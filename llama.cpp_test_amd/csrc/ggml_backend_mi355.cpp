@@ -419,6 +419,8 @@ ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
     memcpy(&softcap, (const float *) op->op_params + 2, sizeof(float));
     const int D = (int) q->ne[0], n_q = (int) q->ne[1], n_head = (int) q->ne[2], n_kv = (int) k->ne[1], n_head_kv = (int) k->ne[2];
     if (!fa_paged_ok(op)) {   // outside the paged kernels' geometries: the flat kernel reads the tensors where they lie
+        // (a cache tensor that an earlier paged call re-laid as tiles has no flat rows any more: one context never mixes the two kinds of node, stop if one does)
+        if (in_place_of(k) || in_place_of(v)) GGML_ABORT("mi355: flash_attn_ext outside the paged geometries over a cache tensor that is laid out as a block pool (%s)", k->name);
         pkv_flat_attn_args f = {};
         f.q = (const float *) q->data; f.q_stride_tok = (int64_t) (q->nb[1] / sizeof(float)); f.q_stride_head = (int64_t) (q->nb[2] / sizeof(float));
         f.k = k->data; f.k_stride_tok = (int64_t) k->nb[1]; f.k_stride_head = (int64_t) k->nb[2];

@@ -18,7 +18,7 @@ def test_every_declared_symbol_is_exported(pkv):
     L = pkv.lib()
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.pkv_abi_version() == 2
+    assert L.pkv_abi_version() == 3
 
 
 def test_layout_helpers_match_reference_row_sizes(pkv, O):
