@@ -292,7 +292,10 @@ typedef struct pkv_flat_attn_args {
     float *       out;
     int32_t n_q, n_kv, n_head, n_head_kv, head_dim, type_k, type_v;
     float   scale, max_bias, logit_softcap;           /* op_params[0..2] */
+    void *  workspace;                                /* optional device scratch (pkv_flash_attn_ext_flat_workspace_bytes): a launch of few query rows over a */
+    size_t  workspace_bytes;                          /* long K / V (a decode step) is then cut along the cells (split-KV + a merge launch); NULL = unsplit    */
 } pkv_flat_attn_args;
+size_t pkv_flash_attn_ext_flat_workspace_bytes(int n_q, int n_head, int head_dim, int n_kv);   /* 0: a launch of this shape never splits */
 int pkv_flash_attn_ext_flat(const pkv_flat_attn_args * args, void * stream);
 
 /* In-place K-shift: replaces build_kv_self_shift / build_rope_shift (/ref/src/llama-context.cpp:447-571).

@@ -89,7 +89,8 @@ class FlatAttnArgs(C.Structure):   # pkv_flat_attn_args
                 ("v", C.c_void_p), ("v_stride_tok", C.c_int64), ("v_stride_head", C.c_int64),
                 ("mask", C.c_void_p), ("mask_stride", C.c_int64), ("out", C.c_void_p),
                 ("n_q", C.c_int32), ("n_kv", C.c_int32), ("n_head", C.c_int32), ("n_head_kv", C.c_int32), ("head_dim", C.c_int32),
-                ("type_k", C.c_int32), ("type_v", C.c_int32), ("scale", C.c_float), ("max_bias", C.c_float), ("logit_softcap", C.c_float)]
+                ("type_k", C.c_int32), ("type_v", C.c_int32), ("scale", C.c_float), ("max_bias", C.c_float), ("logit_softcap", C.c_float),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class Gemv(C.Structure):
@@ -123,6 +124,7 @@ def lib() -> C.CDLL:
         L.pkv_row_size.argtypes = [C.c_int, C.c_int64]
         L.pkv_cache_create.restype = C.c_void_p
         L.pkv_attn_prefill_workspace_bytes.restype = C.c_size_t
+        L.pkv_flash_attn_ext_flat_workspace_bytes.restype = C.c_size_t
         if hasattr(L, "pkv_act_image_bytes"):   # (absent only from the round-1 build that probes/ab_decode.py loads for A/B runs)
             L.pkv_act_image_bytes.restype = C.c_size_t
             L.pkv_act_image_bytes.argtypes = [C.c_int64]
@@ -377,7 +379,8 @@ def attn_prefill(q, k_pool, v_pool, block_table, seq_lens, q_start, **kw):
     return _attn(lib().pkv_attn_prefill, q, k_pool, v_pool, block_table, seq_lens, q_start=q_start, **kw)
 
 
-def flash_attn_ext_flat(q, k, v, mask=None, *, type_k: int, type_v: int, scale: float, max_bias: float = 0.0, softcap: float = 0.0, out=None, stream=None):
+def flash_attn_ext_flat(q, k, v, mask=None, *, type_k: int, type_v: int, scale: float, max_bias: float = 0.0, softcap: float = 0.0, out=None, stream=None, split: bool = True,
+                        workspace=None):
     """ggml_flash_attn_ext on the reference's own tensor layout (pkv_flash_attn_ext_flat): what the paged kernels do not take — head sizes up to 256, bf16
     rows, any gqa ratio, strided views.  q f32 [n_head][n_q][D] (any strides with a unit last one); k / v uint8 [n_head_kv][n_kv][row bytes] in the
     reference's bytes (views allowed: strides are taken from the tensors); mask f16 [>= n_q][n_kv] or None.  Returns out f32 [n_q][n_head][D]."""
@@ -393,6 +396,11 @@ def flash_attn_ext_flat(q, k, v, mask=None, *, type_k: int, type_v: int, scale: 
                      v=_ptr(v), v_stride_tok=v.stride(1), v_stride_head=v.stride(0), mask=_ptr(mask), mask_stride=mask.stride(0) if mask is not None else 0,
                      out=_ptr(out), n_q=n_q, n_kv=n_kv, n_head=n_head, n_head_kv=n_head_kv, head_dim=D, type_k=type_k, type_v=type_v, scale=scale,
                      max_bias=max_bias, logit_softcap=softcap)
+    if split:                                        # split-KV for launches of few query rows over a long K / V (the library decides; needs the scratch)
+        need = lib().pkv_flash_attn_ext_flat_workspace_bytes(n_q, n_head, D, n_kv)
+        if need:
+            ws = workspace if workspace is not None and workspace.numel() * workspace.element_size() >= need else torch.empty(need, dtype=torch.uint8, device=q.device)
+            a.workspace, a.workspace_bytes = _ptr(ws), need
     check(lib().pkv_flash_attn_ext_flat(C.byref(a), C.c_void_p(_stream(stream))))
     return out
 

@@ -429,6 +429,9 @@ ggml_status run_flash_attn(backend_ctx * bc, ggml_tensor * op) {
         f.out = (float *) op->data;
         f.n_q = n_q; f.n_kv = n_kv; f.n_head = n_head; f.n_head_kv = n_head_kv; f.head_dim = D; f.type_k = k->type; f.type_v = v->type;
         f.scale = scale; f.max_bias = max_bias; f.logit_softcap = softcap;
+        f.workspace_bytes = pkv_flash_attn_ext_flat_workspace_bytes(n_q, n_head, D, n_kv);
+        f.workspace = f.workspace_bytes ? bc->arena(f.workspace_bytes) : nullptr;   // (no arena: the launch runs unsplit)
+        if (!f.workspace) f.workspace_bytes = 0;
         if (pkv_flash_attn_ext_flat(&f, bc->stream)) { MI355_LOG("flash_attn_ext (flat) failed: %s\n", pkv_last_error()); return GGML_STATUS_FAILED; }
         return GGML_STATUS_SUCCESS;
     }

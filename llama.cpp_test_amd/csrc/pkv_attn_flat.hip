@@ -18,11 +18,12 @@
 // row); one cross-wave merge through LDS.  A coverage kernel, not a roofline one: the hot geometries never come here (pkv_flash_attn_ext_flat's callers
 // ask the paged kernels first).
 #include "pkv_common.h"
+#include <algorithm>
 
 namespace pkv {
 namespace {
 
-constexpr int FLAT_NW = 4, FLAT_NW_LONG = 16, FLAT_DMAX = 256;   // waves per workgroup: 4, or 16 once a row has >= 16 chunks of 64 cells to walk
+constexpr int FLAT_NW = 4, FLAT_NW_LONG = 16, FLAT_DMAX = 256, FLAT_MAX_SPLIT = 32;   // waves per workgroup: 4, or 16 once a row has >= 16 chunks of 64 cells to walk
 
 struct FlatArgs {
     const float * q; int64_t q_s_tok, q_s_head;
@@ -33,6 +34,8 @@ struct FlatArgs {
     float scale, softcap, max_bias, m0, m1;
     unsigned n_head_log2;
     int k_al16, v_al16;
+    int n_split, split_len;            // split-KV: workgroup z walks the cells [z * split_len, (z + 1) * split_len) and leaves an (m, l, O) partial
+    float * part;                      // [n_q][n_head][n_split][D + 2]
 };
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned) h << 16); }
@@ -68,6 +71,33 @@ template <int T> __device__ __forceinline__ int blk_value(int nib, unsigned qh, 
     else if constexpr (T == PKV_TYPE_IQ4_NL) return iq4nl_value(nib);
     else if constexpr (T == PKV_TYPE_Q5_0) return (nib | (int) (((qh >> e) & 1u) << 4)) - 16;
     else                                   return nib | (int) (((qh >> e) & 1u) << 4);
+}
+
+// the workgroup's result for column `col` of (query row, head): the output itself (a row that sees no cell: zeros, as the paged kernels), or — split-KV — its
+// (m, l, unnormalised O) partial
+__device__ __forceinline__ void flat_store(const FlatArgs & a, int iq, int h, int col, float M, float L, float o) {
+    if (a.n_split == 1) { a.out[((size_t) iq * a.n_head + h) * a.D + col] = L > 0.0f ? o * (1.0f / L) : 0.0f; return; }
+    float * p = a.part + (((size_t) iq * a.n_head + h) * a.n_split + blockIdx.z) * (a.D + 2);
+    p[2 + col] = o;
+    if (col == 0) { p[0] = M; p[1] = L; }
+}
+// grid (n_q, n_head) x 256: out = sum_z O_z e^{m_z - M} / sum_z l_z e^{m_z - M}
+__global__ void __launch_bounds__(FLAT_DMAX) flat_merge_kernel(const FlatArgs a) {
+    const int iq = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    if (d >= a.D) return;
+    const float * p = a.part + ((size_t) iq * a.n_head + h) * a.n_split * (a.D + 2);
+    float M = -INFINITY;
+    for (int z = 0; z < a.n_split; ++z) M = fmaxf(M, p[(size_t) z * (a.D + 2)]);
+    float L = 0.0f, o = 0.0f;
+    if (M != -INFINITY) {
+        for (int z = 0; z < a.n_split; ++z) {
+            const float * pz = p + (size_t) z * (a.D + 2);
+            const float f = expf(pz[0] - M);
+            L = fmaf(pz[1], f, L);
+            o = fmaf(pz[2 + d], f, o);
+        }
+    }
+    a.out[((size_t) iq * a.n_head + h) * a.D + d] = L > 0.0f ? o * (1.0f / L) : 0.0f;
 }
 
 __device__ __forceinline__ float wave_max(float x) {
@@ -216,10 +246,11 @@ __global__ void __launch_bounds__(64 * FLAT_NW_LONG) attn_flat_kernel(const Flat
     const bool ksafe = a.k_al16 != 0;
     float m = -INFINITY, l = 0.0f, acc[FLAT_DMAX / 64] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    for (int c0 = wave * 64; c0 < a.n_kv; c0 += nw * 64) {
+    const int kv_beg = (int) blockIdx.z * a.split_len, kv_end = min(a.n_kv, kv_beg + a.split_len);
+    for (int c0 = kv_beg + wave * 64; c0 < kv_end; c0 += nw * 64) {
         const int t = c0 + lane;
         float s = -INFINITY;
-        if (t < a.n_kv) {
+        if (t < kv_end) {
             const float mv = mrow ? slope * (float) mrow[t] : 0.0f;
             if (mv != -INFINITY) {                                    // :12349-12352: a masked cell is skipped
                 s = k_dot<KT>(kb + (size_t) t * a.k_s_tok, sQ, sQd, D, ksafe) * a.scale;
@@ -235,7 +266,7 @@ __global__ void __launch_bounds__(64 * FLAT_NW_LONG) attn_flat_kernel(const Flat
         m = mn;
 #pragma unroll
         for (int i = 0; i < FLAT_DMAX / 64; ++i) acc[i] *= alpha;
-        const int nt = min(64, a.n_kv - c0);
+        const int nt = min(64, kv_end - c0);
         for (int j = 0; j < nt; ++j) {
             const float pj = __shfl(p, j);
             if (pj == 0.0f) continue;                                // (wave-uniform)
@@ -264,13 +295,136 @@ __global__ void __launch_bounds__(64 * FLAT_NW_LONG) attn_flat_kernel(const Flat
                 o = fmaf(sAcc[w][tid], f, o);
             }
         }
-        a.out[((size_t) iq * a.n_head + h) * D + tid] = L > 0.0f ? o * (1.0f / L) : 0.0f;   // (a row that sees no cell: zeros, as the paged kernels)
+        flat_store(a, iq, h, tid, M, L, o);
     }
+}
+
+// ---- the same operator for 16-bit rows (f16 / bf16 K and V, 16-byte aligned): LPR = D / 8 (rounded up to a power of two) lanes share a row, 16 bytes each, so
+//      one wave instruction reads 64 / LPR whole rows and every byte of a line is used (the lane-per-row form above keeps the texture path busy with 64 lines
+//      per K instruction and 2-byte V loads: profiles/r03_flat_bench.txt).  The lane's eight Q values stay in registers; the partial dots of a row are
+//      summed across its LPR lanes, lane j of a row slot keeps the logit of the slot's j-th row — one logit per lane, as above —, the weights go back to the
+//      rows' lanes by a shuffle for PV, and the R = 64 / LPR row slots' accumulators are added at the end.
+template <int KT, int VT, int LPR>
+__global__ void __launch_bounds__(64 * FLAT_NW_LONG) attn_flat16_kernel(const FlatArgs a) {
+    constexpr int R = 64 / LPR;
+    const int iq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int D = a.D, hk = h / (a.n_head / a.n_head_kv), nw = (int) (blockDim.x >> 6);
+    const int g = lane / LPR, j = lane % LPR;
+    const bool active = 8 * j < D;
+    __shared__ float sAcc[FLAT_NW_LONG][FLAT_DMAX], sM[FLAT_NW_LONG], sL[FLAT_NW_LONG];
+
+    float qv[8];
+    {
+        const float * qrow = a.q + (size_t) iq * a.q_s_tok + (size_t) h * a.q_s_head + 8 * j;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = active ? qrow[e] : 0.0f;
+            qv[e] = KT == PKV_TYPE_F16 ? (float) (_Float16) x : bf_round(x);
+        }
+    }
+    const float slope = a.max_bias > 0.0f ? ((unsigned) h < a.n_head_log2 ? powf(a.m0, (float) (h + 1)) : powf(a.m1, (float) (2 * (h - (int) a.n_head_log2) + 1))) : 1.0f;
+    const _Float16 * mrow = a.mask ? a.mask + (size_t) iq * a.mask_stride : nullptr;
+    const char * kb = a.k + (size_t) hk * a.k_s_head + 16 * j, * vb = a.v + (size_t) hk * a.v_s_head + 16 * j;
+    float m = -INFINITY, l = 0.0f, acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto dot8 = [&](const uint4 & w) {
+        const unsigned u[4] = {w.x, w.y, w.z, w.w};
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s = fmaf(e16<KT>((unsigned short) (u[i] & 0xffffu)), qv[2 * i], s);
+            s = fmaf(e16<KT>((unsigned short) (u[i] >> 16)), qv[2 * i + 1], s);
+        }
+        return s;
+    };
+
+    const int kv_beg = (int) blockIdx.z * a.split_len, kv_end = min(a.n_kv, kv_beg + a.split_len);
+    for (int c0 = kv_beg + wave * 64; c0 < kv_end; c0 += nw * 64) {
+        // ---- logits: instruction i covers the rows c0 + i * R + g; lane j of a slot keeps row j's
+        float sraw = 0.0f;
+#pragma unroll 4
+        for (int i = 0; i < LPR; ++i) {
+            const int t = c0 + i * R + g;
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (active && t < kv_end) w = *reinterpret_cast<const uint4 *>(kb + (size_t) t * a.k_s_tok);
+            float part = dot8(w);
+#pragma unroll
+            for (int o = LPR / 2; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+            if (i == j) sraw = part;
+        }
+        const int t = c0 + j * R + g;                                 // this lane's cell
+        float s = -INFINITY;
+        if (t < kv_end) {
+            const float mv = mrow ? slope * (float) mrow[t] : 0.0f;
+            if (mv != -INFINITY) {
+                s = sraw * a.scale;
+                if (a.softcap != 0.0f) s = a.softcap * tanhf(s);
+                s += mv;
+            }
+        }
+        const float cm = wave_max(s);
+        if (cm == -INFINITY) continue;                               // (wave-uniform)
+        const float mn = fmaxf(m, cm);
+        const float alpha = expf(m - mn), p = expf(s - mn);
+        l = l * alpha + wave_sum(p);
+        m = mn;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+        // ---- PV: the weight of row c0 + i * R + g sits in lane i of this slot
+#pragma unroll 4
+        for (int i = 0; i < LPR; ++i) {
+            const int tr = c0 + i * R + g;
+            const float pr = __shfl(p, (lane & ~(LPR - 1)) | i);
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (active && tr < kv_end) w = *reinterpret_cast<const uint4 *>(vb + (size_t) tr * a.v_s_tok);
+            const unsigned u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                acc[2 * x]     = fmaf(e16<VT>((unsigned short) (u[x] & 0xffffu)), pr, acc[2 * x]);
+                acc[2 * x + 1] = fmaf(e16<VT>((unsigned short) (u[x] >> 16)), pr, acc[2 * x + 1]);
+            }
+        }
+    }
+    // the row slots of the wave, then the waves
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o);
+    if (lane == 0) { sM[wave] = m; sL[wave] = l; }
+    if (g == 0 && active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sAcc[wave][8 * j + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < D) {
+        float M = sM[0];
+        for (int w = 1; w < nw; ++w) M = fmaxf(M, sM[w]);
+        float L = 0.0f, o = 0.0f;
+        if (M != -INFINITY) {
+            for (int w = 0; w < nw; ++w) {
+                const float f = expf(sM[w] - M);
+                L = fmaf(sL[w], f, L);
+                o = fmaf(sAcc[w][tid], f, o);
+            }
+        }
+        flat_store(a, iq, h, tid, M, L, o);
+    }
+}
+
+template <int KT, int VT>
+int launch_flat16(const FlatArgs & fa, hipStream_t st) {
+    const dim3 grid(fa.n_q, fa.n_head, fa.n_split), block(64 * (fa.split_len >= 64 * FLAT_NW_LONG ? FLAT_NW_LONG : FLAT_NW));
+    const int lanes = (fa.D + 7) / 8;
+    if (lanes <= 4)       hipLaunchKernelGGL((attn_flat16_kernel<KT, VT, 4>), grid, block, 0, st, fa);
+    else if (lanes <= 8)  hipLaunchKernelGGL((attn_flat16_kernel<KT, VT, 8>), grid, block, 0, st, fa);
+    else if (lanes <= 16) hipLaunchKernelGGL((attn_flat16_kernel<KT, VT, 16>), grid, block, 0, st, fa);
+    else                  hipLaunchKernelGGL((attn_flat16_kernel<KT, VT, 32>), grid, block, 0, st, fa);
+    PKV_HIP(hipGetLastError());
+    return PKV_OK;
 }
 
 template <int KT>
 int launch_v(const FlatArgs & fa, int type_v, hipStream_t st) {
-    const dim3 grid(fa.n_q, fa.n_head), block(64 * (fa.n_kv >= 64 * FLAT_NW_LONG ? FLAT_NW_LONG : FLAT_NW));
+    const dim3 grid(fa.n_q, fa.n_head, fa.n_split), block(64 * (fa.split_len >= 64 * FLAT_NW_LONG ? FLAT_NW_LONG : FLAT_NW));
     switch (type_v) {
 #define PKV_FLAT_V(VT) case VT: hipLaunchKernelGGL((attn_flat_kernel<KT, VT>), grid, block, 0, st, fa); break
         PKV_FLAT_V(PKV_TYPE_F16); PKV_FLAT_V(PKV_TYPE_BF16); PKV_FLAT_V(PKV_TYPE_Q8_0); PKV_FLAT_V(PKV_TYPE_Q4_0);
@@ -384,6 +538,13 @@ __global__ void __launch_bounds__(256) quantize_blocks_kernel(const float * x, c
 
 }  // namespace
 
+// [n_q][n_head][FLAT_MAX_SPLIT][D + 2] floats: what the split-KV mode of a launch of this shape can use (0: it never splits)
+size_t flat_workspace_bytes(int n_q, int n_head, int D, int n_kv) {
+    const long long pairs = (long long) n_q * n_head;
+    if (pairs <= 0 || pairs >= 1024 || n_kv < 512) return 0;
+    return (size_t) pairs * FLAT_MAX_SPLIT * (D + 2) * sizeof(float);
+}
+
 int launch_attn_flat(const pkv_flat_attn_args & a, hipStream_t st) {
     PKV_REQUIRE(a.q && a.k && a.v && a.out, "pkv_flash_attn_ext_flat: null pointer");
     PKV_REQUIRE(a.n_q > 0 && a.n_kv > 0 && a.n_head > 0 && a.n_head_kv > 0 && a.n_head % a.n_head_kv == 0, "pkv_flash_attn_ext_flat: bad shape");
@@ -413,18 +574,43 @@ int launch_attn_flat(const pkv_flat_attn_args & a, hipStream_t st) {
     fa.m0 = powf(2.0f, -(a.max_bias) / fa.n_head_log2);
     fa.m1 = powf(2.0f, -(a.max_bias / 2.0f) / fa.n_head_log2);
     fa.k_al16 = ((uintptr_t) a.k % 16) == 0 && a.k_stride_tok % 16 == 0 && a.k_stride_head % 16 == 0;
-    fa.v_al16 = 0;
-    switch (a.type_k) {
-        case PKV_TYPE_F16:  return launch_v<PKV_TYPE_F16>(fa, a.type_v, st);
-        case PKV_TYPE_BF16: return launch_v<PKV_TYPE_BF16>(fa, a.type_v, st);
-        case PKV_TYPE_Q8_0: return launch_v<PKV_TYPE_Q8_0>(fa, a.type_v, st);
-        case PKV_TYPE_Q4_0: return launch_v<PKV_TYPE_Q4_0>(fa, a.type_v, st);
-        case PKV_TYPE_Q4_1: return launch_v<PKV_TYPE_Q4_1>(fa, a.type_v, st);
-        case PKV_TYPE_Q5_0: return launch_v<PKV_TYPE_Q5_0>(fa, a.type_v, st);
-        case PKV_TYPE_Q5_1: return launch_v<PKV_TYPE_Q5_1>(fa, a.type_v, st);
-        case PKV_TYPE_IQ4_NL: return launch_v<PKV_TYPE_IQ4_NL>(fa, a.type_v, st);
+    fa.v_al16 = ((uintptr_t) a.v % 16) == 0 && a.v_stride_tok % 16 == 0 && a.v_stride_head % 16 == 0;
+    // split-KV: a launch of few (query row, head) pairs over a long K / V (a decode step: 32 workgroups for 256 CUs) is cut along the cells into n_split
+    // workgroups per pair that leave (m, l, O) partials in the caller's workspace, merged by a second small launch.  Whole 64-cell chunks per share, at least
+    // 256 cells each; no workspace (or a short one): unsplit.
+    fa.n_split = 1; fa.split_len = a.n_kv; fa.part = nullptr;
+    {
+        const long long pairs = (long long) a.n_q * a.n_head;
+        int ns = (int) std::min<long long>(FLAT_MAX_SPLIT, (1024 + pairs - 1) / pairs);
+        ns = std::min(ns, a.n_kv / 256);
+        if (ns > 1 && a.workspace && a.workspace_bytes >= flat_workspace_bytes(a.n_q, a.n_head, a.head_dim, a.n_kv)) {
+            const int len = (((a.n_kv + ns - 1) / ns) + 63) & ~63;
+            fa.split_len = len; fa.n_split = (a.n_kv + len - 1) / len; fa.part = (float *) a.workspace;
+        }
     }
-    return PKV_ERR_UNSUPPORTED;
+    int rc = PKV_ERR_UNSUPPORTED;
+    const bool k16 = a.type_k == PKV_TYPE_F16 || a.type_k == PKV_TYPE_BF16, v16 = a.type_v == PKV_TYPE_F16 || a.type_v == PKV_TYPE_BF16;
+    static const bool no_rowcoop = getenv("PKV_FLAT_NO_ROWCOOP") != nullptr;   // (A/B against the lane-per-row form)
+    if (k16 && v16 && fa.k_al16 && fa.v_al16 && a.head_dim % 8 == 0 && !no_rowcoop) {   // 16-bit rows, 16-byte aligned, whole 8-element chunks: the row-cooperative form
+        if (a.type_k == PKV_TYPE_F16)  rc = a.type_v == PKV_TYPE_F16 ? launch_flat16<PKV_TYPE_F16, PKV_TYPE_F16>(fa, st) : launch_flat16<PKV_TYPE_F16, PKV_TYPE_BF16>(fa, st);
+        else                           rc = a.type_v == PKV_TYPE_F16 ? launch_flat16<PKV_TYPE_BF16, PKV_TYPE_F16>(fa, st) : launch_flat16<PKV_TYPE_BF16, PKV_TYPE_BF16>(fa, st);
+    } else {
+        switch (a.type_k) {
+            case PKV_TYPE_F16:  rc = launch_v<PKV_TYPE_F16>(fa, a.type_v, st); break;
+            case PKV_TYPE_BF16: rc = launch_v<PKV_TYPE_BF16>(fa, a.type_v, st); break;
+            case PKV_TYPE_Q8_0: rc = launch_v<PKV_TYPE_Q8_0>(fa, a.type_v, st); break;
+            case PKV_TYPE_Q4_0: rc = launch_v<PKV_TYPE_Q4_0>(fa, a.type_v, st); break;
+            case PKV_TYPE_Q4_1: rc = launch_v<PKV_TYPE_Q4_1>(fa, a.type_v, st); break;
+            case PKV_TYPE_Q5_0: rc = launch_v<PKV_TYPE_Q5_0>(fa, a.type_v, st); break;
+            case PKV_TYPE_Q5_1: rc = launch_v<PKV_TYPE_Q5_1>(fa, a.type_v, st); break;
+            case PKV_TYPE_IQ4_NL: rc = launch_v<PKV_TYPE_IQ4_NL>(fa, a.type_v, st); break;
+        }
+    }
+    if (rc == PKV_OK && fa.n_split > 1) {
+        hipLaunchKernelGGL(flat_merge_kernel, dim3(fa.n_q, fa.n_head), dim3(FLAT_DMAX), 0, st, fa);
+        PKV_HIP(hipGetLastError());
+    }
+    return rc;
 }
 
 // pkv_convert_f32 for the cache types that exist only as flat rows

@@ -275,6 +275,7 @@ int pkv_attn_prefill(const pkv_attn_args * args, void * stream) {
     return launch_attn_prefill(*args, (hipStream_t) stream);
 }
 
+size_t pkv_flash_attn_ext_flat_workspace_bytes(int n_q, int n_head, int head_dim, int n_kv) { return flat_workspace_bytes(n_q, n_head, head_dim, n_kv); }
 int pkv_flash_attn_ext_flat(const pkv_flat_attn_args * args, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(args != nullptr, "pkv_flash_attn_ext_flat: null args");

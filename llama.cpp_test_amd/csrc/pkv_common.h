@@ -155,6 +155,7 @@ int launch_kv_store(float * q, int n_head_q, const float * k_cur, const float * 
 int launch_attn_decode(const pkv_attn_args & a, hipStream_t st, const pkv_step_args * step = nullptr);
 int launch_attn_prefill(const pkv_attn_args & a, hipStream_t st, const float * rope_cache = nullptr);   // rope_cache: RoPE(Q) fused in (NORM pairs)
 int launch_attn_flat(const pkv_flat_attn_args & a, hipStream_t st);   // pkv_attn_flat.hip
+size_t flat_workspace_bytes(int n_q, int n_head, int D, int n_kv);
 int launch_quantize_blocks(const float * x, void * dst, int type, int64_t n_rows, int64_t ne0, hipStream_t st);   // q4_1 / q5_0 / q5_1 / iq4_nl (pkv_attn_flat.hip)
 int launch_attn_decode_stamps(const pkv_attn_args & a, const pkv_step_args * step, unsigned long long * stamps, int mode, hipStream_t st);
 size_t decode_workspace_bytes(int n_tok, int n_head, int D, int max_seq_len);

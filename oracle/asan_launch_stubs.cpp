@@ -28,6 +28,7 @@ int launch_attn_decode(pkv_attn_args const&, hipStream_t, pkv_step_args const*) 
 int launch_copy_blocks(void*, unsigned long, int const*, int const*, int, hipStream_t) { return PKV_ERR_NO_DEVICE; }
 int launch_cpy_strided(void const*, int, long const*, long const*, void*, int, long const*, long const*, hipStream_t) { return PKV_ERR_NO_DEVICE; }
 int launch_attn_flat(pkv_flat_attn_args const&, hipStream_t) { return PKV_ERR_NO_DEVICE; }
+size_t flat_workspace_bytes(int, int, int, int) { return 0; }
 int launch_quantize_blocks(float const*, void*, int, long, long, hipStream_t) { return PKV_ERR_NO_DEVICE; }
 void set_prefill_stamps(void*) {}
 int launch_attn_prefill(pkv_attn_args const&, hipStream_t, float const*) { return PKV_ERR_NO_DEVICE; }

@@ -14,10 +14,11 @@ def run(D, nh, nkv, n_kv, n_q, t):
     if t in ("f16", "bf16"):                              # random bytes hold inf / nan patterns: clear the exponent's top bit
         for x in ks + vs: x[..., 1::2] &= 0x3F if t == "f16" else 0xBF; 
     out = torch.empty((n_q, nh, D), device="cuda")
-    for i in range(3): pkv.flash_attn_ext_flat(q, ks[i], vs[i], None, type_k=T[t], type_v=T[t], scale=D ** -0.5, out=out)
+    ws = torch.empty(max(16, pkv.lib().pkv_flash_attn_ext_flat_workspace_bytes(n_q, nh, D, n_kv)), dtype=torch.uint8, device="cuda")   # split-KV scratch (decode shapes)
+    for i in range(3): pkv.flash_attn_ext_flat(q, ks[i], vs[i], None, type_k=T[t], type_v=T[t], scale=D ** -0.5, out=out, workspace=ws)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    for i in range(reps): pkv.flash_attn_ext_flat(q, ks[i], vs[i], None, type_k=T[t], type_v=T[t], scale=D ** -0.5, out=out)
+    for i in range(reps): pkv.flash_attn_ext_flat(q, ks[i], vs[i], None, type_k=T[t], type_v=T[t], scale=D ** -0.5, out=out, workspace=ws)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     byt = 2 * nkv * n_kv * rb

@@ -143,3 +143,20 @@ def test_kv_store_of_the_remaining_cache_types_is_bit_exact(pkv, O, t):
         assert np.array_equal(g[nz], w[nz]) and not g[~nz][:, :2].any() and (~nz).sum() >= 8
     else:
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tk", ["bf16", "q8_0"])
+def test_split_kv_of_a_decode_shaped_launch(pkv, O, tk):
+    """few query rows over a long K / V: the launch is cut along the cells (partials + merge launch) when the caller lends a workspace — same result as the unsplit
+    launch up to the order of the additions, same bars against the oracle; a range that is masked out entirely contributes nothing"""
+    tk = T[tk]
+    rng = np.random.default_rng(70 + tk)
+    D, nh, nkv, n_kv, n_q = 128, 8, 2, 4099, 1
+    q, k, v, mask = _case(O, rng, D, nh, nkv, n_kv, n_q, tk, tk)
+    mask[:, 1024:2048] = -np.inf                                     # one whole share of the split sees nothing
+    assert pkv.lib().pkv_flash_attn_ext_flat_workspace_bytes(n_q, nh, D, n_kv) > 0
+    a = pkv.flash_attn_ext_flat(dev(q), dev(k), dev(v), dev(mask), type_k=tk, type_v=tk, scale=D ** -0.5)
+    b = pkv.flash_attn_ext_flat(dev(q), dev(k), dev(v), dev(mask), type_k=tk, type_v=tk, scale=D ** -0.5, split=False)
+    torch.cuda.synchronize()
+    assert np.abs(a.cpu().numpy() - b.cpu().numpy()).max() <= 2e-6
+    _check(O, a.cpu().numpy(), q, k, v, mask, tk, tk, D)
