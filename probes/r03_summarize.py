@@ -12,8 +12,9 @@ tag = "r03"
 
 
 def one(pattern):
+    # gpurun MERGES a run's files into the local directory: files of earlier evidence runs (other process ids in their names) stay behind.  The newest one is this run's.
     g = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None
 
 
 def cp(src, dst):
