@@ -841,7 +841,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         if (fuse && (n->op == GGML_OP_RMS_NORM || n->op == GGML_OP_MUL_MAT)) {
             auto kq_col = [&](const ggml_tensor * t, const ggml_tensor * col) {   // t = MUL_MAT of K-quant rows with the single column `col`
                 const ggml_tensor * w = t->src[0], * x = t->src[1];
-                return t->op == GGML_OP_MUL_MAT && x == col && w && (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q6_K) && ggml_is_contiguous(w) && f32c(x) && f32c(t) &&
+                return t->op == GGML_OP_MUL_MAT && x == col && w && (w->type == GGML_TYPE_Q4_K || w->type == GGML_TYPE_Q5_K || w->type == GGML_TYPE_Q6_K) && ggml_is_contiguous(w) && f32c(x) && f32c(t) &&
                        ggml_nrows(x) == 1 && w->ne[2] == 1 && w->ne[3] == 1 && w->ne[0] == x->ne[0] && w->ne[0] % 256 == 0 && w->ne[0] <= 49152 && w->ne[1] % 2 == 0 &&
                        !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
             };
@@ -880,7 +880,14 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             // and the epilogue node reads or writes (those nodes run AFTER the fused launch): ggml-alloc's in-place placement of today's llama graphs is safe, a
             // graph cut by cb_eval / OUTPUT flags / adapters need not be
             bool wtype_uniform = true;                       // one launch = one row layout (plane-layout weights of a WEIGHTS buffer and GGUF-order ones do not mix)
-            for (int q = 1; q < np; ++q) wtype_uniform = wtype_uniform && (wtype(ggml_graph_node(g, prod[q])->src[0]) & PKV_TYPE_PACKED) == (wtype(ggml_graph_node(g, prod[0])->src[0]) & PKV_TYPE_PACKED);
+            {   // (q5_K rows have no plane layout and run as a launch of their own inside pkv_gemv_q: they do not take part in the comparison)
+                int pk0 = -1;
+                for (int q = 0; q < np; ++q) {
+                    const int tq = (int) wtype(ggml_graph_node(g, prod[q])->src[0]);
+                    if ((tq & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K) continue;
+                    if (pk0 < 0) pk0 = tq & PKV_TYPE_PACKED; else wtype_uniform = wtype_uniform && (tq & PKV_TYPE_PACKED) == pk0;
+                }
+            }
             if (!wtype_uniform) ok = false;
             auto early_ok = [&](const ggml_tensor * out, int last_idx, std::initializer_list<int> chain) {
                 if (overlaps(out, xsrc) || (nw && (overlaps(out, nw) || overlaps(out, n) || overlaps(out, col)))) return false;

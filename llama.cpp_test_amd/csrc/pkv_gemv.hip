@@ -133,6 +133,37 @@ __device__ __forceinline__ float dot_q4k(const uint4 & hdr, const uint4 & qa, co
     return d * (float) (s1 * ilo + s2 * ihi) - dmin * (float) (m1 * b0 + m2 * b1);
 }
 
+// one 64-element group of a block_q5_K row (176 B: {d, dmin, scales[12]}, qh[32], qs[128], /ref/ggml/src/ggml-common.h:291-308): the q4_K group
+// plus its fifth bits — bit 2 p of qh[l] belongs to element 64 p + l, bit 2 p + 1 to element 64 p + 32 + l (dequantize_row_q5_K,
+// /ref/ggml/src/ggml-quants.c:1482-1507: u1 = 1 << 2 p, u2 = 2 << 2 p).  ha / hb = the block's 32 bytes of qh (shared by its four groups); the 5-bit
+// quants 0..31 enter the integer dots as ggml_vec_dot_q5_K_q8_K forms them (ggml-cpu-quants.c: sum_j scale_j (q5 . q8)_j, sum_j min_j bsum_j).
+template <int TAIL>
+__device__ __forceinline__ float dot_q5k(const uint4 & hdr, const uint4 & qa, const uint4 & qb, const uint4 & ha, const uint4 & hb, int p, const uint32_t * rec) {
+    const uint4 x0 = *reinterpret_cast<const uint4 *>(rec), x1 = *reinterpret_cast<const uint4 *>(rec + 4), x2 = *reinterpret_cast<const uint4 *>(rec + 8),
+                x3 = *reinterpret_cast<const uint4 *>(rec + 12), tl = *reinterpret_cast<const uint4 *>(rec + 16);
+    const uint32_t xq[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+    const float dx = __uint_as_float(tl.z);
+    int b0, b1;
+    if constexpr (TAIL == 0) { b0 = (int) tl.x; b1 = (int) tl.y; }
+    else { b0 = ((int) (tl.x << 16) >> 16) + ((int) tl.x >> 16); b1 = ((int) (tl.y << 16) >> 16) + ((int) tl.y >> 16); }
+    const float d = h2f((uint16_t) (hdr.x & 0xFFFF)) * dx, dmin = h2f((uint16_t) (hdr.x >> 16)) * dx;
+    const uint32_t sh = 16u * (uint32_t) (p & 1);                               // get_scale_min_k4, as in dot_q4k
+    const uint32_t ty = hdr.y >> sh, tz = hdr.z >> sh, tw = hdr.w >> sh;
+    const uint32_t sc_lo = ty & 0x3F3Fu, mn_lo = tz & 0x3F3Fu;
+    const uint32_t sc_hi = (tw & 0x0F0Fu) | ((ty >> 2) & 0x3030u), mn_hi = ((tw >> 4) & 0x0F0Fu) | ((tz >> 2) & 0x3030u);
+    const uint32_t sc = p < 2 ? sc_lo : sc_hi, mn = p < 2 ? mn_lo : mn_hi;
+    const int s1 = (int) (sc & 0xFF), s2 = (int) (sc >> 8), m1 = (int) (mn & 0xFF), m2 = (int) (mn >> 8);
+    const uint32_t qw[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w}, qh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+    int ilo = 0, ihi = 0;
+#pragma unroll
+    for (int w4 = 0; w4 < 8; ++w4) {           // byte b of dword w4: qs / qh byte 4 w4 + b of the group / block
+        const uint32_t h = qh[w4] >> (2 * p);  // 2 p <= 6: bits 0 / 1 of every byte = the group's two fifth bits of that byte
+        ilo = __builtin_amdgcn_sdot4((int) ((qw[w4] & 0x0F0F0F0Fu) | ((h & 0x01010101u) << 4)), (int) xq[w4], ilo, false);
+        ihi = __builtin_amdgcn_sdot4((int) (((qw[w4] >> 4) & 0x0F0F0F0Fu) | ((h & 0x02020202u) << 3)), (int) xq[8 + w4], ihi, false);
+    }
+    return d * (float) (s1 * ilo + s2 * ihi) - dmin * (float) (m1 * b0 + m2 * b1);
+}
+
 // block_q6_K (210 bytes: every other block sits 2 bytes off a dword boundary — the 16-byte loads below are misaligned, which gfx950 global
 // loads serve correctly, probes/unaligned_probe.hip): quarter `qt` = (n, is) of the block -> elements n*128 + 32 j + 16 is + [0, 16), j = 0..3,
 // scale index 8 n + is + 2 j (dequantize_row_q6_K, /ref/ggml/src/ggml-quants.c:1690-1719).  la = ql[16 is ..], lb = ql[32 + 16 is ..],
@@ -184,7 +215,7 @@ __device__ __forceinline__ float wsum_dpp(float x) {
 }
 
 // One unit of a wave's work = 128 (row, 64-element group) items of a row pair: the lane's items u = 0, 1.  Its loads (MODE 12: q4_K rows
-// only, 3 x 16 bytes per item; MODE 14: q6_K only, 4 x 16 + 2; MODE 0: any mix, the q6_K shape for every lane so that the number of loads
+// only, 3 x 16 bytes per item; MODE 13: q5_K only, GGUF order, 5 x 16; MODE 14: q6_K only, 4 x 16 + 2; MODE 0: any mix of q4_K / q6_K, the q6_K shape for every lane so that the number of loads
 // in flight does not depend on the lane's type — a q4_K lane re-reads its header) are issued TWO units ahead of the dots that consume them.
 // Plain named registers per pipeline stage (a struct handed to lambdas by reference ended up in scratch memory: 368 bytes per lane and
 // every weight load doubled by a scratch store — rocprofv3 Scratch_Size column).
@@ -212,7 +243,7 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
         return *reinterpret_cast<const uint4 *>(p);
     }
 }
-#define PKV_UNIT_DECL(S) uint4 S##r0[UI], S##r1[UI], S##r2[UI], S##r3[UI]; uint16_t S##dh[UI]; int S##g[UI], S##p[UI], S##ty[UI], S##rs[UI]; bool S##ok[UI]; int S##mi; int64_t S##m0;
+#define PKV_UNIT_DECL(S) uint4 S##r0[UI], S##r1[UI], S##r2[UI], S##r3[UI], S##r4[UI]; uint16_t S##dh[UI]; int S##g[UI], S##p[UI], S##ty[UI], S##rs[UI]; bool S##ok[UI]; int S##mi; int64_t S##m0;
 #define PKV_UNIT_LOAD(S, RPI, FI, PAST)                                                                                                           \
     {                                                                                                                                          \
         const int rp_ = first + __builtin_amdgcn_readfirstlane(RPI) * stride, f0_ = __builtin_amdgcn_readfirstlane(FI) * (64 * UI);            \
@@ -245,8 +276,15 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
                     S##dh[u] = *reinterpret_cast<const uint16_t *>(k4 ? bl_ + 32 * gpr : rw_ + 52 * gpr + 2 * (ga_ >> 2)    );                 \
                 }                                                                                                                              \
             } else {                                                                                                                           \
-            const unsigned char * bp = rw_ + (size_t) (ga_ >> 2) *       (S##ty[u] == PKV_TYPE_Q4_K ? 144 : 210);                                \
+            const unsigned char * bp = rw_ + (size_t) (ga_ >> 2) * (S##ty[u] == PKV_TYPE_Q4_K ? 144 : (S##ty[u] == PKV_TYPE_Q5_K ? 176 : 210));           \
             const int n_ = pa_ >> 1, is_ = pa_ & 1;                                                                                            \
+            if (MODE == PKV_TYPE_Q5_K) {   /* header, the group's 32 bytes of nibbles, the block's 32 bytes of fifth bits (176 = 11 x 16: all aligned) */ \
+                S##r0[u] = ld16w<false>(bp);                                                                                                   \
+                S##r1[u] = ld16w<false>(bp + 48 + 32 * pa_    );                                                                               \
+                S##r2[u] = ld16w<false>(bp + 64 + 32 * pa_    );                                                                               \
+                S##r3[u] = ld16w<false>(bp + 16);                                                                                              \
+                S##r4[u] = ld16w<false>(bp + 32); S##dh[u] = 0;                                                                                \
+            } else                                                                                                                             \
             if (MODE == PKV_TYPE_Q4_K) {                                                                                                       \
                 S##r0[u] = ld16w<false>(bp);                                                                                                   \
                 S##r1[u] = ld16w<false>(bp + 16 + 32 * pa_    );                                                                               \
@@ -268,7 +306,8 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
         _Pragma("unroll") for (int u = 0; u < UI; ++u) {                                                                                        \
             float part;                                                                                                                        \
             if (PKV_GEMV_ABLATE == 1) { part = __uint_as_float((S##r0[u].x ^ S##r1[u].y ^ S##r2[u].z ^ S##r3[u].w ^ S##r1[u].w ^ S##r2[u].x) & 0x3fffffffu); } else \
-            if (S##ty[u] == PKV_TYPE_Q4_K) part = dot_q4k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##p[u], sq + S##g[u] * REC);                             \
+            if (MODE == PKV_TYPE_Q5_K) part = dot_q5k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##r4[u], S##p[u], sq + S##g[u] * REC);             \
+            else if (S##ty[u] == PKV_TYPE_Q4_K) part = dot_q4k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##p[u], sq + S##g[u] * REC);                        \
             else part = dot_q6k(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##dh[u], S##p[u], sq + ((S##g[u] & ~3) + 2 * (S##p[u] >> 1)) * REC);            \
             if (!S##ok[u]) part = 0.0f;                                                                                                        \
             acc0 += S##rs[u] ? 0.0f : part;                                                                                                    \
@@ -361,7 +400,7 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict
         if ((int) threadIdx.x < (aK >> 5)) bpre = reinterpret_cast<const int *>(aimg + aK + (aK >> 8) * 4)[threadIdx.x];
     }
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int TAIL = MODE == PKV_TYPE_Q4_K ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
+    constexpr int TAIL = (MODE == PKV_TYPE_Q4_K || MODE == PKV_TYPE_Q5_K) ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
     const int gpr = aK >> 6;
     uint32_t * sq = g_lds;                                           // gpr records of REC dwords
     __shared__ double sred[32];                                       // sums of squares per 256-element block (norm prologue)
@@ -657,6 +696,30 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
                 "pkv_gemv_q: in-kernel column: x (and norm_w) 16-byte aligned, K <= 8192 with a norm");
     PKV_REQUIRE(!g.silu_mul || (g.n == 2 && g.M[0] == g.M[1] && !g.residual), "pkv_gemv_q: silu_mul needs two products of equal M and no residual");
     PKV_REQUIRE(!g.residual || g.n == 1, "pkv_gemv_q: the residual epilogue takes one product");
+    // block_q5_K rows (what a Q5_K_M file holds beside its q6_K tensors): a launch of their own (MODE 13, GGUF order — a 64-element group's fifth
+    // bits are spread over the block's 32 bytes of qh, so there is no byte permutation into planes); a group that mixes them with other types
+    // (wq / wk q5_K + wv q6_K) goes out as one launch per run of like rows: the in-kernel column (norm included) is the same bits in each.
+    {
+        bool any5 = false, all5 = true;
+        for (int i = 0; i < g.n; ++i) { const bool q5 = (g.type_w[i] & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K; any5 = any5 || q5; all5 = all5 && q5; }
+        if (any5) {
+            for (int i = 0; i < g.n; ++i)
+                if (g.type_w[i] == (PKV_TYPE_Q5_K | PKV_TYPE_PACKED)) { set_error("pkv_gemv_q: q5_K rows have no plane layout"); return PKV_ERR_UNSUPPORTED; }
+        }
+        if (any5 && !all5) {
+            if (g.silu_mul) { set_error("pkv_gemv_q: silu_mul over q5_K and another row type"); return PKV_ERR_UNSUPPORTED; }
+            for (int i0 = 0; i0 < g.n; ) {
+                int i1 = i0 + 1;
+                while (i1 < g.n && (g.type_w[i1] == PKV_TYPE_Q5_K) == (g.type_w[i0] == PKV_TYPE_Q5_K)) ++i1;
+                pkv_gemv s = g;
+                s.n = i1 - i0;
+                for (int k = 0; k < s.n; ++k) { s.type_w[k] = g.type_w[i0 + k]; s.w[k] = g.w[i0 + k]; s.y[k] = g.y[i0 + k]; s.M[k] = g.M[i0 + k]; }
+                if (int rc = launch_gemv(s, st)) return rc;
+                i0 = i1;
+            }
+            return PKV_OK;
+        }
+    }
     GemvArgs a = {};
     int tot = 0;
     const bool packed = (g.type_w[0] & PKV_TYPE_PACKED) != 0;       // plane-layout rows (pkv_wlayout.h): all matrices of a launch, or none
@@ -665,7 +728,7 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
         PKV_REQUIRE(g.w[i] && g.y[i] && g.M[i] > 0 && g.M[i] % 2 == 0, "pkv_gemv_q: matrix %d: null pointer or odd row count", i);
         PKV_REQUIRE(((g.type_w[i] & PKV_TYPE_PACKED) != 0) == packed, "pkv_gemv_q: the matrices of one launch are all packed or all in GGUF order");
         tw[i] = g.type_w[i] & ~PKV_TYPE_PACKED;
-        if (tw[i] != PKV_TYPE_Q4_K && tw[i] != PKV_TYPE_Q6_K) { set_error("pkv_gemv_q: weight type %d not supported (q4_K, q6_K)", g.type_w[i]); return PKV_ERR_UNSUPPORTED; }
+        if (tw[i] != PKV_TYPE_Q4_K && tw[i] != PKV_TYPE_Q5_K && tw[i] != PKV_TYPE_Q6_K) { set_error("pkv_gemv_q: weight type %d not supported (q4_K, q5_K, q6_K)", g.type_w[i]); return PKV_ERR_UNSUPPORTED; }
         a.w[i] = (const char *) g.w[i]; a.y[i] = g.y[i]; a.M[i] = g.M[i]; a.type[i] = tw[i];
         tot += g.silu_mul ? (i == 0 ? (int) g.M[0] : 0) : (int) (g.M[i] / 2);
         a.rp_end[i] = tot;
@@ -680,9 +743,9 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     a.gpr = (int) (g.K / 64); a.gs = 0;
     const size_t lds = (size_t) REC * a.gpr * 4;
     // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)
-    bool all4 = true, all6 = true;
-    for (int i = 0; i < g.n; ++i) { all4 = all4 && tw[i] == PKV_TYPE_Q4_K; all6 = all6 && tw[i] == PKV_TYPE_Q6_K; }
-    const int mode = all4 ? PKV_TYPE_Q4_K : (all6 ? PKV_TYPE_Q6_K : 0);
+    bool all4 = true, all5 = true, all6 = true;
+    for (int i = 0; i < g.n; ++i) { all4 = all4 && tw[i] == PKV_TYPE_Q4_K; all5 = all5 && tw[i] == PKV_TYPE_Q5_K; all6 = all6 && tw[i] == PKV_TYPE_Q6_K; }
+    const int mode = all4 ? PKV_TYPE_Q4_K : (all5 ? PKV_TYPE_Q5_K : (all6 ? PKV_TYPE_Q6_K : 0));
     int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
     // (8 waves with exactly 7 row pairs each instead of 16 with 3 or 4 — gate + up at Llama-3-8B sizes — is SLOWER, 16.4 vs 14.3 us: the waves hide
     // each other's load latency; profiles/r03_gemv_shapes.txt)
@@ -702,6 +765,7 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
 #define PKV_GEMV_PICK_W(MODE_, PK_) do { if (split) PKV_GEMV_PICK_S(MODE_, 16, 2, PK_); else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16, 1, PK_); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8, 1, PK_); else PKV_GEMV_PICK_S(MODE_, 4, 1, PK_); } while (0)
 #define PKV_GEMV_PICK_P(MODE_) do { if (packed) PKV_GEMV_PICK_W(MODE_, true); else PKV_GEMV_PICK_W(MODE_, false); } while (0)
     if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_P(PKV_TYPE_Q4_K);
+    else if (mode == PKV_TYPE_Q5_K) PKV_GEMV_PICK_W(PKV_TYPE_Q5_K, false);
     else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_P(PKV_TYPE_Q6_K);
     else                            PKV_GEMV_PICK_P(0);
     PKV_HIP(hipGetLastError());

@@ -593,7 +593,7 @@ int launch_silu(const float * x, float * y, int64_t n, hipStream_t st) {
     return PKV_OK;
 }
 // one column of K-quant weights: the decode-step product of pkv_gemv.hip (the column quantized to q8_K in its prologue)
-static bool gemv_shape(int type_w, int64_t M, int64_t K) { type_w &= ~PKV_TYPE_PACKED; return (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q6_K) && K % 256 == 0 && K <= 49152 && M % 2 == 0; }
+static bool gemv_shape(int type_w, int64_t M, int64_t K) { type_w &= ~PKV_TYPE_PACKED; return (type_w == PKV_TYPE_Q4_K || type_w == PKV_TYPE_Q5_K || type_w == PKV_TYPE_Q6_K) && K % 256 == 0 && K <= 49152 && M % 2 == 0; }
 constexpr int64_t GEMM_MIN_COLS = 16;   // from here on a weight tile read once per 128 columns beats a stream per column
 int launch_mul_mat(const void * w, int type_w, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, hipStream_t st) {
     if (M == 0 || n_cols == 0) return PKV_OK;

@@ -24,11 +24,12 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from . import (F16, Q4_K, Q6_K, PACKED, act_image, weights_pack, PagedKVCache, PkvError, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add, rms_norm_mul, rope_cache,
+from . import (F16, Q4_K, Q5_K, Q6_K, PACKED, act_image, weights_pack, PagedKVCache, PkvError, attn_decode_step, attn_workspace, gemv_q, get_rows, mul_mat, add, rms_norm_mul, rope_cache,
                rope_params, silu_mul, kv_store)
 from .gguf_synth import read_gguf, row_bytes
 
-_KQ = (Q4_K, Q6_K)
+_KQ = (Q4_K, Q5_K, Q6_K)    # row types of the decode-step products (pkv_gemv_q)
+_PK = (Q4_K, Q6_K)          # ... of them, the ones with a plane layout (a q5_K row's fifth bits do not separate by bytes)
 
 
 class LlamaDecoder:
@@ -52,7 +53,7 @@ class LlamaDecoder:
             ne, t, _, data = tensors[name]
             w = torch.from_numpy(np.array(data)).to(dev)                    # a copy: the file map is read-only
             ne, t = tuple(int(x) for x in ne), int(t)
-            if pack_weights and t in _KQ and len(ne) == 2 and ne[0] % 256 == 0:
+            if pack_weights and t in _PK and len(ne) == 2 and ne[0] % 256 == 0:
                 # K-quant rows are re-laid inside their own bytes at upload (plane layout, csrc/pkv_wlayout.h; the reference's CPU backend repacks on
                 # set_tensor too, /root/reference/ggml/src/ggml-cpu/ggml-cpu-aarch64.cpp:4145-4172): same integers, same results, coalesced streaming
                 w, t = weights_pack(w, t, ne[1], ne[0]), t | PACKED
@@ -111,9 +112,12 @@ class LlamaDecoder:
         return n
 
     # ---- products ------------------------------------------------------------------------------------------------------------
-    def _kq(self, names) -> bool:
-        return (all((self.w[n][1] & ~PACKED) in _KQ for n in names) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
-                and len({self.w[n][1] & PACKED for n in names}) == 1)
+    def _kq(self, names, silu=False) -> bool:
+        ts = [self.w[n][1] for n in names]
+        if silu and len({(t & ~PACKED) == Q5_K for t in ts}) != 1:      # SiLU(gate) * up in one launch: both q5_K or neither
+            return False
+        return (all((t & ~PACKED) in _KQ for t in ts) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
+                and len({t & PACKED for t in ts if (t & ~PACKED) != Q5_K}) <= 1)
 
     def _products(self, names, outs, x_f32, *, norm=None, residual=None, silu=False, image=None):
         """outs[i] = W_i x' (+ residual | SwiGLU) with x' = x, or rms_norm(x) * norm weights: ONE pkv_gemv_q launch for K-quant rows (the column is
@@ -121,7 +125,7 @@ class LlamaDecoder:
         ws = [self.w[n] for n in names]
         K = ws[0][2][0]
         nw = self.w[norm][0].view(self.torch.float32) if norm is not None else None
-        if self._kq(names) and (nw is None or K <= 8192):
+        if self._kq(names, silu) and (nw is None or K <= 8192):
             # image: the column as the q8_K activation image its producer left (the attention merge launch: pkv_attn_args::out_image)
             gemv_q([w[0] for w in ws], [w[1] for w in ws], [w[2][1] for w in ws], K, image if nw is None else None, outs, residual=residual, silu_mul=silu,
                    x=x_f32, norm_w=nw, eps=self.eps)

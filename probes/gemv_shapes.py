@@ -34,12 +34,20 @@ SHAPES = [  # name, [(type, M)], K, norm, residual, silu
     ("down q6_K (+residual)", [(14, 4096)], 14336, False, True, False),
     ("lm_head q6_K (norm)", [(14, 128256)], 4096, True, False, False),
 ]
+SHAPES_Q5 = [  # --q5: the same layer in the tensor mix of a Q5_K_M file (block_q5_K rows stay in GGUF order: no packed arm for them)
+    ("wq+wk+wv q5_K (norm)", [(13, 4096), (13, 1024), (13, 1024)], 4096, True, False, False),
+    ("wq+wk q5_K + wv q6_K (norm; two launches)", [(13, 4096), (13, 1024), (14, 1024)], 4096, True, False, False),
+    ("wo q5_K (+residual)", [(13, 4096)], 4096, False, True, False),
+    ("gate+up q5_K (norm, SwiGLU)", [(13, 14336), (13, 14336)], 4096, True, False, True),
+    ("down q5_K (+residual)", [(13, 4096)], 14336, False, True, False),
+]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", nargs="*", default=[]); ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--hot", type=int, default=0, help="cycle through only this many weight buffers (1-2: the weights stay in the 256 MiB Infinity Cache): what a product would take if its weights had been prefetched")
+    ap.add_argument("--q5", action="store_true", help="the q5_K shapes instead")
     ap.add_argument("--packed", action="store_true", help="second arm: the same library on plane-layout rows (type | PKV_TYPE_PACKED; random bytes, timing only)")
     a = ap.parse_args()
     mods = {"this tree": load_pkg("pkv_a", None)}
@@ -53,8 +61,8 @@ def main():
     dev = torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(1)
     st = torch.cuda.Stream()
-    rs = {12: 144, 14: 210}
-    for name, mats, K, norm, resid, silu in SHAPES:
+    rs = {12: 144, 13: 176, 14: 210}
+    for name, mats, K, norm, resid, silu in (SHAPES_Q5 if a.q5 else SHAPES):
         nbytes = sum(M * (K // 256) * rs[t] for t, M in mats)
         n_buf = max(2, min(32, int(600e6 // nbytes) + 1))
         if a.hot: n_buf = a.hot
@@ -72,11 +80,11 @@ def main():
                     for i in range(n_launch):
                         w = ws[i % n_buf]
                         if silu:
-                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], silu_mul=True, x=x, norm_w=nw, eps=1e-5)
+                            m.gemv_q(w, [t | (fl if t != 13 else 0) for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], silu_mul=True, x=x, norm_w=nw, eps=1e-5)
                         elif resid:
-                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], residual=outs[0], x=x)
+                            m.gemv_q(w, [t | (fl if t != 13 else 0) for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], residual=outs[0], x=x)
                         else:
-                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, outs, x=x, norm_w=nw, eps=1e-5)
+                            m.gemv_q(w, [t | (fl if t != 13 else 0) for t, _ in mats], [M for _, M in mats], K, None, outs, x=x, norm_w=nw, eps=1e-5)
                 run(); torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st):

@@ -102,3 +102,60 @@ def test_weight_types_and_bytes(pkv, model_path):
     total = sum(t.numel() for n, (t, _, _) in d.w.items())
     assert 0 < d.weight_bytes() < total
     d.close()
+
+
+def _q8k_round(x):
+    """the activation column as the products see it: quantize_row_q8_K per 256 elements, back in f64"""
+    xb = np.asarray(x, np.float32).reshape(-1, 256)
+    mx = xb[np.arange(len(xb)), np.abs(xb).argmax(-1)]
+    isc = np.where(mx != 0, np.float32(-127.0) / np.where(mx != 0, mx, 1).astype(np.float32), 0).astype(np.float32)
+    q = np.rint((isc[:, None] * xb).astype(np.float32))
+    d = np.where(mx != 0, np.float32(1.0) / np.where(mx != 0, isc, 1).astype(np.float32), 0).astype(np.float64)
+    return (d[:, None] * q).reshape(-1)
+
+
+@pytest.mark.parametrize("wtype,k_mix", [(13, True), (13, False)])
+def test_q5_K_model_first_token_against_exact_arithmetic(pkv, tmp_path, wtype, k_mix):
+    """the tensor mix of a Q5_K_M file (block_q5_K + block_q6_K; r03: q5_K rows in the decode-step products, MODE 13 of csrc/pkv_gemv.hip, the wq / wk / wv
+    group as one launch per run of like rows) through the own host loop: with ONE cell in the cache attention is the identity on V, so the step is a chain
+    of products this test restates in f64 on the numpy-dequantized weights (dequantizers bit-equal to the reference's, tests/test_gguf.py) with each
+    activation column rounded to the reference's q8_K integers — the logits must agree to f32-accumulation noise, eagerly and as a captured graph"""
+    from llama_cpp_test_amd import gguf_synth as G
+    from llama_cpp_test_amd.decoder import LlamaDecoder
+    cfg = dict(n_layer=3, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=256, n_ctx=256, rope_freq_base=500000.0, seed=90 + k_mix)
+    path = str(tmp_path / "q5.gguf")
+    G.synth_llama(path, wtype=wtype, k_mix=k_mix, **cfg)
+    _, tensors, _ = G.read_gguf(path)
+
+    def W(name):
+        ne, t, _, data = tensors[name]
+        t, raw = int(t), bytes(data)
+        if t == 0:
+            return np.frombuffer(raw, np.float32).astype(np.float64)
+        deq = {12: G.dequantize_q4_K, 13: G.dequantize_q5_K, 14: G.dequantize_q6_K}[t]
+        return np.asarray(deq(raw, int(ne[0])), np.float64).reshape(int(ne[1]), int(ne[0]))
+    types = {int(tensors[n][1]) for n in tensors if n.endswith("weight") and len(tensors[n][0]) == 2}
+    assert types == ({13, 14} if k_mix else {13})
+    eps, tok = 1e-5, 7
+    E, H, HK, D = cfg["n_embd"], cfg["n_head"], cfg["n_head_kv"], cfg["n_embd"] // cfg["n_head"]
+    rms = lambda x, w: x / np.sqrt((x * x).mean() + eps) * w     # noqa: E731
+    h = W("token_embd.weight")[tok].astype(np.float32).astype(np.float64)
+    for il in range(cfg["n_layer"]):
+        p = f"blk.{il}."
+        xn = _q8k_round(rms(h, W(p + "attn_norm.weight")))
+        v = (W(p + "attn_v.weight") @ xn).astype(np.float32).astype(np.float16).astype(np.float64)        # through the f16 cache
+        attn = np.repeat(v.reshape(HK, D), H // HK, axis=0).reshape(-1)                                     # one cell: softmax == 1
+        h = h + W(p + "attn_output.weight") @ _q8k_round(attn)
+        xf = _q8k_round(rms(h, W(p + "ffn_norm.weight")))
+        g_, u_ = W(p + "ffn_gate.weight") @ xf, W(p + "ffn_up.weight") @ xf
+        h = h + W(p + "ffn_down.weight") @ _q8k_round(g_ / (1 + np.exp(-g_)) * u_)
+    want = W("output.weight") @ _q8k_round(rms(h, W("output_norm.weight")))
+    d = LlamaDecoder(path, n_ctx=256)
+    assert {t & ~pkv.PACKED for (_, t, ne) in d.w.values() if len(ne) == 2} == types and d.w["blk.0.attn_q.weight"][1] == pkv.Q5_K     # q5_K rows stay in GGUF order
+    got = d.eval(tok, 0).cpu().numpy().copy()
+    # (a value that lands on a rounding boundary of the NEXT column's q8_K image may flip one integer against the f64 chain: 1e-5 leaves room for that)
+    assert nmse(got, want) <= 1e-5 and int(np.argmax(got)) == int(np.argmax(want))
+    d.capture()
+    d.cache.seq_rm(0, 0, -1)
+    assert np.array_equal(d.eval(tok, 0).cpu().numpy(), got)
+    d.close()
