@@ -642,7 +642,7 @@ def gemv_q(ws, types, Ms, K: int, image, outs, *, residual=None, silu_mul: bool 
 
 
 def weights_pack(w, type_w: int, n_rows: int, K: int, *, inverse: bool = False, out=None, stream=None):
-    """pkv_weights_pack: GGUF-order q4_K / q6_K rows (device bytes) -> the plane layout the decode-step products stream (`type | PACKED`), or back
+    """pkv_weights_pack: GGUF-order q4_K / q5_K / q6_K rows (device bytes) -> the plane layout the decode-step products stream (`type | PACKED`), or back
     (inverse=True, byte-exact).  Returns a new device byte tensor."""
     import torch
     out = torch.empty_like(w) if out is None else out
@@ -687,7 +687,24 @@ def pack_rows_host(rows: np.ndarray, type_w: int, K: int, inverse: bool = False)
         d = rows[:, 52 * gpr:].reshape(n, nb, 2)
         ql = np.concatenate([la, lb], axis=3).reshape(n, nb, 128)
         return np.concatenate([ql, hh, sc, d], axis=2).reshape(n, nb * 210)
-    raise ValueError("pack_rows_host: q4_K / q6_K only")
+    if type_w == Q5_K:
+        if not inverse:
+            blk = rows.reshape(n, nb, 176)
+            hdr = blk[:, :, :16].reshape(n, nb * 16)
+            ha = blk[:, :, 16:32].reshape(n, nb * 16)
+            hb = blk[:, :, 32:48].reshape(n, nb * 16)
+            qs = blk[:, :, 48:].reshape(n, nb, 4, 2, 16)                    # [block][p][half][16]
+            qa = qs[:, :, :, 0, :].reshape(n, gpr * 16)
+            qb = qs[:, :, :, 1, :].reshape(n, gpr * 16)
+            return np.concatenate([qa, qb, ha, hb, hdr], axis=1)
+        qa = rows[:, :16 * gpr].reshape(n, nb, 4, 1, 16)
+        qb = rows[:, 16 * gpr:32 * gpr].reshape(n, nb, 4, 1, 16)
+        ha = rows[:, 32 * gpr:36 * gpr].reshape(n, nb, 16)
+        hb = rows[:, 36 * gpr:40 * gpr].reshape(n, nb, 16)
+        hdr = rows[:, 40 * gpr:].reshape(n, nb, 16)
+        qs = np.concatenate([qa, qb], axis=3).reshape(n, nb, 128)
+        return np.concatenate([hdr, ha, hb, qs], axis=2).reshape(n, nb * 176)
+    raise ValueError("pack_rows_host: q4_K / q5_K / q6_K only")
 
 
 def get_rows(w, type_w: int, ids, K: int, n_rows_w: int, out=None, stream=None):

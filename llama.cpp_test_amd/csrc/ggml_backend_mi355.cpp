@@ -168,7 +168,7 @@ void in_place_rows(kv_mirror * m, size_t off, size_t n, void * host, bool to_poo
 // ---- K-quant weights in the plane layout ------------------------------------------------------------------------------------
 bool packable(const ggml_tensor * t) {
     static const bool off = getenv("GGML_MI355_NO_PACK") != nullptr;
-    return !off && !t->view_src && t->buffer && t->buffer->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS && (t->type == GGML_TYPE_Q4_K || t->type == GGML_TYPE_Q6_K) &&
+    return !off && !t->view_src && t->buffer && t->buffer->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS && (t->type == GGML_TYPE_Q4_K || t->type == GGML_TYPE_Q5_K || t->type == GGML_TYPE_Q6_K) &&
            ggml_is_contiguous(t) && t->ne[0] % 256 == 0;
 }
 // the packed weight tensor `t` is (a row-aligned view of), or NULL
@@ -880,14 +880,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
             // and the epilogue node reads or writes (those nodes run AFTER the fused launch): ggml-alloc's in-place placement of today's llama graphs is safe, a
             // graph cut by cb_eval / OUTPUT flags / adapters need not be
             bool wtype_uniform = true;                       // one launch = one row layout (plane-layout weights of a WEIGHTS buffer and GGUF-order ones do not mix)
-            {   // (q5_K rows have no plane layout and run as a launch of their own inside pkv_gemv_q: they do not take part in the comparison)
-                int pk0 = -1;
-                for (int q = 0; q < np; ++q) {
-                    const int tq = (int) wtype(ggml_graph_node(g, prod[q])->src[0]);
-                    if ((tq & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K) continue;
-                    if (pk0 < 0) pk0 = tq & PKV_TYPE_PACKED; else wtype_uniform = wtype_uniform && (tq & PKV_TYPE_PACKED) == pk0;
-                }
-            }
+            for (int q = 1; q < np; ++q) wtype_uniform = wtype_uniform && (wtype(ggml_graph_node(g, prod[q])->src[0]) & PKV_TYPE_PACKED) == (wtype(ggml_graph_node(g, prod[0])->src[0]) & PKV_TYPE_PACKED);
             if (!wtype_uniform) ok = false;
             auto early_ok = [&](const ggml_tensor * out, int last_idx, std::initializer_list<int> chain) {
                 if (overlaps(out, xsrc) || (nw && (overlaps(out, nw) || overlaps(out, n) || overlaps(out, col)))) return false;

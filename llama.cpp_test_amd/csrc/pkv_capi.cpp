@@ -597,7 +597,7 @@ int pkv_soft_max_ext_f32(const float * x, const void * mask, int mask_f16, float
     PKV_REQUIRE(x && y && ne00 > 0 && ne01 >= 0 && ne02 > 0 && ne03 > 0 && max_bias >= 0.0f, "pkv_soft_max_ext_f32: bad arguments");
     return launch_soft_max(x, mask, mask_f16, y, ne00, ne01, ne02, ne03, scale, max_bias, (hipStream_t) stream);
 }
-static bool packed_type_ok(int type_w) { const int bt = type_w & ~PKV_TYPE_PACKED; return type_w == bt || bt == PKV_TYPE_Q4_K || bt == PKV_TYPE_Q6_K; }
+static bool packed_type_ok(int type_w) { const int bt = type_w & ~PKV_TYPE_PACKED; return type_w == bt || bt == PKV_TYPE_Q4_K || bt == PKV_TYPE_Q5_K || bt == PKV_TYPE_Q6_K; }
 int pkv_mul_mat(const void * w, int type_wf, const float * x, float * y, int64_t M, int64_t K, int64_t n_cols, void * stream) {
     if (int rc = ensure_device()) return rc;
     PKV_REQUIRE(w && x && y && M >= 0 && K > 0 && n_cols >= 0 && packed_type_ok(type_wf), "pkv_mul_mat: bad arguments");

@@ -95,6 +95,11 @@ template <> struct RawW<PKV_TYPE_Q5_K> {   // block_q5_K (:291-308): header {d, 
         for (int i = 0; i < 32; ++i) o[i] = (_Float16) (d1 * (float) (((b[i] >> s4) & 0xF) | (((hb[i] >> j) & 1) << 4)) - m1);
     }
 };
+template <> struct RawW<(PKV_TYPE_Q5_K | PKV_TYPE_PACKED)> : RawW<PKV_TYPE_Q5_K> {   // planes of pkv_wlayout.h: qa, qb per group; ha, hb, header per block
+    __device__ __forceinline__ void load(const unsigned char * row, int64_t k0, int64_t K) { const size_t gpr = (size_t) (K >> 6), g = (size_t) (k0 >> 6);
+        h = ldu(row + 40 * gpr + 16 * (g >> 2)); qh[0] = ldu(row + 32 * gpr + 16 * (g >> 2)); qh[1] = ldu(row + 36 * gpr + 16 * (g >> 2));
+        q[0] = ldu(row + 16 * g); q[1] = ldu(row + 16 * gpr + 16 * g); }
+};
 template <> struct RawW<PKV_TYPE_Q6_K> {   // block_q6_K (:309-319): e0 = k0 % 256, n = e0 / 128, j = (e0 % 128) / 32: ql[64 n + 32 (j & 1) + l] nibble j >> 1, qh[32 n + l] bits 2 j
     static constexpr int NLOADS = 6;
     uint4 ql[2], qh[2]; uint16_t sc2, d;
@@ -285,6 +290,8 @@ template <> struct Deq<PKV_TYPE_Q5_K> { static __device__ __forceinline__ void r
 #pragma unroll
     for (int i = 0; i < 8; ++i) cvt4(((q[i] >> s4) & 0x0F0F0F0Fu) | (((hh[i] >> j) & 0x01010101u) << 4), nb, d1, m1, ow[2 * i], ow[2 * i + 1]);   // 5-bit quants 0..31
 } };
+template <> struct Deq<(PKV_TYPE_Q5_K | PKV_TYPE_PACKED)> { static __device__ __forceinline__ void run(const RawW<(PKV_TYPE_Q5_K | PKV_TYPE_PACKED)> & w, int64_t k0, uint4 * o) {
+    Deq<PKV_TYPE_Q5_K>::run(w, k0, o); } };
 template <> struct Deq<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> { static __device__ __forceinline__ void run(const RawW<(PKV_TYPE_Q4_K | PKV_TYPE_PACKED)> & w, int64_t k0, uint4 * o) {
     Deq<PKV_TYPE_Q4_K>::run(w, k0, o); } };
 template <> struct Deq<PKV_TYPE_Q6_K> { static __device__ __forceinline__ void run(const RawW<PKV_TYPE_Q6_K> & w, int64_t k0, uint4 * o) {
@@ -791,6 +798,7 @@ int launch_gemm2(GemmArgs & a, int type_w, int64_t n_cols, hipStream_t st, bool 
         case PKV_TYPE_Q5_K: PKV_GEMM2(PKV_TYPE_Q5_K); break;
         case PKV_TYPE_Q6_K: PKV_GEMM2(PKV_TYPE_Q6_K); break;
         case PKV_TYPE_Q4_K | PKV_TYPE_PACKED: PKV_GEMM2((PKV_TYPE_Q4_K | PKV_TYPE_PACKED)); break;
+        case PKV_TYPE_Q5_K | PKV_TYPE_PACKED: PKV_GEMM2((PKV_TYPE_Q5_K | PKV_TYPE_PACKED)); break;
         case PKV_TYPE_Q6_K | PKV_TYPE_PACKED: PKV_GEMM2((PKV_TYPE_Q6_K | PKV_TYPE_PACKED)); break;
         default: return PKV_OK;
     }
@@ -853,6 +861,7 @@ int launch_gemm_multi(int n, const void * const * w, int type_w, const float * x
         case PKV_TYPE_Q5_K: PKV_GEMM(PKV_TYPE_Q5_K); break;
         case PKV_TYPE_Q6_K: PKV_GEMM(PKV_TYPE_Q6_K); break;
         case PKV_TYPE_Q4_K | PKV_TYPE_PACKED: PKV_GEMM((PKV_TYPE_Q4_K | PKV_TYPE_PACKED)); break;
+        case PKV_TYPE_Q5_K | PKV_TYPE_PACKED: PKV_GEMM((PKV_TYPE_Q5_K | PKV_TYPE_PACKED)); break;
         case PKV_TYPE_Q6_K | PKV_TYPE_PACKED: PKV_GEMM((PKV_TYPE_Q6_K | PKV_TYPE_PACKED)); break;
     }
 #undef PKV_GEMM

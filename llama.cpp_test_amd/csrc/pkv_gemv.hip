@@ -215,7 +215,7 @@ __device__ __forceinline__ float wsum_dpp(float x) {
 }
 
 // One unit of a wave's work = 128 (row, 64-element group) items of a row pair: the lane's items u = 0, 1.  Its loads (MODE 12: q4_K rows
-// only, 3 x 16 bytes per item; MODE 13: q5_K only, GGUF order, 5 x 16; MODE 14: q6_K only, 4 x 16 + 2; MODE 0: any mix of q4_K / q6_K, the q6_K shape for every lane so that the number of loads
+// only, 3 x 16 bytes per item; MODE 13: q5_K only, 5 x 16; MODE 14: q6_K only, 4 x 16 + 2; MODE 0: any mix of q4_K / q6_K, the q6_K shape for every lane so that the number of loads
 // in flight does not depend on the lane's type — a q4_K lane re-reads its header) are issued TWO units ahead of the dots that consume them.
 // Plain named registers per pipeline stage (a struct handed to lambdas by reference ended up in scratch memory: 368 bytes per lane and
 // every weight load doubled by a scratch store — rocprofv3 Scratch_Size column).
@@ -263,6 +263,13 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
             if constexpr (PK) {   /* plane layout (pkv_wlayout.h): lane-consecutive items = consecutive 16 bytes of each plane */              \
                 const bool k4 = MODE == PKV_TYPE_Q4_K || (MODE == 0 && S##ty[u] == PKV_TYPE_Q4_K);                                             \
                 const unsigned char * it_ = rw_ + 16 * ga_, * bl_ = rw_ + 16 * (ga_ >> 2);                                                           \
+                if (MODE == PKV_TYPE_Q5_K) {   /* planes: qa, qb per item; ha, hb, header per block */                                          \
+                    S##r0[u] = ld16w<NTL>(bl_ + 40 * gpr);                                                                                     \
+                    S##r1[u] = ld16w<NTL>(it_);                                                                                                \
+                    S##r2[u] = ld16w<NTL>(it_ + 16 * gpr);                                                                                     \
+                    S##r3[u] = ld16w<NTL>(bl_ + 32 * gpr);                                                                                     \
+                    S##r4[u] = ld16w<NTL>(bl_ + 36 * gpr); S##dh[u] = 0;                                                                       \
+                } else                                                                                                                         \
                 if (MODE == PKV_TYPE_Q4_K) {                                                                                                   \
                     S##r0[u] = ld16w<NTL>(bl_ + 32 * gpr);                                                                                     \
                     S##r1[u] = ld16w<NTL>(it_);                                                                                                \
@@ -597,7 +604,7 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict
 template <int T, bool PK = false>
 __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int32_t * ids, float * out, int64_t K, int64_t n_rows_w) {
     const int gpr = (int) (K >> 6);
-    auto pk = [&](size_t o) -> size_t { if constexpr (!PK) return o; else return T == PKV_TYPE_Q4_K ? pk_offset_q4k(gpr, o) : pk_offset_q6k(gpr, o); };
+    auto pk = [&](size_t o) -> size_t { if constexpr (!PK) return o; else return T == PKV_TYPE_Q4_K ? pk_offset_q4k(gpr, o) : (T == PKV_TYPE_Q5_K ? pk_offset_q5k(gpr, o) : pk_offset_q6k(gpr, o)); };
     const int64_t r = ids[blockIdx.x];
     float * o = out + (size_t) blockIdx.x * K;
     if (r < 0 || r >= n_rows_w) { for (int64_t k = threadIdx.x; k < K; k += 256) o[k] = 0.0f; return; }
@@ -627,15 +634,15 @@ __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int
         }
     } else if constexpr (T == PKV_TYPE_Q5_K) {      // dequantize_row_q5_K (:1482-1507)
         for (int64_t k = threadIdx.x; k < K; k += 256) {
-            const unsigned char * b = row + (size_t) (k >> 8) * 176;
+            const size_t b = (size_t) (k >> 8) * 176;                       // GGUF-order offset of the block inside the row
             const int e = (int) (k & 255), j = e >> 5, l = e & 31;
-            const float d = h2f(*reinterpret_cast<const uint16_t *>(b)), dmin = h2f(*reinterpret_cast<const uint16_t *>(b + 2));
-            auto s = [&](int i) -> int { return (int) b[4 + i]; };
+            const float d = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b))), dmin = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b + 2)));
+            auto s = [&](int i) -> int { return (int) row[pk(b + 4 + i)]; };
             int sc, mn;
             if (j < 4) { sc = s(j) & 63; mn = s(j + 4) & 63; }
             else       { sc = (s(j + 4) & 0xF) | ((s(j - 4) >> 6) << 4); mn = (s(j + 4) >> 4) | ((s(j) >> 6) << 4); }
-            const unsigned char qb = b[48 + 32 * (j >> 1) + l];
-            const int q = ((j & 1) ? (qb >> 4) : (qb & 0xF)) + (((b[16 + l] >> j) & 1) ? 16 : 0);
+            const unsigned char qb = row[pk(b + 48 + 32 * (j >> 1) + l)];
+            const int q = ((j & 1) ? (qb >> 4) : (qb & 0xF)) + (((row[pk(b + 16 + l)] >> j) & 1) ? 16 : 0);
             const float d1 = d * (float) sc, m1 = dmin * (float) mn;
             o[k] = d1 * (float) q - m1;
         }
@@ -660,7 +667,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const uint16_t * src, ui
     const int64_t rb2 = (int64_t) (row_size(T, K) >> 1), n = n_rows * rb2;
     for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
         const int64_t r = i / rb2, o = (i - r * rb2) * 2;
-        const int64_t po = (int64_t) (T == PKV_TYPE_Q4_K ? pk_offset_q4k(gpr, (size_t) o) : pk_offset_q6k(gpr, (size_t) o));
+        const int64_t po = (int64_t) (T == PKV_TYPE_Q4_K ? pk_offset_q4k(gpr, (size_t) o) : (T == PKV_TYPE_Q5_K ? pk_offset_q5k(gpr, (size_t) o) : pk_offset_q6k(gpr, (size_t) o)));
         if (inverse) dst[i] = src[r * rb2 + (po >> 1)];
         else         dst[r * rb2 + (po >> 1)] = src[i];
     }
@@ -670,12 +677,13 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const uint16_t * src, ui
 
 int launch_pack_rows(const void * src, void * dst, int type, int64_t n_rows, int64_t K, int inverse, hipStream_t st) {
     PKV_REQUIRE(src && dst && src != dst && n_rows >= 0 && K > 0 && K % 256 == 0, "pkv_weights_pack: bad arguments (src != dst, K %% 256 == 0)");
-    PKV_REQUIRE(type == PKV_TYPE_Q4_K || type == PKV_TYPE_Q6_K, "pkv_weights_pack: q4_K / q6_K rows only");
+    PKV_REQUIRE(type == PKV_TYPE_Q4_K || type == PKV_TYPE_Q5_K || type == PKV_TYPE_Q6_K, "pkv_weights_pack: q4_K / q5_K / q6_K rows only");
     PKV_REQUIRE(((uintptr_t) src % 2) == 0 && ((uintptr_t) dst % 2) == 0, "pkv_weights_pack: 2-byte aligned pointers");
     if (n_rows == 0) return PKV_OK;
     const int64_t n = n_rows * (int64_t) (row_size(type, K) >> 1);
     const unsigned grid = (unsigned) std::min<int64_t>((n + 255) / 256, 1 << 16);
     if (type == PKV_TYPE_Q4_K) hipLaunchKernelGGL(pack_rows_kernel<PKV_TYPE_Q4_K>, dim3(grid), dim3(256), 0, st, (const uint16_t *) src, (uint16_t *) dst, n_rows, K, inverse);
+    else if (type == PKV_TYPE_Q5_K) hipLaunchKernelGGL(pack_rows_kernel<PKV_TYPE_Q5_K>, dim3(grid), dim3(256), 0, st, (const uint16_t *) src, (uint16_t *) dst, n_rows, K, inverse);
     else                       hipLaunchKernelGGL(pack_rows_kernel<PKV_TYPE_Q6_K>, dim3(grid), dim3(256), 0, st, (const uint16_t *) src, (uint16_t *) dst, n_rows, K, inverse);
     PKV_HIP(hipGetLastError());
     return PKV_OK;
@@ -696,21 +704,17 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
                 "pkv_gemv_q: in-kernel column: x (and norm_w) 16-byte aligned, K <= 8192 with a norm");
     PKV_REQUIRE(!g.silu_mul || (g.n == 2 && g.M[0] == g.M[1] && !g.residual), "pkv_gemv_q: silu_mul needs two products of equal M and no residual");
     PKV_REQUIRE(!g.residual || g.n == 1, "pkv_gemv_q: the residual epilogue takes one product");
-    // block_q5_K rows (what a Q5_K_M file holds beside its q6_K tensors): a launch of their own (MODE 13, GGUF order — a 64-element group's fifth
-    // bits are spread over the block's 32 bytes of qh, so there is no byte permutation into planes); a group that mixes them with other types
-    // (wq / wk q5_K + wv q6_K) goes out as one launch per run of like rows: the in-kernel column (norm included) is the same bits in each.
+    // block_q5_K rows (what a Q5_K_M file holds beside its q6_K tensors): a launch of their own (MODE 13: five 16-byte loads per 64-element group —
+    // the q4_K three plus the block's 32 bytes of fifth bits); a group that mixes them with other types (wq / wk q5_K + wv q6_K) goes out as one
+    // launch per run of like rows: the in-kernel column (norm included) is the same bits in each.
     {
         bool any5 = false, all5 = true;
         for (int i = 0; i < g.n; ++i) { const bool q5 = (g.type_w[i] & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K; any5 = any5 || q5; all5 = all5 && q5; }
-        if (any5) {
-            for (int i = 0; i < g.n; ++i)
-                if (g.type_w[i] == (PKV_TYPE_Q5_K | PKV_TYPE_PACKED)) { set_error("pkv_gemv_q: q5_K rows have no plane layout"); return PKV_ERR_UNSUPPORTED; }
-        }
         if (any5 && !all5) {
             if (g.silu_mul) { set_error("pkv_gemv_q: silu_mul over q5_K and another row type"); return PKV_ERR_UNSUPPORTED; }
             for (int i0 = 0; i0 < g.n; ) {
                 int i1 = i0 + 1;
-                while (i1 < g.n && (g.type_w[i1] == PKV_TYPE_Q5_K) == (g.type_w[i0] == PKV_TYPE_Q5_K)) ++i1;
+                while (i1 < g.n && ((g.type_w[i1] & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K) == ((g.type_w[i0] & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K)) ++i1;
                 pkv_gemv s = g;
                 s.n = i1 - i0;
                 for (int k = 0; k < s.n; ++k) { s.type_w[k] = g.type_w[i0 + k]; s.w[k] = g.w[i0 + k]; s.y[k] = g.y[i0 + k]; s.M[k] = g.M[i0 + k]; }
@@ -765,7 +769,7 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
 #define PKV_GEMV_PICK_W(MODE_, PK_) do { if (split) PKV_GEMV_PICK_S(MODE_, 16, 2, PK_); else if (nwv == 16) PKV_GEMV_PICK_S(MODE_, 16, 1, PK_); else if (nwv == 8) PKV_GEMV_PICK_S(MODE_, 8, 1, PK_); else PKV_GEMV_PICK_S(MODE_, 4, 1, PK_); } while (0)
 #define PKV_GEMV_PICK_P(MODE_) do { if (packed) PKV_GEMV_PICK_W(MODE_, true); else PKV_GEMV_PICK_W(MODE_, false); } while (0)
     if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_P(PKV_TYPE_Q4_K);
-    else if (mode == PKV_TYPE_Q5_K) PKV_GEMV_PICK_W(PKV_TYPE_Q5_K, false);
+    else if (mode == PKV_TYPE_Q5_K) PKV_GEMV_PICK_P(PKV_TYPE_Q5_K);
     else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_P(PKV_TYPE_Q6_K);
     else                            PKV_GEMV_PICK_P(0);
     PKV_HIP(hipGetLastError());
@@ -776,6 +780,7 @@ int launch_get_rows(const void * w, int type_w, const int32_t * ids, float * out
     if (n_ids == 0) return PKV_OK;
     const dim3 grid((unsigned) n_ids);
     if (type_w == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q4_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
+    if (type_w == (PKV_TYPE_Q5_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q5_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
     if (type_w == (PKV_TYPE_Q6_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q6_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
     switch (type_w) {
         case PKV_TYPE_F32:  hipLaunchKernelGGL(get_rows_kernel<PKV_TYPE_F32>, grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); break;

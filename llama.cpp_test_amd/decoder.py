@@ -29,7 +29,6 @@ from . import (F16, Q4_K, Q5_K, Q6_K, PACKED, act_image, weights_pack, PagedKVCa
 from .gguf_synth import read_gguf, row_bytes
 
 _KQ = (Q4_K, Q5_K, Q6_K)    # row types of the decode-step products (pkv_gemv_q)
-_PK = (Q4_K, Q6_K)          # ... of them, the ones with a plane layout (a q5_K row's fifth bits do not separate by bytes)
 
 
 class LlamaDecoder:
@@ -53,7 +52,7 @@ class LlamaDecoder:
             ne, t, _, data = tensors[name]
             w = torch.from_numpy(np.array(data)).to(dev)                    # a copy: the file map is read-only
             ne, t = tuple(int(x) for x in ne), int(t)
-            if pack_weights and t in _PK and len(ne) == 2 and ne[0] % 256 == 0:
+            if pack_weights and t in _KQ and len(ne) == 2 and ne[0] % 256 == 0:
                 # K-quant rows are re-laid inside their own bytes at upload (plane layout, csrc/pkv_wlayout.h; the reference's CPU backend repacks on
                 # set_tensor too, /root/reference/ggml/src/ggml-cpu/ggml-cpu-aarch64.cpp:4145-4172): same integers, same results, coalesced streaming
                 w, t = weights_pack(w, t, ne[1], ne[0]), t | PACKED
@@ -117,7 +116,7 @@ class LlamaDecoder:
         if silu and len({(t & ~PACKED) == Q5_K for t in ts}) != 1:      # SiLU(gate) * up in one launch: both q5_K or neither
             return False
         return (all((t & ~PACKED) in _KQ for t in ts) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
-                and len({t & PACKED for t in ts if (t & ~PACKED) != Q5_K}) <= 1)
+                and len({t & PACKED for t in ts}) == 1)
 
     def _products(self, names, outs, x_f32, *, norm=None, residual=None, silu=False, image=None):
         """outs[i] = W_i x' (+ residual | SwiGLU) with x' = x, or rms_norm(x) * norm weights: ONE pkv_gemv_q launch for K-quant rows (the column is
