@@ -49,7 +49,7 @@ extern "C" {
 /* values follow enum ggml_type (/ref/ggml/include/ggml.h:351-360) */
 enum pkv_type { PKV_TYPE_F32 = 0, PKV_TYPE_F16 = 1, PKV_TYPE_Q4_0 = 2, PKV_TYPE_Q8_0 = 8,
                 PKV_TYPE_Q4_K = 12, /* weights of pkv_mul_mat / pkv_gemv_q only (block_q4_K, /ref/ggml/src/ggml-common.h:279-290); not a KV type */
-                PKV_TYPE_Q5_K = 13, /* weights of pkv_mul_mat / pkv_gemv_q / pkv_get_rows (block_q5_K, :291-308; Q5_K_M files); GGUF order only (no plane layout)  */
+                PKV_TYPE_Q5_K = 13, /* weights of pkv_mul_mat / pkv_gemv_q / pkv_get_rows (block_q5_K, :291-308; Q5_K_M files); and (r03) a plane layout like the other two                  */
                 PKV_TYPE_Q6_K = 14, /* weights of pkv_gemv_q / pkv_get_rows only (block_q6_K, :309-319): what a Q4_K_M file mixes in          */
                 PKV_TYPE_BF16 = 30, /* K / V rows of pkv_flash_attn_ext_flat only (ggml_bf16_t, /ref/ggml/include/ggml.h:339-342): not a pool type */
                 /* the remaining cache types of /ref/common/arg.cpp:172-182 — flat rows only: pkv_convert_f32 (the KV store) and pkv_flash_attn_ext_flat */
@@ -443,8 +443,7 @@ int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x
  * pkv_gemv_q then streams the rows of up to three matrices that share the column in ONE launch (wq + wk + wv; gate + up), with the
  * epilogues a llama layer needs: y = residual + W x (attn_out / ffn_down onto the residual stream, :4120,:4160) or
  * y = silu(W0 x) * (W1 x) (LLM_FFN_SILU + LLM_FFN_PAR of build_ffn).  Rows are block_q4_K / block_q5_K / block_q6_K in the reference's format
- * (per matrix: a Q4_K_M / Q5_K_M file keeps attn_v / ffn_down / output in q6_K), K % 256 == 0, M even.  block_q5_K rows run as a launch of
- * their own kind (a group that mixes them with other rows is split into one launch per run of like rows; silu_mul needs both of one kind). */
+ * (per matrix: a Q4_K_M / Q5_K_M file keeps attn_v / ffn_down / output in q6_K), K % 256 == 0, M even; the matrices of one launch may differ in type. */
 #define PKV_GEMV_MAX 3
 typedef struct pkv_gemv {
     int32_t       n;                   /* products that share the activation image (1..PKV_GEMV_MAX)                          */
@@ -469,7 +468,7 @@ int pkv_rms_norm_mul_q(const float * x, const float * res, float * x_out, const 
 int pkv_gemv_q(const pkv_gemv * g, void * stream);
 /* PLANE layout of K-quant weight rows (csrc/pkv_wlayout.h): the same bytes re-laid INSIDE each row at upload so that a wave instruction of the
  * decode-step products reads 1 KiB of contiguous bytes per plane (q4_K row: [16 B of low-half nibbles per 64-element group][16 B of the other half]
- * [16-byte block headers]; q6_K row: [ql lo][ql hi][qh][scales][d]) — the GGUF block order puts every lane's load at a 144- / 210-byte stride.
+ * [16-byte block headers]; q5_K row: the same two planes, then [qh 0..15][qh 16..31][headers] per block; q6_K row: [ql lo][ql hi][qh][scales][d]) — the GGUF block order puts every lane's load at a 144- / 210-byte stride.
  * Precedent: the reference's CPU backend repacks weights on set_tensor (/ref/ggml/src/ggml-cpu/ggml-cpu-aarch64.cpp:3663-3810, :4145-4172).
  * A packed tensor is named by `type | PKV_TYPE_PACKED` in pkv_gemv.type_w[], pkv_mul_mat, pkv_mul_mat_multi and pkv_get_rows; results are bit-identical
  * to the GGUF-order tensor's.  pkv_weights_pack converts n_rows rows of K elements (src != dst; inverse = 1: back to GGUF order, byte-exact). */

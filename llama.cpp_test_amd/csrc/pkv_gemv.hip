@@ -215,7 +215,7 @@ __device__ __forceinline__ float wsum_dpp(float x) {
 }
 
 // One unit of a wave's work = 128 (row, 64-element group) items of a row pair: the lane's items u = 0, 1.  Its loads (MODE 12: q4_K rows
-// only, 3 x 16 bytes per item; MODE 13: q5_K only, 5 x 16; MODE 14: q6_K only, 4 x 16 + 2; MODE 0: any mix of q4_K / q6_K, the q6_K shape for every lane so that the number of loads
+// only, 3 x 16 bytes per item; MODE 13: q5_K only, 5 x 16; MODE 14: q6_K only, 4 x 16 + 2; MODE 1: any mix that holds q5_K rows (5 x 16 + 2 for every lane); MODE 0: any mix of q4_K / q6_K, the q6_K shape for every lane so that the number of loads
 // in flight does not depend on the lane's type — a q4_K lane re-reads its header) are issued TWO units ahead of the dots that consume them.
 // Plain named registers per pipeline stage (a struct handed to lambdas by reference ended up in scratch memory: 368 bytes per lane and
 // every weight load doubled by a scratch store — rocprofv3 Scratch_Size column).
@@ -257,12 +257,22 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
             S##rs[u] = fc >= gpr;                                                                                                              \
             S##g[u] = fc - S##rs[u] * gpr;                                                                                                     \
             S##p[u] = S##g[u] & 3;                                                                                                             \
-            S##ty[u] = MODE ? MODE : (S##rs[u] ? t1_ : t0_);                                                                                   \
+            S##ty[u] = MODE > 1 ? MODE : (S##rs[u] ? t1_ : t0_);                                                                               \
             const unsigned char * rw_ = reinterpret_cast<const unsigned char *>(S##rs[u] ? q1_ : q0_);                                         \
             const int ga_ = (PAST) ? 0 : S##g[u], pa_ = ga_ & 3;   /* a request past the wave's last unit: every lane the row's first 16 bytes (one line) */ \
             if constexpr (PK) {   /* plane layout (pkv_wlayout.h): lane-consecutive items = consecutive 16 bytes of each plane */              \
                 const bool k4 = MODE == PKV_TYPE_Q4_K || (MODE == 0 && S##ty[u] == PKV_TYPE_Q4_K);                                             \
                 const unsigned char * it_ = rw_ + 16 * ga_, * bl_ = rw_ + 16 * (ga_ >> 2);                                                           \
+                if (MODE == 1) {   /* any mix with q5_K rows: five loads + the 2-byte one for every lane (a q4_K / q6_K lane re-reads its header / scales) */ \
+                    const bool k4_ = S##ty[u] == PKV_TYPE_Q4_K, k5_ = S##ty[u] == PKV_TYPE_Q5_K, k45_ = k4_ || k5_;                             \
+                    const unsigned char * hd_ = bl_ + (k4_ ? 32 : (k5_ ? 40 : 48)) * gpr;   /* header plane (q6_K: the scale plane) */          \
+                    S##r0[u] = ld16w<NTL>(k45_ ? hd_ : it_);                                                                                   \
+                    S##r1[u] = ld16w<NTL>(k45_ ? it_ : it_ + 16 * gpr);                                                                        \
+                    S##r2[u] = ld16w<NTL>(k45_ ? it_ + 16 * gpr : it_ + 32 * gpr);                                                             \
+                    S##r3[u] = ld16w<NTL>(k5_ ? bl_ + 32 * gpr : hd_);                                                                         \
+                    S##r4[u] = ld16w<NTL>(k5_ ? bl_ + 36 * gpr : hd_);                                                                         \
+                    S##dh[u] = *reinterpret_cast<const uint16_t *>(k45_ ? hd_ : rw_ + 52 * gpr + 2 * (ga_ >> 2));                              \
+                } else                                                                                                                         \
                 if (MODE == PKV_TYPE_Q5_K) {   /* planes: qa, qb per item; ha, hb, header per block */                                          \
                     S##r0[u] = ld16w<NTL>(bl_ + 40 * gpr);                                                                                     \
                     S##r1[u] = ld16w<NTL>(it_);                                                                                                \
@@ -285,6 +295,15 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
             } else {                                                                                                                           \
             const unsigned char * bp = rw_ + (size_t) (ga_ >> 2) * (S##ty[u] == PKV_TYPE_Q4_K ? 144 : (S##ty[u] == PKV_TYPE_Q5_K ? 176 : 210));           \
             const int n_ = pa_ >> 1, is_ = pa_ & 1;                                                                                            \
+            if (MODE == 1) {                                                                                                                   \
+                const bool k4_ = S##ty[u] == PKV_TYPE_Q4_K, k5_ = S##ty[u] == PKV_TYPE_Q5_K, k45_ = k4_ || k5_;                                 \
+                S##r0[u] = ld16w<false>(bp + (k45_ ? 0 : 64 * n_ + 16 * is_));                                                                 \
+                S##r1[u] = ld16w<false>(bp + (k4_ ? 16 + 32 * pa_ : (k5_ ? 48 + 32 * pa_ : 64 * n_ + 16 * is_ + 32)));                         \
+                S##r2[u] = ld16w<false>(bp + (k4_ ? 32 + 32 * pa_ : (k5_ ? 64 + 32 * pa_ : 128 + 32 * n_ + 16 * is_)));                        \
+                S##r3[u] = ld16w<false>(bp + (k5_ ? 16 : (k4_ ? 0 : 192)));                                                                    \
+                S##r4[u] = ld16w<false>(bp + (k5_ ? 32 : (k4_ ? 0 : 192)));                                                                    \
+                S##dh[u] = *reinterpret_cast<const uint16_t *>(bp + (k45_ ? 0 : 208));                                                         \
+            } else                                                                                                                             \
             if (MODE == PKV_TYPE_Q5_K) {   /* header, the group's 32 bytes of nibbles, the block's 32 bytes of fifth bits (176 = 11 x 16: all aligned) */ \
                 S##r0[u] = ld16w<false>(bp);                                                                                                   \
                 S##r1[u] = ld16w<false>(bp + 48 + 32 * pa_    );                                                                               \
@@ -313,7 +332,7 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
         _Pragma("unroll") for (int u = 0; u < UI; ++u) {                                                                                        \
             float part;                                                                                                                        \
             if (PKV_GEMV_ABLATE == 1) { part = __uint_as_float((S##r0[u].x ^ S##r1[u].y ^ S##r2[u].z ^ S##r3[u].w ^ S##r1[u].w ^ S##r2[u].x) & 0x3fffffffu); } else \
-            if (MODE == PKV_TYPE_Q5_K) part = dot_q5k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##r4[u], S##p[u], sq + S##g[u] * REC);             \
+            if (MODE == PKV_TYPE_Q5_K || (MODE == 1 && S##ty[u] == PKV_TYPE_Q5_K)) part = dot_q5k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##r4[u], S##p[u], sq + S##g[u] * REC); \
             else if (S##ty[u] == PKV_TYPE_Q4_K) part = dot_q4k<TAIL>(S##r0[u], S##r1[u], S##r2[u], S##p[u], sq + S##g[u] * REC);                        \
             else part = dot_q6k(S##r0[u], S##r1[u], S##r2[u], S##r3[u], S##dh[u], S##p[u], sq + ((S##g[u] & ~3) + 2 * (S##p[u] >> 1)) * REC);            \
             if (!S##ok[u]) part = 0.0f;                                                                                                        \
@@ -704,26 +723,6 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
                 "pkv_gemv_q: in-kernel column: x (and norm_w) 16-byte aligned, K <= 8192 with a norm");
     PKV_REQUIRE(!g.silu_mul || (g.n == 2 && g.M[0] == g.M[1] && !g.residual), "pkv_gemv_q: silu_mul needs two products of equal M and no residual");
     PKV_REQUIRE(!g.residual || g.n == 1, "pkv_gemv_q: the residual epilogue takes one product");
-    // block_q5_K rows (what a Q5_K_M file holds beside its q6_K tensors): a launch of their own (MODE 13: five 16-byte loads per 64-element group —
-    // the q4_K three plus the block's 32 bytes of fifth bits); a group that mixes them with other types (wq / wk q5_K + wv q6_K) goes out as one
-    // launch per run of like rows: the in-kernel column (norm included) is the same bits in each.
-    {
-        bool any5 = false, all5 = true;
-        for (int i = 0; i < g.n; ++i) { const bool q5 = (g.type_w[i] & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K; any5 = any5 || q5; all5 = all5 && q5; }
-        if (any5 && !all5) {
-            if (g.silu_mul) { set_error("pkv_gemv_q: silu_mul over q5_K and another row type"); return PKV_ERR_UNSUPPORTED; }
-            for (int i0 = 0; i0 < g.n; ) {
-                int i1 = i0 + 1;
-                while (i1 < g.n && ((g.type_w[i1] & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K) == ((g.type_w[i0] & ~PKV_TYPE_PACKED) == PKV_TYPE_Q5_K)) ++i1;
-                pkv_gemv s = g;
-                s.n = i1 - i0;
-                for (int k = 0; k < s.n; ++k) { s.type_w[k] = g.type_w[i0 + k]; s.w[k] = g.w[i0 + k]; s.y[k] = g.y[i0 + k]; s.M[k] = g.M[i0 + k]; }
-                if (int rc = launch_gemv(s, st)) return rc;
-                i0 = i1;
-            }
-            return PKV_OK;
-        }
-    }
     GemvArgs a = {};
     int tot = 0;
     const bool packed = (g.type_w[0] & PKV_TYPE_PACKED) != 0;       // plane-layout rows (pkv_wlayout.h): all matrices of a launch, or none
@@ -749,7 +748,10 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     // one workgroup per CU; its wave count follows the row pairs there are (every wave one row pair at least where the product has them)
     bool all4 = true, all5 = true, all6 = true;
     for (int i = 0; i < g.n; ++i) { all4 = all4 && tw[i] == PKV_TYPE_Q4_K; all5 = all5 && tw[i] == PKV_TYPE_Q5_K; all6 = all6 && tw[i] == PKV_TYPE_Q6_K; }
-    const int mode = all4 ? PKV_TYPE_Q4_K : (all5 ? PKV_TYPE_Q5_K : (all6 ? PKV_TYPE_Q6_K : 0));
+    bool any5 = false;
+    for (int i = 0; i < g.n; ++i) any5 = any5 || tw[i] == PKV_TYPE_Q5_K;
+    // (a group that mixes q5_K rows with others — wq / wk q5_K + wv q6_K of a Q5_K_M file — runs as MODE 1: as two launches it cost 16.8 us against 8.2)
+    const int mode = all4 ? PKV_TYPE_Q4_K : (all5 ? PKV_TYPE_Q5_K : (all6 ? PKV_TYPE_Q6_K : (any5 ? 1 : 0)));
     int nwv  = tot >= 256 * 12 ? 16 : (tot >= 256 * 6 ? 8 : 4);
     // (8 waves with exactly 7 row pairs each instead of 16 with 3 or 4 — gate + up at Llama-3-8B sizes — is SLOWER, 16.4 vs 14.3 us: the waves hide
     // each other's load latency; profiles/r03_gemv_shapes.txt)
@@ -771,6 +773,7 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
     if (mode == PKV_TYPE_Q4_K)      PKV_GEMV_PICK_P(PKV_TYPE_Q4_K);
     else if (mode == PKV_TYPE_Q5_K) PKV_GEMV_PICK_P(PKV_TYPE_Q5_K);
     else if (mode == PKV_TYPE_Q6_K) PKV_GEMV_PICK_P(PKV_TYPE_Q6_K);
+    else if (mode == 1)             PKV_GEMV_PICK_P(1);
     else                            PKV_GEMV_PICK_P(0);
     PKV_HIP(hipGetLastError());
     return PKV_OK;

@@ -111,10 +111,8 @@ class LlamaDecoder:
         return n
 
     # ---- products ------------------------------------------------------------------------------------------------------------
-    def _kq(self, names, silu=False) -> bool:
+    def _kq(self, names) -> bool:
         ts = [self.w[n][1] for n in names]
-        if silu and len({(t & ~PACKED) == Q5_K for t in ts}) != 1:      # SiLU(gate) * up in one launch: both q5_K or neither
-            return False
         return (all((t & ~PACKED) in _KQ for t in ts) and all(self.w[n][2][0] % 256 == 0 and self.w[n][2][1] % 2 == 0 for n in names)
                 and len({t & PACKED for t in ts}) == 1)
 
@@ -124,7 +122,7 @@ class LlamaDecoder:
         ws = [self.w[n] for n in names]
         K = ws[0][2][0]
         nw = self.w[norm][0].view(self.torch.float32) if norm is not None else None
-        if self._kq(names, silu) and (nw is None or K <= 8192):
+        if self._kq(names) and (nw is None or K <= 8192):
             # image: the column as the q8_K activation image its producer left (the attention merge launch: pkv_attn_args::out_image)
             gemv_q([w[0] for w in ws], [w[1] for w in ws], [w[2][1] for w in ws], K, image if nw is None else None, outs, residual=residual, silu_mul=silu,
                    x=x_f32, norm_w=nw, eps=self.eps)

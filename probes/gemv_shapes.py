@@ -34,9 +34,9 @@ SHAPES = [  # name, [(type, M)], K, norm, residual, silu
     ("down q6_K (+residual)", [(14, 4096)], 14336, False, True, False),
     ("lm_head q6_K (norm)", [(14, 128256)], 4096, True, False, False),
 ]
-SHAPES_Q5 = [  # --q5: the same layer in the tensor mix of a Q5_K_M file (block_q5_K rows stay in GGUF order: no packed arm for them)
+SHAPES_Q5 = [  # --q5: the same layer in the tensor mix of a Q5_K_M file
     ("wq+wk+wv q5_K (norm)", [(13, 4096), (13, 1024), (13, 1024)], 4096, True, False, False),
-    ("wq+wk q5_K + wv q6_K (norm; two launches)", [(13, 4096), (13, 1024), (14, 1024)], 4096, True, False, False),
+    ("wq+wk q5_K + wv q6_K (norm)", [(13, 4096), (13, 1024), (14, 1024)], 4096, True, False, False),
     ("wo q5_K (+residual)", [(13, 4096)], 4096, False, True, False),
     ("gate+up q5_K (norm, SwiGLU)", [(13, 14336), (13, 14336)], 4096, True, False, True),
     ("down q5_K (+residual)", [(13, 4096)], 14336, False, True, False),
@@ -80,11 +80,11 @@ def main():
                     for i in range(n_launch):
                         w = ws[i % n_buf]
                         if silu:
-                            m.gemv_q(w, [t | (fl if t != 13 else 0) for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], silu_mul=True, x=x, norm_w=nw, eps=1e-5)
+                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], silu_mul=True, x=x, norm_w=nw, eps=1e-5)
                         elif resid:
-                            m.gemv_q(w, [t | (fl if t != 13 else 0) for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], residual=outs[0], x=x)
+                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, [outs[0]], residual=outs[0], x=x)
                         else:
-                            m.gemv_q(w, [t | (fl if t != 13 else 0) for t, _ in mats], [M for _, M in mats], K, None, outs, x=x, norm_w=nw, eps=1e-5)
+                            m.gemv_q(w, [t | fl for t, _ in mats], [M for _, M in mats], K, None, outs, x=x, norm_w=nw, eps=1e-5)
                 run(); torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st):

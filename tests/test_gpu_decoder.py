@@ -116,8 +116,8 @@ def _q8k_round(x):
 
 @pytest.mark.parametrize("wtype,k_mix", [(13, True), (13, False)])
 def test_q5_K_model_first_token_against_exact_arithmetic(pkv, tmp_path, wtype, k_mix):
-    """the tensor mix of a Q5_K_M file (block_q5_K + block_q6_K; r03: q5_K rows in the decode-step products, MODE 13 of csrc/pkv_gemv.hip, the wq / wk / wv
-    group as one launch per run of like rows) through the own host loop: with ONE cell in the cache attention is the identity on V, so the step is a chain
+    """the tensor mix of a Q5_K_M file (block_q5_K + block_q6_K; r03: q5_K rows in the decode-step products, MODES 13 / 1 of csrc/pkv_gemv.hip, the wq / wk / wv
+    group of mixed row types in one launch) through the own host loop: with ONE cell in the cache attention is the identity on V, so the step is a chain
     of products this test restates in f64 on the numpy-dequantized weights (dequantizers bit-equal to the reference's, tests/test_gguf.py) with each
     activation column rounded to the reference's q8_K integers — the logits must agree to f32-accumulation noise, eagerly and as a captured graph"""
     from llama_cpp_test_amd import gguf_synth as G

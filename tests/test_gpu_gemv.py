@@ -97,7 +97,7 @@ def test_gemv_single(pkv, tname, M, K):
 @pytest.mark.parametrize("types,Ms,K", [(("q4_K", "q4_K", "q4_K"), (4096, 1024, 1024), 4096), (("q4_K", "q4_K", "q6_K"), (4096, 1024, 1024), 4096),
                                         (("q6_K", "q4_K"), (64, 130), 768), (("q4_K", "q6_K", "q4_K"), (2, 4, 6), 256),
                                         (("q5_K", "q5_K", "q6_K"), (4096, 1024, 1024), 4096), (("q5_K", "q5_K", "q5_K"), (4096, 1024, 1024), 4096),
-                                        (("q6_K", "q5_K", "q4_K"), (64, 130, 32), 768), (("q5_K", "q6_K", "q5_K"), (2, 4, 6), 256)])
+                                        (("q6_K", "q5_K", "q4_K"), (64, 130, 32), 768), (("q5_K", "q6_K", "q5_K"), (2, 4, 6), 256), (("q4_K", "q5_K"), (4096, 4096), 14336)])
 def test_gemv_multi_equals_single(pkv, types, Ms, K):
     """products that share the activation image in ONE launch == the separate launches, bit for bit, mixed weight types included"""
     from llama_cpp_test_amd import gguf_synth as G
@@ -113,7 +113,7 @@ def test_gemv_multi_equals_single(pkv, types, Ms, K):
         assert torch.equal(y, one)
 
 
-@pytest.mark.parametrize("tg,tu,M,K", [("q4_K", "q4_K", 14336, 4096), ("q4_K", "q6_K", 300, 1024), ("q5_K", "q5_K", 14336, 4096), ("q5_K", "q5_K", 300, 1024)])
+@pytest.mark.parametrize("tg,tu,M,K", [("q4_K", "q4_K", 14336, 4096), ("q4_K", "q6_K", 300, 1024), ("q5_K", "q5_K", 14336, 4096), ("q5_K", "q5_K", 300, 1024), ("q5_K", "q6_K", 300, 1024), ("q4_K", "q5_K", 1024, 4096)])
 def test_gemv_swiglu(pkv, tg, tu, M, K):
     """gate + up + SiLU(gate) * up in one launch == silu(W_gate x) * (W_up x) of the separate products"""
     from llama_cpp_test_amd import gguf_synth as G
@@ -179,7 +179,7 @@ def test_gemv_in_kernel_column_equals_separate_launches(pkv, K, norm):
     got = [torch.zeros(M, device="cuda") for _ in range(2)]
     pkv.gemv_q([wq, w6], [12, 14], [M, M], K, None, got, x=x, norm_w=nw, eps=1e-5)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
-    # q5_K rows beside q6_K ones (the wq / wk / wv group of a Q5_K_M file): one launch per run of like rows inside the call, each with the same in-kernel column
+    # q5_K rows beside q6_K ones (the wq / wk / wv group of a Q5_K_M file; MODE 1 of the kernel)
     w5, _ = weights(G, rng, 13, M, K)
     want5 = [torch.zeros(M, device="cuda") for _ in range(3)]
     pkv.gemv_q([w5, w6, w5], [13, 14, 13], [M, M, M], K, img, want5)

@@ -33,7 +33,7 @@ def test_pack_matches_host_and_round_trips(pkv, tname, M, K):
                                         (("q4_K", "q4_K", "q6_K"), (4096, 1024, 1024), 4096), (("q4_K", "q6_K", "q4_K"), (2, 4, 6), 256),
                                         (("q6_K", "q4_K"), (64, 130), 768), (("q4_K",), (1030,), 768), (("q6_K",), (16032,), 4096), (("q4_K",), (512,), 28672),
                                         (("q5_K",), (4096,), 4096), (("q5_K",), (4096,), 14336), (("q5_K", "q5_K", "q5_K"), (4096, 1024, 1024), 4096), (("q5_K", "q5_K", "q6_K"), (4096, 1024, 1024), 4096),
-                                        (("q5_K", "q5_K", "q6_K"), (2, 4, 6), 256), (("q5_K",), (1030,), 768), (("q5_K",), (16032,), 4096), (("q5_K",), (512,), 28672)])
+                                        (("q5_K", "q5_K", "q6_K"), (2, 4, 6), 256), (("q6_K", "q5_K", "q4_K"), (64, 130, 32), 768), (("q5_K",), (1030,), 768), (("q5_K",), (16032,), 4096), (("q5_K",), (512,), 28672)])
 def test_gemv_packed_equals_gguf_order(pkv, types, Ms, K):
     from llama_cpp_test_amd import gguf_synth as G
     rng = np.random.default_rng(sum(Ms) + K)
