@@ -3,8 +3,12 @@
 # the bench command and of the end-to-end step, PMC traffic passes (separate, as MI355X_MICROARCH.md prescribes), in-kernel stamps, A/B against the
 # round-1 library, the secondary configurations quoted in DESIGN.md.  Summarise afterwards with probes/r03_summarize.py (dev container).
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-O=gpurun_out/r03_final; rm -rf $O; mkdir -p $O
+O=gpurun_out/r03_final; mkdir -p $O
+# PART=a: tests, smoke, bench, rocprof / PMC passes, stamps.  PART=b: secondary configurations, product / prefill probes, the reference runtime and harness.
+# (one gpurun call is limited to 20 minutes; the two halves write into the same directory, merged back by gpurun)
+PART=${PART:-ab}
 step() { echo "== $1" | tee -a $O/steps.log; }
+if [[ $PART == *a* ]]; then
 step "gpu tests"
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
 tail -2 $O/gpu_tests.log
@@ -26,6 +30,8 @@ tail -1 $O/e2e_stats.log
 step "stamps"
 timeout -k 10 300 python3 probes/decode_stamps.py --mode 2 > $O/stamps_8b.txt 2>&1 || tail -3 $O/stamps_8b.txt
 timeout -k 10 300 python3 probes/decode_stamps.py --mode 2 --model 70b --ctx 16384 > $O/stamps_70b.txt 2>&1 || tail -3 $O/stamps_70b.txt
+fi
+if [[ $PART == *b* ]]; then
 step "secondary configurations"
 for cfg in "nseq32:--n-seq 32" "nseq32_ctx640:--n-seq 32 --ctx 640" "q8_0:--kv-type q8_0" "q4_0:--kv-type q4_0" "q8_0_nseq32:--n-seq 32 --kv-type q8_0" "q4_0_nseq32:--n-seq 32 --kv-type q4_0" "70b_ctx16384:--model 70b --ctx 16384" "two_call:--two-call" "fused_merge:--fused-merge" "one_tile_nseq32:--n-seq 32" "one_tile_70b:--model 70b --ctx 16384"; do
   n=${cfg%%:*}; f=${cfg#*:}
@@ -36,6 +42,8 @@ done
 step "gemv shapes / gemm / batched bench / prefill"
 unset PKV_DECODE_NTILE
 timeout -k 10 400 python3 probes/gemv_shapes.py --packed > $O/gemv_shapes.txt 2>&1; grep -v amdgpu.ids $O/gemv_shapes.txt
+timeout -k 10 300 python3 probes/gemv_shapes.py --q5 --packed > $O/gemv_shapes_q5.txt 2>&1; grep -v amdgpu.ids $O/gemv_shapes_q5.txt
+{ timeout -k 10 300 python3 probes/e2e_profile.py --wtype q5_K --steps 30; timeout -k 10 300 python3 probes/e2e_profile.py --wtype q5_K --steps 30 --no-pack; } 2>&1 | grep -v amdgpu.ids > $O/e2e_q5km.txt; cat $O/e2e_q5km.txt
 timeout -k 10 300 python3 probes/gemm_bench.py > $O/gemm_bench.txt 2>&1; grep -v amdgpu.ids $O/gemm_bench.txt
 timeout -k 10 300 python3 probes/batched_bench.py > $O/batched_bench.txt 2>&1; timeout -k 10 300 python3 probes/batched_bench.py --pp-f16 >> $O/batched_bench.txt 2>&1; timeout -k 10 300 python3 probes/batched_bench.py --kv-type q8_0 >> $O/batched_bench.txt 2>&1; grep -v amdgpu.ids $O/batched_bench.txt
 timeout -k 10 300 python3 probes/bench_prefill.py > $O/bench_prefill.txt 2>&1; tail -6 $O/bench_prefill.txt
@@ -51,6 +59,7 @@ for op in FLASH_ATTN_EXT ROPE ROPE_BACK CPY CONT RMS_NORM ADD MUL SILU MUL_MAT S
   echo "$op OK=$(grep -c '): OK' $O/tbo_$op.txt) FAIL=$(grep -c FAIL $O/tbo_$op.txt) not-supported=$(grep -c 'not supported' $O/tbo_$op.txt)"
 done
 unset GGML_BACKEND_PATH
+fi
 find $O -name "*_agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 grep -l "Memory access fault" $O/*.log $O/*.txt $O/*.err 2>/dev/null && { echo "GPU FAULT in the files above"; exit 1; }
 du -sh $O

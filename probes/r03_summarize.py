@@ -37,7 +37,7 @@ def counters(path, key):
 cp(os.path.join(SRC, "bench_n1.json"), f"{tag}_bench_n1.json")
 cp(one("stats/**/*kernel_stats.csv"), f"{tag}_bench_kernel_stats.csv")
 cp(one("e2e_stats/**/*kernel_stats.csv"), f"{tag}_e2e_kernel_stats.csv")
-for a, b in (("timeline.txt", "bench_timeline.txt"), ("stamps_8b.txt", "decode_stamps_8b.txt"), ("stamps_70b.txt", "decode_stamps_70b.txt"), ("gemv_shapes.txt", "gemv_shapes.txt"), ("gemm_bench.txt", "gemm_bench.txt"), ("batched_bench.txt", "batched_bench.txt"),
+for a, b in (("timeline.txt", "bench_timeline.txt"), ("stamps_8b.txt", "decode_stamps_8b.txt"), ("stamps_70b.txt", "decode_stamps_70b.txt"), ("gemv_shapes.txt", "gemv_shapes.txt"), ("gemv_shapes_q5.txt", "gemv_shapes_q5.txt"), ("e2e_q5km.txt", "e2e_q5km.txt"), ("gemm_bench.txt", "gemm_bench.txt"), ("batched_bench.txt", "batched_bench.txt"),
              ("bench_prefill.txt", "bench_prefill.txt"), ("prefill_pmc.txt", "prefill_pmc.txt"), ("ablate.txt", "prefill_ablation.txt"), ("prefill_stamps.txt", "prefill_stamps.txt"), ("e2e_8b_q4k_plugin.txt", "e2e_8b_q4k_plugin.txt"), ("tinyllama_e2e_plugin.txt", "tinyllama_e2e_plugin.txt"),
              ("gpu_tests.log", "gpu_tests.txt"), ("smoke.log", "smoke.txt")):
     cp(os.path.join(SRC, a), f"{tag}_{b}")
