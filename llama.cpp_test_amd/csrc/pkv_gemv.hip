@@ -349,7 +349,7 @@ template <bool NT> __device__ __forceinline__ uint4 ld16w(const unsigned char * 
                 s0 += o_.x; s1 += o_.y;                                                                                                        \
             }                                                                                                                                  \
             if (lane == 0 && live && kpart == 0) {                                                                                             \
-                if (a.silu_mul) {                                                                                                              \
+                if (a_silu) {                                                                                                                  \
                     a.y[0][m0_] = s0 / (1.0f + expf(-s0)) * s1;                                                                                \
                 } else {                                                                                                                       \
                     float * y = mi_ == 0 ? a.y[0] : (mi_ == 1 ? a.y[1] : a.y[2]);                                                              \
@@ -382,6 +382,38 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict
     constexpr int UI = 1;
     constexpr int NT = 64 * NWV;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    // The by-value struct spans four 64-byte lines of the kernel-argument segment, and left to itself hipcc fetched its fields where they are used:
+    // rp_end[] (line 1), then — behind the division of the row-pair count — silu_mul (line 2), then w[] (line 0) and type[]: three DEPENDENT scalar-
+    // cache misses between the launch and the first weight request (ISA audit of the r03 build).  One field of each line is requested up here in one
+    // batch and pinned behind the column's vector loads; the later scalar loads of their neighbours hit the scalar cache.  (Pinning all thirteen
+    // dwords instead overflowed the SGPR file: spills to scratch at kernel entry.)
+    // Measured (profiles/r03_gemv_args_early_ab.txt): the products' times do not move (7.13 vs 7.10, 5.30 vs 5.35, 14.61 vs 14.60, 14.21 vs 14.47 us); end to end 606-607
+    // against 601 tok/s in one box — the scalar loads were not what the ramp waits for.  Kept: it costs nothing.
+#ifndef PKV_GEMV_ARGS_EARLY
+#define PKV_GEMV_ARGS_EARLY 1
+#endif
+#if PKV_GEMV_ARGS_EARLY
+    const int e0 = a.rp_end[0], e1 = a.rp_end[1], e2 = a.rp_end[2], a_silu = a.silu_mul;
+    const char * const a_w0 = a.w[0];
+    const int grid = (int) gridDim.x;      // (an implicit argument behind the struct: the fourth line)
+#define a_w1 a.w[1]
+#define a_w2 a.w[2]
+#define a_t0 a.type[0]
+#define a_t1 a.type[1]
+#define a_t2 a.type[2]
+    __builtin_amdgcn_sched_barrier(0);     // (the requests stay up here; the wait for them comes behind the column's vector loads, at the pin below)
+#else
+#define e2 a.rp_end[2]
+#define a_silu a.silu_mul
+#define a_w0 a.w[0]
+#define a_w1 a.w[1]
+#define a_w2 a.w[2]
+#define a_t0 a.type[0]
+#define a_t1 a.type[1]
+#define a_t2 a.type[2]
+    const int e0 = a.rp_end[0], e1 = a.rp_end[1];
+    const int grid = (int) gridDim.x;
+#endif
     // The column's own loads go out FIRST.  Vector-memory results return in issue order (one vmcnt counter per wave) and a CU serves its
     // requests first come, first served: r02 requested two units of weights per wave (192 KB per CU at 16 waves) ahead of the column, so the
     // column (16-57 KB, L2-resident) arrived behind ALL of them — the norm / quantize prologue started 5-8 us into the launch and every dot
@@ -426,13 +458,16 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict
         if ((int) threadIdx.x < (aK >> 5)) bpre = reinterpret_cast<const int *>(aimg + aK + (aK >> 8) * 4)[threadIdx.x];
     }
     __builtin_amdgcn_sched_barrier(0);
+#if PKV_GEMV_ARGS_EARLY
+    asm volatile("" :: "s"(e0), "s"(e1), "s"(e2), "s"(a_silu), "s"(a_w0), "s"(grid));
+#endif
     constexpr int TAIL = (MODE == PKV_TYPE_Q4_K || MODE == PKV_TYPE_Q5_K) ? 0 : 1;                // record tail format (per-32 sums | per-16 sums as int16)
     const int gpr = aK >> 6;
     uint32_t * sq = g_lds;                                           // gpr records of REC dwords
     __shared__ double sred[32];                                       // sums of squares per 256-element block (norm prologue)
-    const int total_rp = a.rp_end[0] > a.rp_end[1] ? (a.rp_end[0] > a.rp_end[2] ? a.rp_end[0] : a.rp_end[2]) : (a.rp_end[1] > a.rp_end[2] ? a.rp_end[1] : a.rp_end[2]);
+    const int total_rp = e0 > e1 ? (e0 > e2 ? e0 : e2) : (e1 > e2 ? e1 : e2);
     __shared__ float2 sPart[NWV / 2];
-    const int grid = (int) gridDim.x, stride = grid * (NWV / KS);
+    const int stride = grid * (NWV / KS);
     const int kpart = KS == 2 ? (wv & 1) : 0;
     const int mine = (int) blockIdx.x + grid * (KS == 2 ? (wv >> 1) : wv);
     const bool live = mine < total_rp;                                // a surplus wave shadows the last row pair up to the stores: no early exit before the barriers
@@ -444,20 +479,19 @@ __global__ void __launch_bounds__(64 * NWV) gemv_kernel(const float * __restrict
     const int n_f0 = (f_half + 64 * UI - 1) / (64 * UI);              // units per row pair (per half)
     const int n_it = n_rp * n_f0;
     // kernel-argument arrays are only ever indexed with constants (a dynamic index would move the struct to scratch)
-    const int e0 = a.rp_end[0], e1 = a.rp_end[1];
     auto rows_of = [&](int rp, const char *& r0, const char *& r1, int & type0, int & type1, int & mi, int64_t & m0) {
         rp = __builtin_amdgcn_readfirstlane(rp);                      // wave-uniform by construction: the pointer arithmetic stays on the scalar unit
         mi = rp < e0 ? 0 : (rp < e1 ? 1 : 2);
         const int rpl = rp - (mi == 0 ? 0 : (mi == 1 ? e0 : e1));
         const char * w0, * w1;
-        if (a.silu_mul) { m0 = rp; w0 = a.w[0]; w1 = a.w[1]; type0 = a.type[0]; type1 = a.type[1]; mi = 0; }
+        if (a_silu) { m0 = rp; w0 = a_w0; w1 = a_w1; type0 = a_t0; type1 = a_t1; mi = 0; }
         else {
             m0 = 2 * (int64_t) rpl;
-            w0 = w1 = mi == 0 ? a.w[0] : (mi == 1 ? a.w[1] : a.w[2]);
-            type0 = type1 = mi == 0 ? a.type[0] : (mi == 1 ? a.type[1] : a.type[2]);
+            w0 = w1 = mi == 0 ? a_w0 : (mi == 1 ? a_w1 : a_w2);
+            type0 = type1 = mi == 0 ? a_t0 : (mi == 1 ? a_t1 : a_t2);
         }
         r0 = w0 + (size_t) m0 * row_size(type0, aK);
-        r1 = w1 + (size_t) (a.silu_mul ? m0 : m0 + 1) * row_size(type1, aK);
+        r1 = w1 + (size_t) (a_silu ? m0 : m0 + 1) * row_size(type1, aK);
     };
     float acc0 = 0.0f, acc1 = 0.0f;
     PKV_UNIT_DECL(A) PKV_UNIT_DECL(B)
