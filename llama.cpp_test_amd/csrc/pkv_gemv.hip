@@ -658,21 +658,24 @@ template <int T, bool PK = false>
 __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int32_t * ids, float * out, int64_t K, int64_t n_rows_w) {
     const int gpr = (int) (K >> 6);
     auto pk = [&](size_t o) -> size_t { if constexpr (!PK) return o; else return T == PKV_TYPE_Q4_K ? pk_offset_q4k(gpr, o) : (T == PKV_TYPE_Q5_K ? pk_offset_q5k(gpr, o) : pk_offset_q6k(gpr, o)); };
+    // blockIdx.y = slice of the row: one looked-up row of a decode step is spread over K / 256 workgroups (as ONE workgroup walking 4096 elements with
+    // dependent byte loads it took 12.5 us per token, profiles/r03_e2e_kernel_stats.csv)
+    const int64_t k_first = (int64_t) blockIdx.y * 256 + threadIdx.x, k_step = 256 * (int64_t) gridDim.y;
     const int64_t r = ids[blockIdx.x];
     float * o = out + (size_t) blockIdx.x * K;
-    if (r < 0 || r >= n_rows_w) { for (int64_t k = threadIdx.x; k < K; k += 256) o[k] = 0.0f; return; }
+    if (r < 0 || r >= n_rows_w) { for (int64_t k = k_first; k < K; k += k_step) o[k] = 0.0f; return; }
     const unsigned char * row = reinterpret_cast<const unsigned char *>(w) + (size_t) r * row_size(T, K);
     if constexpr (T == PKV_TYPE_F32) {
-        for (int64_t k = threadIdx.x; k < K; k += 256) o[k] = reinterpret_cast<const float *>(row)[k];
+        for (int64_t k = k_first; k < K; k += k_step) o[k] = reinterpret_cast<const float *>(row)[k];
     } else if constexpr (T == PKV_TYPE_F16) {
-        for (int64_t k = threadIdx.x; k < K; k += 256) o[k] = (float) reinterpret_cast<const _Float16 *>(row)[k];
+        for (int64_t k = k_first; k < K; k += k_step) o[k] = (float) reinterpret_cast<const _Float16 *>(row)[k];
     } else if constexpr (T == PKV_TYPE_Q8_0) {
-        for (int64_t k = threadIdx.x; k < K; k += 256) {
+        for (int64_t k = k_first; k < K; k += k_step) {
             const unsigned char * b = row + (k >> 5) * 34;
             o[k] = h2f(*reinterpret_cast<const uint16_t *>(b)) * (float) (int) (signed char) b[2 + (k & 31)];
         }
     } else if constexpr (T == PKV_TYPE_Q4_K) {      // dequantize_row_q4_K (/ref/ggml/src/ggml-quants.c:1280-1302)
-        for (int64_t k = threadIdx.x; k < K; k += 256) {
+        for (int64_t k = k_first; k < K; k += k_step) {
             const size_t b = (size_t) (k >> 8) * 144;                       // GGUF-order offset of the block inside the row
             const int e = (int) (k & 255), j = e >> 5, l = e & 31;           // sub-block j, element l
             const float d = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b))), dmin = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b + 2)));
@@ -686,7 +689,7 @@ __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int
             o[k] = d1 * (float) q - m1;
         }
     } else if constexpr (T == PKV_TYPE_Q5_K) {      // dequantize_row_q5_K (:1482-1507)
-        for (int64_t k = threadIdx.x; k < K; k += 256) {
+        for (int64_t k = k_first; k < K; k += k_step) {
             const size_t b = (size_t) (k >> 8) * 176;                       // GGUF-order offset of the block inside the row
             const int e = (int) (k & 255), j = e >> 5, l = e & 31;
             const float d = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b))), dmin = h2f(*reinterpret_cast<const uint16_t *>(row + pk(b + 2)));
@@ -700,7 +703,7 @@ __global__ void __launch_bounds__(256) get_rows_kernel(const char * w, const int
             o[k] = d1 * (float) q - m1;
         }
     } else {                                         // q6_K: dequantize_row_q6_K (:1690-1719)
-        for (int64_t k = threadIdx.x; k < K; k += 256) {
+        for (int64_t k = k_first; k < K; k += k_step) {
             const size_t b = (size_t) (k >> 8) * 210;
             const int e = (int) (k & 255), n = e >> 7, r128 = e & 127, j = r128 >> 5, l = r128 & 31;
             const unsigned char lq = row[pk(b + 64 * n + l + 32 * (j & 1))], hq = row[pk(b + 128 + 32 * n + l)];
@@ -815,7 +818,8 @@ int launch_gemv(const pkv_gemv & g, hipStream_t st) {
 
 int launch_get_rows(const void * w, int type_w, const int32_t * ids, float * out, int64_t n_ids, int64_t K, int64_t n_rows_w, hipStream_t st) {
     if (n_ids == 0) return PKV_OK;
-    const dim3 grid((unsigned) n_ids);
+    const int64_t slices = std::max<int64_t>(1, std::min<int64_t>((K + 255) / 256, 2048 / n_ids));   // few rows: cut them; a prompt's rows fill the chip as they are
+    const dim3 grid((unsigned) n_ids, (unsigned) slices);
     if (type_w == (PKV_TYPE_Q4_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q4_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
     if (type_w == (PKV_TYPE_Q5_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q5_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
     if (type_w == (PKV_TYPE_Q6_K | PKV_TYPE_PACKED)) { hipLaunchKernelGGL((get_rows_kernel<PKV_TYPE_Q6_K, true>), grid, dim3(256), 0, st, (const char *) w, ids, out, K, n_rows_w); PKV_HIP(hipGetLastError()); return PKV_OK; }
