@@ -438,7 +438,7 @@ int pkv_mul_mat_multi(int n, const void * const * w, int type_w, const float * x
 
 /* ---- decode-step weight products (one activation column) for K-quant weights: csrc/pkv_gemv.hip ------------------------------
  * The activation column is quantized once to int8 per 32 elements (the reference's CPU backend quantizes it to q8_K per 256 before a
- * q4_K / q6_K product, /ref/ggml/src/ggml-cpu/ggml-cpu.c:7467-7640) into an "activation image" of pkv_act_image_bytes(K) bytes:
+ * q4_K / q5_K / q6_K product, /ref/ggml/src/ggml-cpu/ggml-cpu.c:7467-7640) into an "activation image" of pkv_act_image_bytes(K) bytes:
  * by pkv_quantize_act, or by pkv_rms_norm_mul_q (rms_norm(x [+ res]) * w straight into the image: build_norm feeding a product).
  * pkv_gemv_q then streams the rows of up to three matrices that share the column in ONE launch (wq + wk + wv; gate + up), with the
  * epilogues a llama layer needs: y = residual + W x (attn_out / ffn_down onto the residual stream, :4120,:4160) or

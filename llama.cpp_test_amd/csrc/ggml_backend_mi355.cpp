@@ -825,7 +825,7 @@ ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {
         if (i1 == users.by_src.end() || i1->second.size() != 1 || i2 == users.by_src.end() || i2->second.empty() || i2->second.size() > 3) return false;
         for (int k : i2->second) {
             const ggml_tensor * t = ggml_graph_node(g, k);
-            if (t->op != GGML_OP_MUL_MAT || t->src[1] != n2 || !t->src[0] || (t->src[0]->type != GGML_TYPE_Q4_K && t->src[0]->type != GGML_TYPE_Q6_K) || t->src[0]->ne[1] % 2 != 0) return false;
+            if (t->op != GGML_OP_MUL_MAT || t->src[1] != n2 || !t->src[0] || (t->src[0]->type != GGML_TYPE_Q4_K && t->src[0]->type != GGML_TYPE_Q5_K && t->src[0]->type != GGML_TYPE_Q6_K) || t->src[0]->ne[1] % 2 != 0) return false;
         }
         return true;
     };

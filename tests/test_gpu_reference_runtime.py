@@ -31,7 +31,7 @@ MODELS = {
                        rope_freqs=True, wtype=12),
     # head size 256 (Gemma-like geometry in a llama graph), gqa 2, f16 weights: outside the paged kernels' geometries -> pkv_flash_attn_ext_flat
     "hs256": dict(n_layer=2, n_embd=1024, n_head=4, n_head_kv=2, n_ff=1024, n_vocab=96, n_ctx=1024, rope_freq_base=10000.0, seed=81),
-    # ... and with the tensor mix of a Q5_K_M file (q5_K + q6_K; r03): every q5_K product, one column or many, through the MFMA product
+    # ... and with the tensor mix of a Q5_K_M file (q5_K + q6_K; r03): q5_K WEIGHTS tensors packed at set_tensor; one column: the decode-step product (MODES 13 / 1 of csrc/pkv_gemv.hip, the wq / wk / wv group of mixed types in one launch), many: the MFMA product
     "llama3_q5km": dict(n_layer=2, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2048, n_vocab=128, n_ctx=2048, rope_freq_base=500000.0, seed=80,
                         rope_freqs=True, wtype=13, k_mix=True),
 }
