@@ -9,6 +9,6 @@ for a in "$@"; do
   if [ "$a" = stamps ]; then FLAG="-DPKV_GEMV_STAMPS=2"; elif [ "$a" = stamps1 ]; then FLAG="-DPKV_GEMV_STAMPS=1"; else FLAG="-DPKV_GEMV_ABLATE=$a"; fi
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=8 $FLAG -c pkv_gemv.hip -o /tmp/gemv_abl$a.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../probes/bin/libpkv_gemv_abl$a.so build/pkv_capi.cpp.o build/pkv_cache.cpp.o build/pkv_attn_decode.hip.o \
-        build/pkv_attn_prefill.hip.o build/pkv_kv_ops.hip.o build/pkv_layer_ops.hip.o /tmp/gemv_abl$a.o build/pkv_gemm.hip.o ) &
+        build/pkv_attn_prefill.hip.o build/pkv_attn_flat.hip.o build/pkv_kv_ops.hip.o build/pkv_layer_ops.hip.o /tmp/gemv_abl$a.o build/pkv_gemm.hip.o ) &
 done
 wait
